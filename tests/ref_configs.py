@@ -1,0 +1,43 @@
+"""The two PM-VAE configurations the hot path is checked on, as plain dicts.
+
+Values restate configs/pm_vae_mnist.py:4-50 and configs/pm_vae_gas.py:4-59 of the reference
+(data, not code); the oracle takes plain dicts so that it does not depend on the product's
+ConfigDict.  tests/test_configs.py checks that the product's configs/*.py agree with these.
+"""
+
+
+def pm_vae_mnist():
+    return {
+        "data": {"dataset": "mnist", "train_split": "train", "validation_split": "test",
+                 "train_batch_size": 256, "val_batch_size": 256, "mask_generator": "MNISTMaskGenerator"},
+        "model": {
+            "latent_dim": 32, "encoder_net": "ConvEncoder", "decoder_net": "ConvDecoder",
+            "posterior_dist": "TriLGaussian", "partial_posterior_dist": "AutoregressiveGMM",
+            "decoder_dist": "Bernoulli",
+            "encoder_net_config": {"conv_layers": [(32, 5, 1), (32, 5, 2), (64, 5, 1), (64, 5, 2), (128, 7, 1)]},
+            "decoder_net_config": {"conv_layers": [(64, 7, 1), (64, 5, 2), (32, 5, 1), (32, 5, 2), (32, 5, 1), (1, 5, 1)]},
+        },
+        "steps": 80000, "validation_freq": 1000,
+        "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 5000},
+    }
+
+
+def pm_vae_gas():
+    return {
+        "data": {"dataset": "gas", "train_split": "train", "validation_split": "val",
+                 "train_batch_size": 512, "val_batch_size": 512, "training_noise": 0.001,
+                 "mask_generator": "BernoulliMaskGenerator"},
+        "model": {
+            "latent_dim": 16, "encoder_net": "ResidualMLP", "decoder_net": "ResidualMLP",
+            "decoder_dist": "IdentityGaussian", "posterior_dist": "TriLGaussian",
+            "decoder_dist_config": {"event_size": 8},
+            "masked_posterior_dist": "AutoregressiveGMM",
+            "masked_posterior_config": {"hidden_units": 256, "residual_blocks": 3},
+            "encoder_net_config": {"residual_blocks": 2, "hidden_units": 256, "layer_norm": False},
+            "decoder_net_config": {"residual_blocks": 2, "hidden_units": 256, "layer_norm": False},
+            "matching_ll_stop_gradients": True,
+        },
+        "beta": {"schedule": "cyclic", "low_value": 0.0, "high_value": 1.0, "period": 50000, "delay": 1000},
+        "steps": 200000, "validation_freq": 1000, "save_final_state": True, "weight_decay": 0.00001,
+        "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 5000},
+    }

@@ -1,0 +1,186 @@
+"""Known-answer tests that pin the CPU oracle (the reference ships no vectors, so
+these are self-derived from the cited reference lines and the published third-party semantics)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import naive_numpy as nn_
+from oracle import pm_vae_oracle as O
+
+torch.set_default_dtype(torch.float64)
+
+
+def test_fill_triangular_tfp_docstring_example():
+    # (i) TFP docstring: fill_triangular([1..6]) = [[4,0,0],[6,5,0],[3,2,1]]
+    got = O.fill_triangular(torch.arange(1.0, 7.0))
+    assert got.tolist() == [[4, 0, 0], [6, 5, 0], [3, 2, 1]]
+    assert nn_.fill_triangular(np.arange(1.0, 7.0)).tolist() == got.tolist()
+    v = np.random.default_rng(0).normal(size=528)
+    assert np.array_equal(nn_.fill_triangular(v), O.fill_triangular(torch.tensor(v)).numpy())
+    # every parameter lands in the lower triangle exactly once
+    idx = nn_.fill_triangular(np.arange(1.0, 529.0))
+    assert sorted(idx[np.tril_indices(32)].tolist()) == list(range(1, 529))
+
+
+def test_cyclic_beta_by_hand():
+    # (ii) utils.py:127-134 with low 0, high 1, period 50000, delay 1000 (configs/pm_vae_gas.py:41-46)
+    f = lambda s: O.cyclical_annealing_beta(s, 0.0, 1.0, 50000, 1000)
+    assert f(0) == 0.0 and f(999) == 0.0 and f(1000) == 0.0
+    assert f(13500) == pytest.approx(0.5)
+    assert f(26000) == 1.0 and f(50999) == 1.0
+    assert f(51000) == 0.0
+
+
+def test_lr_schedule():
+    # (iii) lr(5000) = 1e-3 * 0.9
+    cfg = {"lr_schedule": {"init_value": 1e-3, "decay_rate": 0.9, "transition_steps": 5000}}
+    assert O.lr_value(cfg, 0) == 1e-3
+    assert O.lr_value(cfg, 5000) == pytest.approx(9e-4)
+
+
+def test_tril_kl_and_log_prob_against_torch_distributions():
+    # (iv) closed forms vs torch.distributions (an independent implementation)
+    g = torch.Generator().manual_seed(0)
+    prm = torch.randn(5, 560, generator=g)
+    loc, tril = prm[:, :32], O.fill_scale_tril(prm[:, 32:])
+    q = torch.distributions.MultivariateNormal(loc, scale_tril=tril)
+    p = torch.distributions.MultivariateNormal(torch.zeros(32), scale_tril=torch.eye(32))
+    assert torch.allclose(O.mvn_tril_kl_to_std_normal(loc, tril), torch.distributions.kl_divergence(q, p), rtol=1e-10)
+    z = torch.randn(5, 32, generator=g)
+    assert torch.allclose(O.mvn_tril_log_prob(z, loc, tril), q.log_prob(z), rtol=1e-10)
+    # diag = softplus(raw) + 1e-5 > 0
+    assert (torch.diagonal(tril, dim1=-2, dim2=-1) > 0).all()
+
+
+def test_bernoulli_ll_real_valued_targets():
+    # (v) == -BCEWithLogits for x in [0, 1]
+    g = torch.Generator().manual_seed(1)
+    l, x = torch.randn(4, 50, generator=g) * 3, torch.rand(4, 50, generator=g)
+    ref = -torch.nn.functional.binary_cross_entropy_with_logits(l, x, reduction="none")
+    assert torch.allclose(O.bernoulli_log_prob(l, x), ref, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,pad,size", [(1, 3, 5, 1, "SAME", 9), (2, 4, 5, 2, "SAME", 8),
+                                                    (3, 2, 5, 2, "SAME", 7), (2, 3, 7, 1, "VALID", 7),
+                                                    (2, 2, 4, 2, "SAME", 8)])
+def test_conv2d_vs_naive(cin, cout, k, s, pad, size):
+    rng = np.random.default_rng(2)
+    x, w = rng.normal(size=(2, size, size, cin)), rng.normal(size=(k, k, cin, cout))
+    got = O.conv2d(torch.tensor(x), torch.tensor(w), None, s, pad).numpy()
+    np.testing.assert_allclose(got, nn_.conv2d_nhwc(x, w, s, pad), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,pad,size", [(3, 2, 7, 1, "VALID", 1), (2, 3, 5, 2, "SAME", 4),
+                                                    (2, 2, 5, 1, "SAME", 6), (3, 1, 5, 2, "SAME", 7),
+                                                    (2, 3, 4, 2, "SAME", 5)])
+def test_conv2d_transpose_vs_naive(cin, cout, k, s, pad, size):
+    rng = np.random.default_rng(3)
+    x, w = rng.normal(size=(2, size, size, cin)), rng.normal(size=(k, k, cout, cin))
+    got = O.conv2d_transpose(torch.tensor(x), torch.tensor(w), None, s, pad).numpy()
+    want = nn_.conv2d_transpose_nhwc(x, w, s, pad)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+
+
+def test_shapes_mnist():
+    # (vii) 28 -> 28 -> 14 -> 14 -> 7 -> 1 ; decoder 1 -> 7 -> 14 -> 14 -> 28 -> 28 -> 28
+    assert O.same_padding(28, 5, 2) == (1, 2) and O.same_padding(14, 5, 2) == (1, 2)
+    assert O.same_padding(28, 5, 1) == (2, 2) and O.same_padding(28, 4, 2) == (1, 1)
+    assert O.conv_transpose_padding(5, 2, "SAME") == (3, 2)
+    assert O.conv_transpose_padding(5, 1, "SAME") == (2, 2)
+    assert O.conv_transpose_padding(4, 2, "SAME") == (2, 2)
+    assert O.conv_transpose_padding(7, 1, "VALID") == (6, 6)
+    from tests.ref_configs import pm_vae_mnist
+
+    cfg = pm_vae_mnist()
+    shapes = O.param_shapes(cfg["model"], (28, 28, 1))
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    assert n == 2101969
+    p = O.init_params(cfg["model"], (28, 28, 1), seed=1)
+    x = torch.rand(2, 28, 28, 1)
+    h = x
+    sizes = []
+    for i, (f, k, s) in enumerate(cfg["model"]["encoder_net_config"]["conv_layers"]):
+        h = O.conv2d(h, p[f"encoder_net/conv_{i}/w"], None, s, "VALID" if i == 4 else "SAME")
+        sizes.append(h.shape[1])
+    assert sizes == [28, 14, 14, 7, 1]
+    h = torch.rand(2, 1, 1, 32)
+    sizes = []
+    for i, (f, k, s) in enumerate(cfg["model"]["decoder_net_config"]["conv_layers"]):
+        h = O.conv2d_transpose(h, p[f"decoder_net/conv_t_{i}/w"], None, s, "VALID" if i == 0 else "SAME")
+        sizes.append(h.shape[1])
+    assert sizes == [7, 14, 14, 28, 28, 28] and h.shape[-1] == 1
+
+
+def test_gas_param_count():
+    from tests.ref_configs import pm_vae_gas
+
+    shapes = O.param_shapes(pm_vae_gas()["model"], (8,))
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 880697
+
+
+def test_argmm_batched_equals_scan_and_normalises():
+    # (vi) teacher-forced batching == the sequential scan; GMM density integrates to 1
+    from tests.ref_configs import pm_vae_mnist
+
+    cfg = pm_vae_mnist()["model"]
+    p = O.init_params(cfg, (28, 28, 1), seed=4)
+    g = torch.Generator().manual_seed(5)
+    ctx, z = torch.randn(3, 128, generator=g), torch.randn(3, 32, generator=g)
+    a = O.autoregressive_gmm_log_prob(p, "partial_posterior_dist", ctx, z, 32)
+    b = O.autoregressive_gmm_log_prob_batched(p, "partial_posterior_dist", ctx, z, 32)
+    assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    rng = np.random.default_rng(6)
+    logits, means, raw = rng.normal(size=10), rng.normal(size=10), rng.normal(size=10)
+    scales = np.log1p(np.exp(raw)) + 1e-5
+    grid = np.linspace(-30, 30, 200001)
+    dens = np.array([math.exp(nn_.gmm_log_pdf(logits, means, scales, t)) for t in grid[::50]])
+    assert abs(np.trapezoid(dens, grid[::50]) - 1.0) < 1e-6
+    head = torch.tensor(np.concatenate([logits, means, raw]))[None, :]
+    got = O.gmm_log_prob_columns(head, torch.tensor([[0.3]]), 1, 10)
+    assert got.item() == pytest.approx(nn_.gmm_log_pdf(logits, means, scales, 0.3), rel=1e-12)
+
+
+def test_adam_first_step_by_hand():
+    # optax scale_by_adam: first update = g / (|g| + eps) -> p -= lr * sign-ish
+    cfg = {"lr_schedule": {"init_value": 1e-3, "decay_rate": 0.9, "transition_steps": 5000}, "weight_decay": 0.1}
+    p = {"w": torch.tensor([[1.0, -2.0]]), "b": torch.tensor([0.5])}
+    g = {"w": torch.tensor([[0.25, -4.0]]), "b": torch.tensor([2.0])}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    O.adam_update(p, g, m, v, 0, cfg)
+    u_w = np.array([0.25, -4.0]) / (np.abs([0.25, -4.0]) + 1e-8) + 0.1 * np.array([1.0, -2.0])
+    np.testing.assert_allclose(p["w"].numpy()[0], np.array([1.0, -2.0]) - 1e-3 * u_w, rtol=1e-12)
+    np.testing.assert_allclose(p["b"].numpy(), [0.5 - 1e-3 * 2.0 / (2.0 + 1e-8)], rtol=1e-12)  # ndim==1: no decay
+
+
+def test_gradcheck_small_model():
+    # (xiii) autograd of the restatement vs finite differences (float64) on a tiny conv PM-VAE
+    cfg = {"latent_dim": 3, "encoder_net": "ConvEncoder", "decoder_net": "ConvDecoder",
+           "posterior_dist": "TriLGaussian", "partial_posterior_dist": "AutoregressiveGMM",
+           "partial_posterior_dist_config": {"hidden_units": 8, "num_components": 2}, "decoder_dist": "Bernoulli",
+           "encoder_net_config": {"conv_layers": [(2, 3, 2), (4, 4, 1)]},
+           "decoder_net_config": {"conv_layers": [(2, 4, 1), (1, 3, 2)]}}
+    full = {"model": cfg, "lr_schedule": {"init_value": 1e-3, "decay_rate": 0.9, "transition_steps": 5000}}
+    p = O.init_params(cfg, (8, 8, 1), seed=7)
+    g = torch.Generator().manual_seed(8)
+    x, b, eps = torch.rand(2, 8, 8, 1, generator=g), (torch.rand(2, 8, 8, 1, generator=g) > 0.5).double(), torch.randn(2, 3, generator=g)
+    for t in p.values():
+        t.add_(0.05 * torch.randn(t.shape, generator=g))       # non-zero biases
+    leaves = {k: t.clone().requires_grad_(True) for k, t in p.items()}
+    loss, _, _ = O.pm_vae_loss(leaves, full, x, b, eps, 0)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    rng = np.random.default_rng(9)
+    for name, t in p.items():
+        flat = t.reshape(-1)
+        for idx in rng.choice(flat.numel(), size=min(3, flat.numel()), replace=False):
+            old = flat[idx].item()
+            flat[idx] = old + 1e-6
+            lp = O.pm_vae_loss(p, full, x, b, eps, 0)[0].item()
+            flat[idx] = old - 1e-6
+            lm = O.pm_vae_loss(p, full, x, b, eps, 0)[0].item()
+            flat[idx] = old
+            fd = (lp - lm) / 2e-6
+            assert grads[name].reshape(-1)[idx].item() == pytest.approx(fd, rel=2e-5, abs=1e-8), name
