@@ -74,7 +74,7 @@ def conv2d(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int, padding: str)
         raise ValueError(padding)
     xn = x.permute(0, 3, 1, 2)                       # NHWC -> NCHW for torch's conv
     xn = F.pad(xn, (pl, pr, pt, pb))
-    wn = w.permute(3, 2, 0, 1)                       # HWIO -> OIHW; torch conv2d = cross-correlation
+    wn = w.permute(3, 2, 0, 1).contiguous()          # HWIO -> OIHW; torch conv2d = cross-correlation
     y = F.conv2d(xn, wn, None, stride=stride)
     y = y.permute(0, 2, 3, 1)
     if b is not None:
@@ -99,7 +99,7 @@ def conv2d_transpose(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int, pad
         xd[:, :, ::stride, ::stride] = xn
         xn = xd
     xn = F.pad(xn, (pa_w, pb_w, pa_h, pb_h))
-    wn = w.permute(2, 3, 0, 1)                        # HWOI -> OIHW, un-flipped
+    wn = w.permute(2, 3, 0, 1).contiguous()           # HWOI -> OIHW, un-flipped
     y = F.conv2d(xn, wn, None, stride=1).permute(0, 2, 3, 1)
     if b is not None:
         y = y + b

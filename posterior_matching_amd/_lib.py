@@ -1,0 +1,127 @@
+"""ctypes binding of libpmhip.so (include/pmhip.h).
+
+There is no CPU fallback: if the HIP library is missing or a kernel reports an error the
+product path raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpmhip.so")
+
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+LEAKY_SLOPE = 0.01  # jax.nn.leaky_relu default negative_slope
+
+
+class PmHipError(RuntimeError):
+    pass
+
+
+class GatherDesc(C.Structure):
+    """struct pm_gather_desc (include/pmhip.h)."""
+
+    _fields_ = [
+        ("B", C.c_int),
+        ("IH", C.c_int), ("IW", C.c_int), ("C", C.c_int),
+        ("OH", C.c_int), ("OW", C.c_int), ("N", C.c_int),
+        ("KH", C.c_int), ("KW", C.c_int),
+        ("a", C.c_int), ("cs", C.c_int), ("off", C.c_int), ("d", C.c_int),
+        ("wts", C.c_int), ("wcs", C.c_int), ("wns", C.c_int),
+        ("groups", C.c_int),
+        ("in_gs", C.c_longlong), ("w_gs", C.c_longlong), ("out_gs", C.c_longlong), ("bias_gs", C.c_longlong),
+        ("in_act", C.c_int), ("out_act", C.c_int), ("aux_act", C.c_int),
+        ("slope", C.c_float),
+    ]
+
+
+class LossCfg(C.Structure):
+    _fields_ = [
+        ("beta_kind", C.c_int),
+        ("low", C.c_float), ("high", C.c_float),
+        ("period_or_steps", C.c_int), ("delay_or_begin", C.c_int),
+        ("matching_coef", C.c_float),
+        ("grad_scale", C.c_float),
+    ]
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [
+        ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+        ("lr_init", C.c_float), ("lr_decay_rate", C.c_float), ("lr_transition_steps", C.c_float),
+        ("grad_scale", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_LL = C.c_longlong
+_F = C.c_float
+
+# name -> argtypes ; every function returns int (0 = ok) unless listed in _OTHER_RESTYPE
+SIGNATURES = {
+    "pm_gather_gemm": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
+    "pm_gather_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
+    "pm_mask_concat": [_P, _P, _P, _P, _LL, _I, _I],
+    "pm_tril_sample_kl_fwd": [_P, _P, _P, _P, _P, _I, _I],
+    "pm_tril_sample_kl_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
+    "pm_tril_logprob_fwd": [_P, _P, _P, _P, _I, _I],
+    "pm_tril_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
+    "pm_bernoulli_ll_fwd": [_P, _P, _P, _P, _I, _I],
+    "pm_bernoulli_ll_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "pm_normal_ll_fwd": [_P, _P, _P, _P, _P, _I, _I],
+    "pm_normal_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
+    "pm_argmm_build_input": [_P, _P, _P, _P, _I, _I, _I],
+    "pm_argmm_input_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _F],
+    "pm_gmm_logprob_fwd": [_P, _P, _P, _P, _I, _I, _I],
+    "pm_gmm_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "pm_pmvae_loss": [_P, _P, _P, _P, _I, C.POINTER(LossCfg), _P, _P, _P, _P, _P],
+    "pm_adam_step": [_P, _P, _P, _P, _P, _LL, _LL, _P, C.POINTER(AdamCfg)],
+    "pm_counter_increment": [_P, _P],
+    "pm_normal_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
+    "pm_fill_zero": [_P, _P, _LL],
+    "pm_axpy1": [_P, _P, _P, _LL],
+    "pm_graph_begin": [_P],
+    "pm_graph_end": [_P, C.POINTER(_P)],
+    "pm_graph_launch": [_P, _P],
+    "pm_graph_destroy": [_P],
+    "pm_event_create": [C.POINTER(_P)],
+    "pm_event_record": [_P, _P],
+    "pm_event_synchronize": [_P],
+    "pm_event_elapsed_ms": [_P, _P, C.POINTER(_F)],
+    "pm_event_destroy": [_P],
+    "pm_version": [],
+}
+_OTHER_RESTYPE = {"pm_strerror": ([_I], C.c_char_p), "pm_last_error": ([], C.c_char_p)}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libpmhip.so once; raises PmHipError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PmHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C posterior_matching_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name, (argtypes, restype) in _OTHER_RESTYPE.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        raise PmHipError(f"{what} failed: {lib.pm_strerror(rc).decode()} [{lib.pm_last_error().decode()}]")

@@ -1,0 +1,43 @@
+// Shared device helpers for libpmhip (gfx950 / CDNA4 only: 64-lane waves, f32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/pmhip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PM_WAVE 64
+
+extern thread_local char pm_err_text[256];
+int pm_check_launch(const char* what);
+
+__device__ __forceinline__ float pm_act(float v, int act, float slope) {
+    if (act == PM_ACT_LEAKY) return v >= 0.f ? v : slope * v;  // jax.nn.leaky_relu: where(x >= 0, x, a*x)
+    if (act == PM_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+// derivative expressed on the activation's OUTPUT (sign is preserved by both activations) or on
+// its input: leaky' = 1 for v >= 0 else slope; relu' = 1 for v > 0 else 0 (jax's relu jvp).
+__device__ __forceinline__ float pm_dact(float v, int act, float slope) {
+    if (act == PM_ACT_LEAKY) return v >= 0.f ? 1.f : slope;
+    if (act == PM_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+__device__ __forceinline__ float pm_softplus(float x) {  // logaddexp(x, 0)
+    return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float pm_sigmoid(float x) {
+    return x >= 0.f ? 1.f / (1.f + expf(-x)) : expf(x) / (1.f + expf(x));
+}
+
+__device__ __forceinline__ float pm_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float pm_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,567 @@
+// Gather-GEMM engine: conv / transposed-conv / dense forward, data-gradient and weight-gradient
+// on the f32 MFMA (v_mfma_f32_32x32x2_f32) of gfx950.
+//
+// Replaces the XLA kernels behind hk.Conv2D / hk.Conv2DTranspose / hk.Linear and their jax.grad
+// (reference networks.py:30-36,62-68,116-129).  One index rule
+//     src*d = dst*a + tap*cs + off
+// expresses all four conv flavours (see include/pmhip.h), so one kernel serves every layer.
+//
+// Tiling: a 256-thread workgroup (4 waves) owns a BM x BN output tile and walks K = KH*KW*C in
+// chunks of 32.  The gathered operand is loaded along its contiguous channel axis (16 B per lane
+// when C % 4 == 0), staged in LDS with a 36-float row stride (conflict-free ds_read_b128) and
+// consumed as 32x32x2 MFMA fragments; register prefetch of chunk t+1 overlaps the MFMAs of t.
+#include "pm_common.h"
+
+namespace {
+
+struct Geom {
+    int B, IH, IW, C, OH, OW, N, KH, KW;
+    int a, cs, off, d;
+    int wts, wcs, wns;
+    int M, K;
+    int in_act, out_act, aux_act;
+    float slope;
+};
+
+struct GemmArgs {
+    Geom g;
+    const float* in;
+    const float* w;
+    const float* bias;
+    const float* aux;
+    const float* res;
+    float* out;
+    long long in_gs, w_gs, out_gs, bias_gs;
+};
+
+struct WgradArgs {
+    Geom g;
+    const float* gathered;
+    const float* dense;
+    float* dw;
+    float* db;
+    long long in_gs, w_gs, out_gs, bias_gs;
+    int chunks_per_split;
+};
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;  // 144-byte rows: 16-B aligned, ds_read_b128 conflict-free
+
+__device__ __forceinline__ bool src_coord(int base, int kt, int cs, int d, int lim, int& s) {
+    int t = base + kt * cs;
+    if (t < 0) return false;
+    if (d > 1) {
+        int q = t / d;
+        if (q * d != t) return false;
+        t = q;
+    }
+    s = t;
+    return t < lim;
+}
+
+// ---- gathered-operand tile loaders: tile[row][k], rows = output positions m0.., k = kk0.. ----
+template <int BM, int BKT>
+struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
+    static constexpr int SLOTS = BKT / 4;
+    static constexpr int RPP = 256 / SLOTS;
+    static constexpr int NP = BM / RPP;
+    int slot, r0;
+    int rb[NP], rpy[NP], rqx[NP];
+    f32x4 regs[NP];
+
+    __device__ __forceinline__ void init(int tid) {
+        slot = tid % SLOTS;
+        r0 = tid / SLOTS;
+    }
+    __device__ __forceinline__ void set_rows(const Geom& g, int m0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            int m = m0 + r0 + j * RPP;
+            if (m < g.M) {
+                int q = m % g.OW;
+                int t = m / g.OW;
+                int p = t % g.OH;
+                rb[j] = t / g.OH;
+                rpy[j] = p * g.a + g.off;
+                rqx[j] = q * g.a + g.off;
+            } else {
+                rb[j] = -1;
+                rpy[j] = rqx[j] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0) {
+        int kk = kk0 + 4 * slot;
+        bool kok = kk < g.K;
+        int tap = kk / g.C;
+        int c = kk - tap * g.C;
+        int ky = tap / g.KW;
+        int kx = tap - ky * g.KW;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int sy, sx;
+            if (kok && rb[j] >= 0 && src_coord(rpy[j], ky, g.cs, g.d, g.IH, sy) &&
+                src_coord(rqx[j], kx, g.cs, g.d, g.IW, sx)) {
+                size_t o = (((size_t)rb[j] * g.IH + sy) * g.IW + sx) * g.C + c;
+                v = *reinterpret_cast<const f32x4*>(in + o);
+                if (g.in_act != PM_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pm_act(v[e], g.in_act, g.slope);
+                }
+            }
+            regs[j] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* tile, int ld) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            *reinterpret_cast<f32x4*>(tile + (r0 + j * RPP) * ld + 4 * slot) = regs[j];
+    }
+};
+
+template <int BM, int BKT>
+struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened over (tap, c)
+    static_assert(BKT == 32, "scalar loader walks 32 k per chunk");
+    static constexpr int RPT = BM / 8;  // consecutive rows per thread
+    int kslot, rg;
+    int m_first;
+    float regs[RPT];
+
+    __device__ __forceinline__ void init(int tid) {
+        kslot = tid & 31;
+        rg = tid >> 5;
+    }
+    __device__ __forceinline__ void set_rows(const Geom&, int m0) { m_first = m0 + rg * RPT; }
+    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0) {
+        int kk = kk0 + kslot;
+        bool kok = kk < g.K;
+        int tap = kk / g.C;
+        int c = kk - tap * g.C;
+        int ky = tap / g.KW;
+        int kx = tap - ky * g.KW;
+        int m = m_first;
+        int q = m % g.OW;
+        int t = m / g.OW;
+        int p = t % g.OH;
+        int b = t / g.OH;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            float v = 0.f;
+            int sy, sx;
+            if (kok && (m + j) < g.M && src_coord(p * g.a + g.off, ky, g.cs, g.d, g.IH, sy) &&
+                src_coord(q * g.a + g.off, kx, g.cs, g.d, g.IW, sx)) {
+                size_t o = (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + c;
+                v = pm_act(in[o], g.in_act, g.slope);
+            }
+            regs[j] = v;
+            if (++q == g.OW) {
+                q = 0;
+                if (++p == g.OH) {
+                    p = 0;
+                    ++b;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* tile, int ld) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) tile[(rg * RPT + j) * ld + kslot] = regs[j];
+    }
+};
+
+template <int BM, int BKT, int VEC>
+struct LoaderSel {
+    typedef LoaderV4<BM, BKT> type;
+};
+template <int BM, int BKT>
+struct LoaderSel<BM, BKT, 1> {
+    typedef LoaderV1<BM, BKT> type;
+};
+
+// -------------------------------- forward / data-gradient ------------------------------------
+template <int BM, int BN, int VEC>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
+    constexpr int WM = BM / 32;
+    constexpr int WN = 4 / WM;
+    constexpr int RN = BN / (32 * WN);
+    constexpr int NBE = BK * BN / 256;
+    static_assert(RN >= 1, "tile too narrow for the wave layout");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    float* As = smem;
+    float* Bs = smem + BM * LDS_LD;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int grp = blockIdx.z;
+    const float* in = p.in + (size_t)grp * p.in_gs;
+    const float* w = p.w + (size_t)grp * p.w_gs;
+
+    typename LoaderSel<BM, BK, VEC>::type la;
+    la.init(tid);
+    la.set_rows(g, m0);
+
+    // weight tile: Bs[n][k] = w[kk0 + k][n0 + n]; lanes run along the contiguous weight axis
+    const bool ncontig = (g.wns == 1);
+    float breg[NBE];
+    auto load_b = [&](int kk0) {
+        const bool tap_uniform = (g.C % BK) == 0;
+        const int tap_u = kk0 / g.C;
+        const int c_u = kk0 - tap_u * g.C;
+#pragma unroll
+        for (int j = 0; j < NBE; ++j) {
+            int kl, nl;
+            if (ncontig) {
+                nl = tid % BN;
+                kl = tid / BN + (256 / BN) * j;
+            } else {
+                kl = tid & 31;
+                nl = (tid >> 5) + 8 * j;
+            }
+            int kk = kk0 + kl;
+            int n = n0 + nl;
+            float v = 0.f;
+            if (kk < g.K && n < g.N) {
+                int tap, c;
+                if (tap_uniform) {
+                    tap = tap_u;
+                    c = c_u + kl;
+                } else {
+                    tap = kk / g.C;
+                    c = kk - tap * g.C;
+                }
+                v = w[(size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns];
+            }
+            breg[j] = v;
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int j = 0; j < NBE; ++j) {
+            int kl, nl;
+            if (ncontig) {
+                nl = tid % BN;
+                kl = tid / BN + (256 / BN) * j;
+            } else {
+                kl = tid & 31;
+                nl = (tid >> 5) + 8 * j;
+            }
+            Bs[nl * LDS_LD + kl] = breg[j];
+        }
+    };
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    const int nchunks = (g.K + BK - 1) / BK;
+    la.load(g, in, 0);
+    load_b(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        la.store(As, LDS_LD);
+        store_b();
+        __syncthreads();
+        if (ch + 1 < nchunks) {
+            la.load(g, in, (ch + 1) * BK);
+            load_b((ch + 1) * BK);
+        }
+        const float* arow = As + (wm * 32 + i) * LDS_LD + 4 * h;
+        const float* brow = Bs + (wn * RN * 32 + i) * LDS_LD + 4 * h;
+#pragma unroll
+        for (int u = 0; u < BK / 8; ++u) {
+            f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * u);
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + r * 32 * LDS_LD + 8 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[r], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const float* bias = p.bias ? p.bias + (size_t)grp * p.bias_gs : nullptr;
+    const float* aux = p.aux ? p.aux + (size_t)grp * p.out_gs : nullptr;
+    const float* res = p.res ? p.res + (size_t)grp * p.out_gs : nullptr;
+    float* out = p.out + (size_t)grp * p.out_gs;
+#pragma unroll
+    for (int r = 0; r < RN; ++r) {
+        int n = n0 + (wn * RN + r) * 32 + i;
+        if (n >= g.N) continue;
+        float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m >= g.M) continue;
+            size_t o = (size_t)m * g.N + n;
+            float v = acc[r][e] + bv;
+            if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
+            if (res) v += res[o];
+            out[o] = pm_act(v, g.out_act, g.slope);
+        }
+    }
+}
+
+// ------------------------------------ weight gradient ----------------------------------------
+// dw[kk][n] += sum_m G[m][kk] * D[m][n].  A workgroup owns a (32*RC) x (32*RN) block of dw and a
+// range of 128-row chunks of m; its 4 waves each take 32 rows of a chunk (MFMA k = 2 rows per
+// instruction), are summed through LDS at the end and added to global memory with f32 atomics.
+template <int RC, int RN, int VEC, int DVEC>
+__global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
+    constexpr int CB = 32 * RC;
+    constexpr int NB = 32 * RN;
+    constexpr int BMC = 128;
+    constexpr int TILE = BMC * (CB + NB);
+    constexpr int RED = 4 * CB * NB;
+    constexpr int SMEM = TILE > RED ? TILE : RED;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* Gs = smem;
+    float* Ds = smem + BMC * CB;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int nkb = (g.K + CB - 1) / CB;
+    const int kkb = blockIdx.x % nkb;
+    const int nb = blockIdx.x / nkb;
+    const int kk0 = kkb * CB;
+    const int n0 = nb * NB;
+    const int grp = blockIdx.z;
+    const float* gin = p.gathered + (size_t)grp * p.in_gs;
+    const float* din = p.dense + (size_t)grp * p.out_gs;
+    const bool do_bias = (p.db != nullptr) && (kkb == 0);
+
+    const int total_chunks = (g.M + BMC - 1) / BMC;
+    const int c_begin = blockIdx.y * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    typename LoaderSel<BMC, CB, VEC>::type lg;
+    lg.init(tid);
+
+    // dense tile loader: Ds[row][n]
+    constexpr int DSLOTS = NB / DVEC;
+    constexpr int DRPP = 256 / DSLOTS;
+    constexpr int DNP = BMC / DRPP;
+    const int dslot = tid % DSLOTS;
+    const int dr0 = tid / DSLOTS;
+    float dreg[DNP][DVEC];
+    auto load_d = [&](int m0) {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            int m = m0 + dr0 + j * DRPP;
+            int n = n0 + dslot * DVEC;
+            if (DVEC == 4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < g.M && n < g.N) v = *reinterpret_cast<const f32x4*>(din + (size_t)m * g.N + n);
+#pragma unroll
+                for (int e = 0; e < DVEC; ++e) dreg[j][e] = v[e];
+            } else {
+                dreg[j][0] = (m < g.M && n < g.N) ? din[(size_t)m * g.N + n] : 0.f;
+            }
+        }
+    };
+    auto store_d = [&]() {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j)
+#pragma unroll
+            for (int e = 0; e < DVEC; ++e) Ds[(dr0 + j * DRPP) * NB + dslot * DVEC + e] = dreg[j][e];
+    };
+
+    f32x16 acc[RC][RN];
+    f32x16 accb[RN];
+#pragma unroll
+    for (int a = 0; a < RC; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < RN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[b][e] = 0.f;
+
+    if (c_begin < c_end) {
+        lg.set_rows(g, c_begin * BMC);
+        lg.load(g, gin, kk0);
+        load_d(c_begin * BMC);
+    }
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        lg.store(Gs, CB);
+        store_d();
+        __syncthreads();
+        if (ch + 1 < c_end) {
+            lg.set_rows(g, (ch + 1) * BMC);
+            lg.load(g, gin, kk0);
+            load_d((ch + 1) * BMC);
+        }
+        const float* grow = Gs + (wave * 32 + h) * CB + i;
+        const float* drow = Ds + (wave * 32 + h) * NB + i;
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            float av[RC], bv[RN];
+#pragma unroll
+            for (int a = 0; a < RC; ++a) av[a] = grow[2 * t * CB + 32 * a];
+#pragma unroll
+            for (int b = 0; b < RN; ++b) bv[b] = drow[2 * t * NB + 32 * b];
+#pragma unroll
+            for (int a = 0; a < RC; ++a)
+#pragma unroll
+                for (int b = 0; b < RN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int b = 0; b < RN; ++b)
+                    accb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, bv[b], accb[b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // cross-wave reduction through LDS, then one atomic per element per workgroup
+    float* red = smem;
+#pragma unroll
+    for (int a = 0; a < RC; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int cl = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                int nl = b * 32 + i;
+                red[wave * CB * NB + cl * NB + nl] = acc[a][b][e];
+            }
+    __syncthreads();
+    float* dw = p.dw + (size_t)grp * p.w_gs;
+    for (int e = tid; e < CB * NB; e += 256) {
+        int cl = e / NB;
+        int nl = e - cl * NB;
+        int kk = kk0 + cl;
+        int n = n0 + nl;
+        if (kk < g.K && n < g.N) {
+            float s = red[e] + red[CB * NB + e] + red[2 * CB * NB + e] + red[3 * CB * NB + e];
+            int tap = kk / g.C;
+            int c = kk - tap * g.C;
+            atomicAdd(dw + (size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
+        }
+    }
+    if (do_bias && h == 0) {
+        float* db = p.db + (size_t)grp * p.bias_gs;
+#pragma unroll
+        for (int b = 0; b < RN; ++b) {
+            int n = n0 + b * 32 + i;
+            if (n < g.N) atomicAdd(db + n, accb[b][0]);
+        }
+    }
+}
+
+bool fill_geom(const pm_gather_desc* d, Geom& g) {
+    if (!d || d->B <= 0 || d->C <= 0 || d->N <= 0 || d->KH <= 0 || d->KW <= 0 || d->d <= 0 || d->groups <= 0)
+        return false;
+    if (d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0) return false;
+    if (d->cs != 1 && d->cs != -1) return false;
+    long long M = (long long)d->B * d->OH * d->OW;
+    long long K = (long long)d->KH * d->KW * d->C;
+    if (M > 0x7fffffffLL / 4 || K > 0x7fffffffLL / 4) return false;
+    g.B = d->B; g.IH = d->IH; g.IW = d->IW; g.C = d->C; g.OH = d->OH; g.OW = d->OW; g.N = d->N;
+    g.KH = d->KH; g.KW = d->KW; g.a = d->a; g.cs = d->cs; g.off = d->off; g.d = d->d;
+    g.wts = d->wts; g.wcs = d->wcs; g.wns = d->wns; g.M = (int)M; g.K = (int)K;
+    g.in_act = d->in_act; g.out_act = d->out_act; g.aux_act = d->aux_act; g.slope = d->slope;
+    return true;
+}
+
+template <int BM, int BN>
+void launch_gemm(hipStream_t s, const GemmArgs& a, int groups, bool vec4) {
+    dim3 grid((a.g.M + BM - 1) / BM, (a.g.N + BN - 1) / BN, groups);
+    if (vec4)
+        hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 4>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 1>), grid, dim3(256), 0, s, a);
+}
+
+template <int RC, int RN>
+void launch_wgrad(hipStream_t s, const WgradArgs& a, dim3 grid, bool vec4, bool dvec4) {
+    if constexpr (RC == 1) {  // the scalar gather loader only exists for 32-wide k blocks
+        if (!vec4) {
+            if (dvec4)
+                hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 1, 4>), grid, dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 1, 1>), grid, dim3(256), 0, s, a);
+            return;
+        }
+    }
+    if (dvec4)
+        hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 4, 4>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 4, 1>), grid, dim3(256), 0, s, a);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w,
+                              const float* bias, const float* aux, const float* res, float* out) {
+    GemmArgs a;
+    if (!fill_geom(d, a.g) || !in || !w || !out) return PM_EINVAL;
+    a.in = in; a.w = w; a.bias = bias; a.aux = aux; a.res = res; a.out = out;
+    a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    const bool vec4 = (d->C % 4 == 0) && aligned16(in) && (d->in_gs % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int M = a.g.M, N = a.g.N, G = d->groups;
+    auto nwg = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * G; };
+    if (N <= 32) {
+        launch_gemm<128, 32>(s, a, G, vec4);
+    } else if (N <= 64) {
+        if (nwg(128, 64) >= 256) launch_gemm<128, 64>(s, a, G, vec4);
+        else launch_gemm<64, 64>(s, a, G, vec4);
+    } else {
+        if (nwg(128, 128) >= 256) launch_gemm<128, 128>(s, a, G, vec4);
+        else if (nwg(64, 128) >= 256) launch_gemm<64, 128>(s, a, G, vec4);
+        else if (nwg(64, 64) >= 2 * nwg(32, 128)) launch_gemm<64, 64>(s, a, G, vec4);
+        else launch_gemm<32, 128>(s, a, G, vec4);
+    }
+    return pm_check_launch("pm_gather_gemm");
+}
+
+extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, const float* gathered,
+                               const float* dense, float* dw, float* db) {
+    WgradArgs a;
+    if (!fill_geom(d, a.g) || !gathered || !dense || !dw) return PM_EINVAL;
+    a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db;
+    a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    const bool vec4 = (d->C % 4 == 0) && aligned16(gathered) && (d->in_gs % 4 == 0);
+    const bool dvec4 = (d->N % 4 == 0) && aligned16(dense) && (d->out_gs % 4 == 0);
+    const int rc = (vec4 && a.g.K >= 64) ? 2 : 1;
+    const int rn = a.g.N > 32 ? 2 : 1;
+    const int nkb = (a.g.K + 32 * rc - 1) / (32 * rc);
+    const int nnb = (a.g.N + 32 * rn - 1) / (32 * rn);
+    const int total_chunks = (a.g.M + 127) / 128;
+    long long blocks = (long long)nkb * nnb * d->groups;
+    int splits = (int)((1024 + blocks - 1) / blocks);
+    if (splits < 1) splits = 1;
+    if (splits > total_chunks) splits = total_chunks;
+    a.chunks_per_split = (total_chunks + splits - 1) / splits;
+    splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    dim3 grid(nkb * nnb, splits, d->groups);
+    hipStream_t s = (hipStream_t)stream;
+    if (rc == 2 && rn == 2) launch_wgrad<2, 2>(s, a, grid, vec4, dvec4);
+    else if (rc == 2) launch_wgrad<2, 1>(s, a, grid, vec4, dvec4);
+    else if (rn == 2) launch_wgrad<1, 2>(s, a, grid, vec4, dvec4);
+    else launch_wgrad<1, 1>(s, a, grid, vec4, dvec4);
+    return pm_check_launch("pm_gather_wgrad");
+}

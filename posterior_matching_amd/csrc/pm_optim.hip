@@ -1,0 +1,201 @@
+// Loss composition, beta / learning-rate schedules and the fused optimizer of the PM-VAE step.
+//   loss_fn + beta schedules      reference train_pm_vae.py:28-43,58-72, utils.py:124-136
+//   optax chain (Adam, decayed weights, exponential-decay schedule, apply_updates)
+//                                 reference train_pm_vae.py:74-83 (optax 0.1.0 semantics)
+// The step counter lives in device memory so that a captured HIP graph can be replayed unchanged.
+#include <cstdio>
+#include "pm_common.h"
+
+namespace {
+
+__device__ float beta_from_step(const pm_loss_cfg& c, int step) {
+    if (c.beta_kind == 1) {  // optax.linear_schedule(low, high, steps, begin)
+        if (c.period_or_steps <= 0) return c.high;
+        int cnt = step - c.delay_or_begin;
+        cnt = cnt < 0 ? 0 : (cnt > c.period_or_steps ? c.period_or_steps : cnt);
+        float frac = 1.f - (float)cnt / (float)c.period_or_steps;
+        return (c.low - c.high) * frac + c.high;
+    }
+    if (c.beta_kind == 2) {  // cyclical_annealing_schedule (utils.py:127-134)
+        int period = c.period_or_steps, delay = c.delay_or_begin;
+        int cnt = step - delay;
+        int md = cnt % period;
+        if (md < 0) md += period;  // jnp `%` is floor-mod
+        int half = period / 2;
+        cnt = md < 0 ? 0 : (md > half ? half : md);
+        float frac = 1.f - (float)cnt / (float)half;
+        float x = (c.low - c.high) * frac + c.high;
+        return step >= delay ? x : 0.f;
+    }
+    return 1.f;
+}
+
+__global__ __launch_bounds__(256) void pmvae_loss_kernel(const float* __restrict__ rec, const float* __restrict__ kl,
+                                                           const float* __restrict__ mll, int B, pm_loss_cfg cfg,
+                                                           const int* __restrict__ step_dev, float* __restrict__ out,
+                                                           float* __restrict__ g_rec, float* __restrict__ g_kl,
+                                                           float* __restrict__ g_mll) {
+    __shared__ float red[3][4];
+    const int step = step_dev ? step_dev[0] : 0;
+    const float beta = beta_from_step(cfg, step);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        s0 += rec[b];
+        s1 += kl[b];
+        s2 += mll[b];
+        if (g_rec) g_rec[b] = -cfg.grad_scale;
+        if (g_kl) g_kl[b] = beta * cfg.grad_scale;
+        if (g_mll) g_mll[b] = -cfg.matching_coef * cfg.grad_scale;
+    }
+    s0 = pm_wave_sum(s0);
+    s1 = pm_wave_sum(s1);
+    s2 = pm_wave_sum(s2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[0][wave] = s0;
+        red[1][wave] = s1;
+        red[2][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m0 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / B;
+        float m1 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / B;
+        float m2 = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) / B;
+        out[0] = -(m0 - beta * m1) + cfg.matching_coef * (-m2);
+        out[1] = m0;
+        out[2] = m1;
+        out[3] = m2;
+        out[4] = beta;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v, long long n,
+                                                     long long n_decay, const int* __restrict__ count_dev,
+                                                     pm_adam_cfg c) {
+    const int count = count_dev[0];
+    const float t = (float)(count + 1);
+    const float bc1 = 1.f - powf(c.b1, t);
+    const float bc2 = 1.f - powf(c.b2, t);
+    const float lr = c.lr_init * powf(c.lr_decay_rate, (float)count / c.lr_transition_steps);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gi = g[i] * c.grad_scale;
+        float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
+        float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float u = (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
+        float pi = p[i];
+        if (i < n_decay) u += c.weight_decay * pi;
+        p[i] = pi - lr * u;
+    }
+}
+
+__global__ void counter_increment_kernel(int* c) { c[0] += 1; }
+
+// Philox4x32-10 counter-based generator + Box-Muller: eps ~ N(0,1) for posterior.sample
+// (vae.py:124).  Bit parity with JAX's threefry streams is not a goal; parity tests
+// pass eps explicitly.  key = (seed, stream_id), counter = (element/4, step).
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0,
+                                             unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+}
+
+__global__ __launch_bounds__(256) void normal_fill_kernel(float* __restrict__ out, long long n,
+                                                            unsigned long long seed, const int* __restrict__ step_dev,
+                                                            int stream_id) {
+    const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+    const long long quads = (n + 3) / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long qd = (long long)blockIdx.x * 256 + threadIdx.x; qd < quads; qd += stride) {
+        unsigned c0 = (unsigned)qd, c1 = (unsigned)(qd >> 32), c2 = step, c3 = (unsigned)stream_id;
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const float s = 2.3283064365386963e-10f;  // 2^-32
+        float u0 = ((float)c0 + 0.5f) * s, u1 = ((float)c1 + 0.5f) * s;
+        float u2 = ((float)c2 + 0.5f) * s, u3 = ((float)c3 + 0.5f) * s;
+        u0 = fminf(fmaxf(u0, 1e-10f), 1.f);
+        u2 = fminf(fmaxf(u2, 1e-10f), 1.f);
+        float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+        float v[4];
+        sincosf(6.283185307179586f * u1, &v[1], &v[0]);
+        sincosf(6.283185307179586f * u3, &v[3], &v[2]);
+        v[0] *= r0; v[1] *= r0; v[2] *= r1; v[3] *= r1;
+        for (int e = 0; e < 4; ++e)
+            if (qd * 4 + e < n) out[qd * 4 + e] = v[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy1_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += x[i];
+}
+
+}  // namespace
+
+extern "C" int pm_pmvae_loss(pm_stream_t stream, const float* rec, const float* kl, const float* mll, int B,
+                             const pm_loss_cfg* cfg, const int* step_dev, float* out, float* g_rec, float* g_kl,
+                             float* g_mll) {
+    if (!rec || !kl || !mll || !cfg || !out || B <= 0) return PM_EINVAL;
+    if (cfg->beta_kind == 2 && cfg->period_or_steps < 2) return PM_EINVAL;
+    hipLaunchKernelGGL(pmvae_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rec, kl, mll, B, *cfg, step_dev,
+                       out, g_rec, g_kl, g_mll);
+    return pm_check_launch("pm_pmvae_loss");
+}
+
+extern "C" int pm_adam_step(pm_stream_t stream, float* p, const float* g, float* m, float* v, long long n,
+                            long long n_decay, const int* count_dev, const pm_adam_cfg* cfg) {
+    if (!p || !g || !m || !v || !count_dev || !cfg || n <= 0) return PM_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, n_decay,
+                       count_dev, *cfg);
+    return pm_check_launch("pm_adam_step");
+}
+
+extern "C" int pm_counter_increment(pm_stream_t stream, int* count_dev) {
+    if (!count_dev) return PM_EINVAL;
+    hipLaunchKernelGGL(counter_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, count_dev);
+    return pm_check_launch("pm_counter_increment");
+}
+
+extern "C" int pm_normal_fill(pm_stream_t stream, float* out, long long n, unsigned long long seed,
+                              const int* step_dev, int stream_id) {
+    if (!out || n <= 0) return PM_EINVAL;
+    long long blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, seed,
+                       step_dev, stream_id);
+    return pm_check_launch("pm_normal_fill");
+}
+
+extern "C" int pm_fill_zero(pm_stream_t stream, void* ptr, long long nbytes) {
+    if (!ptr || nbytes <= 0) return PM_EINVAL;
+    hipError_t e = hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        snprintf(pm_err_text, sizeof(pm_err_text), "pm_fill_zero: %s", hipGetErrorString(e));
+        return PM_ELAUNCH;
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_axpy1(pm_stream_t stream, const float* x, float* y, long long n) {
+    if (!x || !y || n <= 0) return PM_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(axpy1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return pm_check_launch("pm_axpy1");
+}

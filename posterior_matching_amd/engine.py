@@ -1,0 +1,158 @@
+"""The per-step training loop of the PM-VAE as one launch sequence (optionally one HIP graph).
+
+This is what bax.Trainer's jitted train_step is for train_pm_vae.py (reference :85-102 with the
+loss_fn of :58-72 and the optimizer of :74-83): sample eps -> forward -> loss -> backward ->
+[gradient all-reduce across ranks] -> Adam -> step += 1.  Every arithmetic op is a libpmhip.so
+kernel; the step counter, beta and learning-rate schedules live on the device so the sequence
+can be captured once and replayed.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Mapping, Optional
+
+import torch
+
+from . import ops
+from ._lib import LossCfg
+from .models.vae import PosteriorMatchingVAE
+from .optim import Chain
+
+
+def loss_cfg_from_config(config: Mapping[str, Any], batch_size: int) -> LossCfg:
+    """get_beta_schedule + the loss weights of loss_fn (train_pm_vae.py:28-43,62-70)."""
+    c = LossCfg()
+    beta = config.get("beta", {}) or {}
+    c.beta_kind, c.low, c.high, c.period_or_steps, c.delay_or_begin = 0, 0.0, 1.0, 1, 0
+    if "schedule" in beta:
+        if beta["schedule"] == "monotonic":
+            c.beta_kind = 1
+            c.low, c.high = beta["low_value"], beta["high_value"]
+            c.period_or_steps, c.delay_or_begin = beta["transition_steps"], beta.get("transition_begin", 0)
+        elif beta["schedule"] == "cyclic":
+            c.beta_kind = 2
+            c.low, c.high = beta["low_value"], beta["high_value"]
+            c.period_or_steps, c.delay_or_begin = beta["period"], beta.get("delay", 0)
+        else:
+            raise KeyError(beta["schedule"])
+    c.matching_coef = config.get("matching_coef", 1.0)
+    c.grad_scale = 1.0 / batch_size
+    return c
+
+
+class PMVAETrainStep:
+    """Fused train step over static device buffers (x, b, eps are copied/generated in place)."""
+
+    def __init__(self, model: PosteriorMatchingVAE, config: Mapping[str, Any], optimizer: Chain, batch_size: int,
+                 x_shape, seed: int = 0, world_size: int = 1, rank: int = 0, use_graph: bool = True,
+                 external_eps: bool = False):
+        if model.store is None:
+            model.init(x_shape)
+        dev = model.store.device
+        self.model, self.opt, self.B = model, optimizer, batch_size
+        self.world_size, self.rank, self.seed = world_size, rank, seed
+        self.loss_cfg = loss_cfg_from_config(config, batch_size)
+        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        x_shape = tuple(x_shape)
+        b_shape = x_shape[:-1] + (1,) if len(x_shape) == 3 else x_shape
+        self.x = torch.zeros((batch_size,) + x_shape, device=dev)
+        self.b = torch.zeros((batch_size,) + b_shape, device=dev)
+        self.eps = torch.zeros((batch_size, model.latent_dim), device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.metrics = torch.zeros(8, device=dev)       # loss, rec, kl, mll, beta
+        self.g_rec = torch.zeros(batch_size, device=dev)
+        self.g_kl = torch.zeros(batch_size, device=dev)
+        self.g_mll = torch.zeros(batch_size, device=dev)
+        self.external_eps = external_eps
+        self.use_graph = use_graph
+        # HIP graph capture is not allowed on the NULL stream: the step owns a side stream
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        self._graph_fb: Optional[ops.Graph] = None
+        self._graph_opt: Optional[ops.Graph] = None
+
+    # -- pieces -----------------------------------------------------------------------------
+    def _forward_backward(self) -> None:
+        m = self.model
+        if not self.external_eps:
+            ops.normal_fill(self.eps, self.seed, self.step_dev, stream_id=self.rank)
+        out = m(self.x, self.b, is_training=True, eps=self.eps)
+        ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], self.loss_cfg, self.step_dev,
+                       self.metrics, self.g_rec, self.g_kl, self.g_mll)
+        m.zero_grad()
+        m.backward(self.g_rec, self.g_kl, self.g_mll)
+
+    def _update(self) -> None:
+        s = self.model.store
+        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        ops.counter_increment(self.step_dev)
+
+    def _allreduce(self) -> None:
+        import torch.distributed as dist
+
+        dist.all_reduce(self.model.store.flat_g)          # sum over ranks; Adam divides by world_size
+
+    # -- one optimizer step on whatever is in self.x / self.b (/ self.eps) ---------------------
+    def step(self) -> None:
+        with torch.cuda.stream(self.stream):
+            self._step()
+
+    def _step(self) -> None:
+        if not self.use_graph:
+            self._forward_backward()
+            if self.world_size > 1:
+                self._allreduce()
+            self._update()
+            return
+        if self._graph_fb is None:
+            # run once eagerly so that every workspace buffer exists before capture
+            self._forward_backward()
+            if self.world_size > 1:
+                self._allreduce()
+            self._update()
+            self.stream.synchronize()
+            self._graph_fb, self._graph_opt = ops.Graph(), ops.Graph()
+            if self.world_size > 1:
+                with self._graph_fb:
+                    self._forward_backward()
+                with self._graph_opt:
+                    self._update()
+            else:
+                with self._graph_fb:
+                    self._forward_backward()
+                    self._update()
+            return
+        self._graph_fb.launch()
+        if self.world_size > 1:
+            self._allreduce()
+            self._graph_opt.launch()
+
+    def set_batch(self, x: torch.Tensor, b: torch.Tensor, eps: Optional[torch.Tensor] = None) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))   # producers of x / b / eps
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+            self.b.copy_(b.reshape(self.b.shape), non_blocking=True)
+            if eps is not None:
+                self.eps.copy_(eps, non_blocking=True)
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def read_metrics(self) -> Dict[str, float]:
+        self.stream.synchronize()
+        v = self.metrics.cpu().tolist()
+        return {"loss": v[0], "reconstruction_ll": v[1], "kl": v[2], "matching_ll": v[3], "beta": v[4]}
+
+    def evaluate(self, x, b, eps) -> Dict[str, float]:
+        """loss_fn with is_training=False (validation, bax semantics): forward + loss only."""
+        m = self.model
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(self.stream):
+            out = m(x, b, is_training=False, eps=eps)
+            cfg = LossCfg.from_buffer_copy(self.loss_cfg)
+            cfg.grad_scale = 1.0 / x.shape[0]
+            metrics = torch.zeros(8, device=x.device)
+            ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], cfg, self.step_dev, metrics, None,
+                           None, None)
+        self.stream.synchronize()
+        v = metrics.cpu().tolist()
+        return {"loss": v[0], "reconstruction_ll": v[1], "kl": v[2], "matching_ll": v[3], "beta": v[4]}

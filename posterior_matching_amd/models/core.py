@@ -1,0 +1,138 @@
+"""Parameter store, feature handle and workspace shared by the host-side model classes.
+
+The reference keeps parameters in haiku pytrees owned by bax.TrainState; here they live in ONE
+flat float32 device buffer (weights first, 1-D leaves last, so that the optimizer's
+`add_decayed_weights(mask = ndim != 1)` of train_pm_vae.py:76-79 is a prefix of the buffer), with
+matching flat buffers for gradients and the two Adam moments.  288 GB of HBM per GPU make it
+pointless to free or re-use activations: every layer keeps its own buffers, allocated once per
+batch size.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..ops import ACT_NONE
+
+
+@dataclass
+class Feat:
+    """A network output handed to its consumer.
+
+    t        : the stored tensor
+    in_act   : activation the consumer must still apply when it loads `t` (ResidualMLP keeps the
+               pre-activation h and lets the next dense layer apply relu on load)
+    grad_act : activation whose derivative, evaluated on `t`, turns a gradient w.r.t. the
+               activated value into a gradient w.r.t. the producer's pre-activation
+    """
+
+    t: torch.Tensor
+    in_act: int = ACT_NONE
+    grad_act: int = ACT_NONE
+
+
+class ParamStore:
+    def __init__(self):
+        self.specs: "OrderedDict[str, Tuple[Tuple[int, ...], int]]" = OrderedDict()
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self.n_decay = 0
+        self.device = None
+
+    def add(self, name: str, shape, fan_in: int = 0) -> None:
+        """fan_in > 0: haiku TruncatedNormal(stddev = 1/sqrt(fan_in)); 0: zeros."""
+        assert name not in self.specs, name
+        assert self.flat_p is None, "parameters are frozen once allocated"
+        self.specs[name] = (tuple(int(s) for s in shape), int(fan_in))
+
+    @property
+    def num_params(self) -> int:
+        return sum(int(np.prod(s)) for s, _ in self.specs.values())
+
+    def allocate(self, device, seed: int = 1) -> None:
+        """Allocates the flat buffers and draws haiku-default initial values (SURVEY A1/A2/A4:
+        N(0,1) truncated to [-2,2] times 1/sqrt(fan_in); biases and log_scale zero)."""
+        from scipy.stats import truncnorm
+
+        self.device = device
+        rng = np.random.default_rng(seed)
+        host = {}
+        for name, (shape, fan_in) in self.specs.items():      # creation order fixes the RNG stream
+            if fan_in > 0:
+                host[name] = (truncnorm.rvs(-2.0, 2.0, size=shape, random_state=rng) / math.sqrt(fan_in)).astype(np.float32)
+            else:
+                host[name] = np.zeros(shape, np.float32)
+        decayed = [n for n, (s, _) in self.specs.items() if len(s) != 1]
+        plain = [n for n, (s, _) in self.specs.items() if len(s) == 1]
+        total = self.num_params
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        off = 0
+        self.offsets = {}
+        for name in decayed + plain:
+            shape = self.specs[name][0]
+            n = int(np.prod(shape))
+            self.offsets[name] = (off, n)
+            self.p[name] = self.flat_p[off:off + n].view(shape)
+            self.g[name] = self.flat_g[off:off + n].view(shape)
+            self.p[name].copy_(torch.from_numpy(host[name]))
+            off += n
+        self.n_decay = sum(self.offsets[n][1] for n in decayed)
+
+    def load_dict(self, values: Dict[str, "np.ndarray | torch.Tensor"]) -> None:
+        for name, val in values.items():
+            t = torch.as_tensor(np.asarray(val.detach().cpu() if isinstance(val, torch.Tensor) else val),
+                                dtype=torch.float32)
+            self.p[name].copy_(t.reshape(self.p[name].shape))
+
+    def to_dict(self, which: str = "p") -> Dict[str, torch.Tensor]:
+        flat = {"p": self.flat_p, "g": self.flat_g, "m": self.flat_m, "v": self.flat_v}[which]
+        return OrderedDict((n, flat[o:o + c].view(self.specs[n][0]).detach().clone()) for n, (o, c) in
+                           ((n, self.offsets[n]) for n in self.specs))
+
+
+class Workspace:
+    """Named device buffers allocated on first use; shapes are fixed per batch size, so a
+    captured HIP graph always sees the same addresses."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs: Dict[Tuple[str, Tuple[int, ...]], torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        key = (name, tuple(int(s) for s in shape))
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = torch.zeros(key[1], dtype=dtype, device=self.device)
+            self._bufs[key] = buf
+        return buf
+
+
+class Module:
+    """Base of the host-side mirrors of the reference's hk.Module classes."""
+
+    def __init__(self, name: Optional[str] = None):
+        self.name = name or type(self).__name__
+        self.store: Optional[ParamStore] = None
+        self.ws: Optional[Workspace] = None
+
+    def attach(self, store: ParamStore, prefix: str) -> None:
+        self.store, self.prefix = store, prefix
+
+    def P(self, leaf: str) -> torch.Tensor:
+        return self.store.p[f"{self.prefix}/{leaf}"]
+
+    def G(self, leaf: str) -> torch.Tensor:
+        return self.store.g[f"{self.prefix}/{leaf}"]
+
+    def buf(self, name: str, shape) -> torch.Tensor:
+        return self.ws.get(f"{self.prefix}/{name}", shape)

@@ -1,0 +1,211 @@
+"""Host-side mirrors of posterior_matching/models/networks.py of the reference.
+
+Same class names, constructor arguments and registry (`get_network`, reference
+networks.py:138-162); the arithmetic runs in libpmhip.so.  Because there is no autodiff here,
+every network also has an explicit `backward`.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+from ..ops import ACT_LEAKY, ACT_NONE, ACT_RELU, LayerGeom
+from .core import Feat, Module, ParamStore
+
+
+class ConvEncoder(Module):
+    """reference networks.py:9-38: SAME convs (last one VALID), leaky_relu after every layer."""
+
+    def __init__(self, conv_layers: Sequence[Tuple[int, int, int]], name: Optional[str] = None):
+        super().__init__(name)
+        self._conv_layers = [tuple(l) for l in conv_layers]
+
+    def build(self, store: ParamStore, prefix: str, in_shape) -> Tuple[int, ...]:
+        if len(in_shape) != 3:
+            raise ValueError(f"ConvEncoder expects [H, W, C] inputs, got {tuple(in_shape)}")  # chex.assert_rank(x, 4)
+        self.attach(store, prefix)
+        h, w, c = in_shape
+        self.geoms: List[LayerGeom] = []
+        n = len(self._conv_layers)
+        for i, (f, k, s) in enumerate(self._conv_layers):
+            g = LayerGeom.conv(h, w, c, f, k, s, "VALID" if i == n - 1 else "SAME")
+            store.add(f"{prefix}/conv_{i}/w", g.weight_shape, fan_in=k * k * c)
+            store.add(f"{prefix}/conv_{i}/b", (f,))
+            self.geoms.append(g)
+            h, w, c = g.OH, g.OW, f
+        return (h, w, c)
+
+    def __call__(self, x: Feat, is_training: bool = False) -> Feat:
+        assert x.in_act == ACT_NONE
+        B = x.t.shape[0]
+        self._x = x
+        self._outs = []
+        h = x.t
+        for i, g in enumerate(self.geoms):
+            out = self.buf(f"out_{i}", (B, g.OH, g.OW, g.CO))
+            ops.layer_forward(g, h, self.P(f"conv_{i}/w"), self.P(f"conv_{i}/b"), out, out_act=ACT_LEAKY)
+            self._outs.append(out)
+            h = out
+        return Feat(h, ACT_NONE, ACT_LEAKY)
+
+    def backward(self, dpre: torch.Tensor, need_input_grad: bool = False) -> Optional[torch.Tensor]:
+        """dpre: gradient w.r.t. the last layer's pre-activation."""
+        B = dpre.shape[0]
+        for i in reversed(range(len(self.geoms))):
+            g = self.geoms[i]
+            inp = self._outs[i - 1] if i > 0 else self._x.t
+            ops.layer_wgrad(g, inp, dpre, self.G(f"conv_{i}/w"), self.G(f"conv_{i}/b"))
+            if i > 0:
+                dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
+                ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY)
+                dpre = dprev
+            elif need_input_grad:
+                dprev = self.buf("dx", (B, g.IH, g.IW, g.CI))
+                ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=self._x.t, aux_act=self._x.grad_act)
+                return dprev
+        return None
+
+
+class ConvDecoder(Module):
+    """reference networks.py:41-72: z -> [B,1,1,Z] -> transposed convs (first VALID, rest SAME),
+    leaky_relu after EVERY layer including the last."""
+
+    def __init__(self, conv_layers: Sequence[Tuple[int, int, int]], name: Optional[str] = None):
+        super().__init__(name)
+        self._conv_layers = [tuple(l) for l in conv_layers]
+
+    def build(self, store: ParamStore, prefix: str, in_shape) -> Tuple[int, ...]:
+        if len(in_shape) != 1:
+            raise ValueError(f"ConvDecoder expects [Z] inputs, got {tuple(in_shape)}")  # chex.assert_rank(x, 2)
+        self.attach(store, prefix)
+        h, w, c = 1, 1, in_shape[0]
+        self.geoms = []
+        for i, (f, k, s) in enumerate(self._conv_layers):
+            g = LayerGeom.conv_t(h, w, c, f, k, s, "VALID" if i == 0 else "SAME")
+            store.add(f"{prefix}/conv_t_{i}/w", g.weight_shape, fan_in=k * k * c)
+            store.add(f"{prefix}/conv_t_{i}/b", (f,))
+            self.geoms.append(g)
+            h, w, c = g.OH, g.OW, f
+        return (h, w, c)
+
+    def __call__(self, x: Feat, is_training: bool = False) -> Feat:
+        B = x.t.shape[0]
+        self._x = x
+        self._outs = []
+        h = x.t
+        for i, g in enumerate(self.geoms):
+            out = self.buf(f"out_{i}", (B, g.OH, g.OW, g.CO))
+            ops.layer_forward(g, h, self.P(f"conv_t_{i}/w"), self.P(f"conv_t_{i}/b"), out,
+                              in_act=x.in_act if i == 0 else ACT_NONE, out_act=ACT_LEAKY)
+            self._outs.append(out)
+            h = out
+        return Feat(h, ACT_NONE, ACT_LEAKY)
+
+    def backward(self, dpre: torch.Tensor, need_input_grad: bool = True) -> Optional[torch.Tensor]:
+        B = dpre.shape[0]
+        for i in reversed(range(len(self.geoms))):
+            g = self.geoms[i]
+            inp = self._outs[i - 1] if i > 0 else self._x.t
+            ops.layer_wgrad(g, inp, dpre, self.G(f"conv_t_{i}/w"), self.G(f"conv_t_{i}/b"),
+                            in_act=ACT_NONE if i > 0 else self._x.in_act)
+            if i > 0:
+                dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
+                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY)
+                dpre = dprev
+            elif need_input_grad:
+                dz = self.buf("dz", (B, g.CI))
+                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dz, aux=self._x.t, aux_act=self._x.grad_act)
+                return dz
+        return None
+
+
+class ResidualMLP(Module):
+    """reference networks.py:75-135 (activation relu): Linear -> N x [act, Linear, act, dropout,
+    Linear, +residual] -> act.  The pre-activation h is what is stored; consumers apply relu on load."""
+
+    def __init__(self, residual_blocks: int = 2, hidden_units: int = 256, activation: Any = "relu",
+                 activate_final: bool = True, dropout: float = 0.0, w_init: Any = None, layer_norm: bool = False,
+                 name: Optional[str] = None):
+        super().__init__(name)
+        if activation not in ("relu", None) and getattr(activation, "__name__", "") != "relu":
+            raise NotImplementedError("ResidualMLP: only the reference default activation (relu) has a HIP path")
+        if layer_norm:
+            raise NotImplementedError("ResidualMLP(layer_norm=True) has no HIP path yet (not used by pm_vae_gas / pm_vae_mnist)")
+        if dropout:
+            raise NotImplementedError("ResidualMLP(dropout>0) has no HIP path yet (not used by pm_vae_gas / pm_vae_mnist)")
+        if w_init is not None:
+            raise NotImplementedError("custom w_init")
+        self._residual_blocks = residual_blocks
+        self._hidden_units = hidden_units
+        self._activate_final = activate_final
+
+    def build(self, store: ParamStore, prefix: str, in_shape) -> Tuple[int, ...]:
+        if len(in_shape) != 1:
+            raise ValueError(f"ResidualMLP expects [D] inputs, got {tuple(in_shape)}")  # chex.assert_rank(x, 2)
+        self.attach(store, prefix)
+        fin, hu = int(in_shape[0]), self._hidden_units
+        self.g_in = LayerGeom.dense(fin, hu)
+        self.g_hid = LayerGeom.dense(hu, hu)
+        store.add(f"{prefix}/linear_0/w", (fin, hu), fan_in=fin)
+        store.add(f"{prefix}/linear_0/b", (hu,))
+        for k in range(self._residual_blocks):
+            for j in range(2):
+                store.add(f"{prefix}/block_{k}/linear_{j}/w", (hu, hu), fan_in=hu)
+                store.add(f"{prefix}/block_{k}/linear_{j}/b", (hu,))
+        return (hu,)
+
+    def __call__(self, x: Feat, is_training: bool = False) -> Feat:
+        rows, hu = x.t.shape[0], self._hidden_units
+        self._x = x
+        h = self.buf("h_0", (rows, hu))
+        ops.layer_forward(self.g_in, x.t, self.P("linear_0/w"), self.P("linear_0/b"), h, in_act=x.in_act)
+        self._h, self._u = [h], []
+        for k in range(self._residual_blocks):
+            u = self.buf(f"u_{k}", (rows, hu))
+            ops.layer_forward(self.g_hid, h, self.P(f"block_{k}/linear_0/w"), self.P(f"block_{k}/linear_0/b"), u,
+                              in_act=ACT_RELU)
+            hn = self.buf(f"h_{k + 1}", (rows, hu))
+            ops.layer_forward(self.g_hid, u, self.P(f"block_{k}/linear_1/w"), self.P(f"block_{k}/linear_1/b"), hn,
+                              in_act=ACT_RELU, res=h)
+            self._u.append(u)
+            self._h.append(hn)
+            h = hn
+        if self._activate_final:
+            return Feat(h, ACT_RELU, ACT_RELU)
+        return Feat(h, ACT_NONE, ACT_NONE)
+
+    def backward(self, dh: torch.Tensor, need_input_grad: bool = False) -> Optional[torch.Tensor]:
+        """dh: gradient w.r.t. the stored pre-activation h of the last block."""
+        rows, hu = dh.shape[0], self._hidden_units
+        for k in reversed(range(self._residual_blocks)):
+            h, u = self._h[k], self._u[k]
+            ops.layer_wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),
+                            in_act=ACT_RELU)
+            du = self.buf(f"du_{k}", (rows, hu))
+            ops.layer_dgrad(self.g_hid, dh, self.P(f"block_{k}/linear_1/w"), du, aux=u, aux_act=ACT_RELU)
+            ops.layer_wgrad(self.g_hid, h, du, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"),
+                            in_act=ACT_RELU)
+            dprev = self.buf(f"dh_{k}", (rows, hu))
+            ops.layer_dgrad(self.g_hid, du, self.P(f"block_{k}/linear_0/w"), dprev, aux=h, aux_act=ACT_RELU, res=dh)
+            dh = dprev
+        ops.layer_wgrad(self.g_in, self._x.t, dh, self.G("linear_0/w"), self.G("linear_0/b"), in_act=self._x.in_act)
+        if need_input_grad:
+            dx = self.buf("dx", (rows, self.g_in.CI))
+            ops.layer_dgrad(self.g_in, dh, self.P("linear_0/w"), dx, aux=self._x.t, aux_act=self._x.grad_act)
+            return dx
+        return None
+
+
+_NETWORKS = {
+    "ConvEncoder": ConvEncoder,
+    "ConvDecoder": ConvDecoder,
+    "ResidualMLP": ResidualMLP,
+}
+
+
+def get_network(network_type: str, network_config: Optional[Dict[str, Any]] = None, name: Optional[str] = None):
+    """reference networks.py:145-162 (KeyError on unknown names, like the reference's dict lookup)."""
+    network_config = dict(network_config or {})
+    return _NETWORKS[network_type](**network_config, name=name)

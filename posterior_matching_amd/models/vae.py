@@ -1,0 +1,139 @@
+"""Host-side mirror of posterior_matching/models/vae.py of the reference: PosteriorMatchingVAE.
+
+Same constructor / from_config / __call__ contract (reference vae.py:35-144); the per-step
+arithmetic runs in libpmhip.so.  JAX's functional autodiff is replaced by an explicit
+`backward(g_rec, g_kl, g_mll)` over the buffers the forward left in HBM.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Mapping, Optional
+
+import torch
+
+from .. import ops
+from ..ops import ACT_NONE
+from .core import Feat, Module, ParamStore, Workspace
+from .distributions import AutoregressiveGMM, TriLGaussian, get_distribution
+from .networks import get_network
+
+
+class PosteriorMatchingVAE(Module):
+    """A VAE with an extra (partial) encoder trained by Posterior Matching (reference vae.py:16-59)."""
+
+    def __init__(self, latent_dim: int, encoder_net, decoder_net, partial_encoder_net, posterior_dist, decoder_dist,
+                 partial_posterior_dist, matching_ll_stop_gradients: bool = False, name: Optional[str] = None,
+                 device: Optional[str] = None, seed: int = 1):
+        super().__init__(name)
+        self.latent_dim = latent_dim
+        self.encoder_net, self.posterior_dist = encoder_net, posterior_dist
+        self.decoder_net, self.decoder_dist = decoder_net, decoder_dist
+        self.partial_encoder_net, self.partial_posterior_dist = partial_encoder_net, partial_posterior_dist
+        self._matching_ll_stop_gradients = matching_ll_stop_gradients
+        self._device = device
+        self._seed = seed
+        self.store: Optional[ParamStore] = None
+        if not isinstance(posterior_dist, TriLGaussian):
+            raise NotImplementedError("posterior_dist must be TriLGaussian (the only posterior head on the hot path)")
+        if not isinstance(partial_posterior_dist, (AutoregressiveGMM, TriLGaussian)):
+            raise NotImplementedError("partial_posterior_dist must be AutoregressiveGMM or TriLGaussian")
+
+    @classmethod
+    def from_config(cls, config: Mapping[str, Any], name: Optional[str] = None, device: Optional[str] = None,
+                    seed: int = 1) -> "PosteriorMatchingVAE":
+        """reference vae.py:61-118, including its key quirk: only `partial_posterior_dist[_config]`
+        is read, so configs that set `masked_posterior_dist` (configs/pm_vae_gas.py:24-27) get
+        partial posterior = posterior_dist.  The reference's in-place mutation of the shared
+        `posterior_dist_config` dict is harmless here and not reproduced."""
+        encoder_net = get_network(config["encoder_net"], config.get("encoder_net_config"), name="encoder_net")
+        decoder_net = get_network(config["decoder_net"], config.get("decoder_net_config"), name="decoder_net")
+        partial_encoder_net = get_network(
+            config.get("partial_encoder_net", config["encoder_net"]),
+            config.get("partial_encoder_net_config", config.get("encoder_net_config")),
+            name="partial_encoder_net")
+        posterior_dist_config = dict(config.get("posterior_dist_config", {}) or {})
+        posterior_dist_config["event_size"] = config["latent_dim"]
+        partial_posterior_dist_config = dict(config.get("partial_posterior_dist_config", posterior_dist_config) or {})
+        partial_posterior_dist_config["event_size"] = config["latent_dim"]
+        posterior_dist = get_distribution(config["posterior_dist"], posterior_dist_config, name="posterior_dist")
+        decoder_dist = get_distribution(config["decoder_dist"], config.get("decoder_dist_config"), name="decoder_dist")
+        partial_posterior_dist = get_distribution(config.get("partial_posterior_dist", config["posterior_dist"]),
+                                                  partial_posterior_dist_config, name="partial_posterior_dist")
+        return cls(config["latent_dim"], encoder_net, decoder_net, partial_encoder_net, posterior_dist, decoder_dist,
+                   partial_posterior_dist, config.get("matching_ll_stop_gradients", False), name=name, device=device,
+                   seed=seed)
+
+    # ------------------------------------------------------------------------------------------
+    def init(self, x_shape, device=None, seed: Optional[int] = None) -> None:
+        """Creates the parameters for per-example inputs of shape `x_shape` ([H,W,C] or [D]);
+        the counterpart of haiku's lazy init at the first call (bax: PRNGKey(seed))."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("posterior_matching_amd needs an MI355X: there is no CPU fallback path")
+        from .. import _lib
+
+        _lib.load()
+        device = torch.device(device or self._device or "cuda:0")
+        store, ws = ParamStore(), Workspace(device)
+        x_shape = tuple(int(s) for s in x_shape)
+        xb_shape = x_shape[:-1] + (2 * x_shape[-1],)
+        mods = [self.encoder_net, self.posterior_dist, self.decoder_net, self.decoder_dist, self.partial_encoder_net,
+                self.partial_posterior_dist]
+        for m in mods:
+            m.ws = ws
+        f = self.encoder_net.build(store, "encoder_net", x_shape)
+        self.posterior_dist.build(store, "posterior_dist", f)
+        f = self.decoder_net.build(store, "decoder_net", (self.latent_dim,))
+        self.decoder_dist.build(store, "decoder_dist", f)
+        f = self.partial_encoder_net.build(store, "partial_encoder_net", xb_shape)
+        self.partial_posterior_dist.build(store, "partial_posterior_dist", f)
+        store.allocate(device, self._seed if seed is None else seed)
+        self.store, self.ws, self._x_shape = store, ws, x_shape
+        self.attach(store, "")
+
+    @property
+    def num_params(self) -> int:
+        return self.store.num_params
+
+    def __call__(self, x: torch.Tensor, b: torch.Tensor, is_training: bool = False,
+                 eps: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """reference vae.py:120-144.  `eps` is the N(0,1) draw behind posterior.sample (required:
+        the caller owns the RNG, see trainer.py).  Returns per-example `reconstruction_ll`, `kl`,
+        `matching_ll` (device tensors owned by the model, overwritten by the next call)."""
+        if self.store is None:
+            self.init(x.shape[1:], x.device)
+        if eps is None:
+            raise ValueError("eps (the reparameterisation noise, [B, latent_dim]) must be given")
+        self._xin, self._b = x, b
+        feat = self.encoder_net(Feat(x), is_training=is_training)
+        z, kl = self.posterior_dist.sample_and_kl(feat, eps)
+        dec = self.decoder_net(Feat(z), is_training=is_training)
+        rec = self.decoder_dist.log_prob_sum(dec, x)
+        xob = self.ws.get("x_o_b", tuple(x.shape[:-1]) + (x.shape[-1] + b.shape[-1],))
+        ops.mask_concat(x, b, xob)
+        pfeat = self.partial_encoder_net(Feat(xob), is_training=is_training)
+        mll = self.partial_posterior_dist.log_prob(pfeat, z)
+        self._z = z
+        return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll}
+
+    def backward(self, g_rec: torch.Tensor, g_kl: torch.Tensor, g_mll: torch.Tensor) -> None:
+        """Accumulates d loss / d params into the flat gradient buffer given the per-example
+        gradients of the loss w.r.t. the three outputs (zero the buffer first: `zero_grad`)."""
+        dpre = self.decoder_dist.backward(g_rec)
+        dz = self.decoder_net.backward(dpre, need_input_grad=True)
+        dz_acc = None if self._matching_ll_stop_gradients else dz          # vae.py:136-137
+        dpenc = self.partial_posterior_dist.backward_log_prob(g_mll, dz_acc)
+        self.partial_encoder_net.backward(dpenc, need_input_grad=False)
+        denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
+        self.encoder_net.backward(denc, need_input_grad=False)
+
+    def zero_grad(self) -> None:
+        ops.fill_zero(self.store.flat_g)
+
+    # checkpoint-style access (reference: TrainState.params pytree)
+    def params_dict(self) -> Dict[str, torch.Tensor]:
+        return self.store.to_dict("p")
+
+    def grads_dict(self) -> Dict[str, torch.Tensor]:
+        return self.store.to_dict("g")
+
+    def load_params(self, values) -> None:
+        self.store.load_dict(values)

@@ -1,0 +1,327 @@
+"""Thin typed wrappers from torch device tensors to the C ABI (include/pmhip.h).
+
+PyTorch is used for device memory and streams only; every arithmetic op of the step runs in
+libpmhip.so.  All calls enqueue on torch's current stream and never synchronise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, LEAKY_SLOPE, GatherDesc  # noqa: F401
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expects contiguous f32 device tensors"
+    return t.data_ptr()
+
+
+def _iptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.int32
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------
+# conv geometry: how each layer maps onto pm_gather_desc
+# ------------------------------------------------------------------------------------------
+def same_padding(in_size: int, k: int, s: int):
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return total // 2, total - total // 2
+
+
+def conv_transpose_padding(k: int, s: int, padding: str):
+    if padding == "SAME":
+        pad_len = k + s - 2
+        pad_a = k - 1 if s > k - 1 else int(math.ceil(pad_len / 2))
+    elif padding == "VALID":
+        pad_len = k + s - 2 + max(k - s, 0)
+        pad_a = k - 1
+    else:
+        raise ValueError(padding)
+    return pad_a, pad_len - pad_a
+
+
+@dataclass
+class LayerGeom:
+    """A conv / transposed-conv / dense layer: x [B,IH,IW,CI] -> y [B,OH,OW,CO]."""
+
+    kind: str  # "conv" | "convT" | "dense"
+    IH: int
+    IW: int
+    CI: int
+    OH: int
+    OW: int
+    CO: int
+    k: int = 1
+    s: int = 1
+    pad: int = 0  # pad_lo (conv) or pad_a (convT)
+
+    @staticmethod
+    def conv(ih, iw, ci, co, k, s, padding):
+        if padding == "SAME":
+            oh, ow = -(-ih // s), -(-iw // s)
+            pad = same_padding(ih, k, s)[0]
+            assert same_padding(iw, k, s)[0] == pad
+        else:
+            oh, ow, pad = (ih - k) // s + 1, (iw - k) // s + 1, 0
+        return LayerGeom("conv", ih, iw, ci, oh, ow, co, k, s, pad)
+
+    @staticmethod
+    def conv_t(ih, iw, ci, co, k, s, padding):
+        pa, pb = conv_transpose_padding(k, s, padding)
+        oh = (ih - 1) * s + 1 + pa + pb - k + 1
+        ow = (iw - 1) * s + 1 + pa + pb - k + 1
+        return LayerGeom("convT", ih, iw, ci, oh, ow, co, k, s, pa)
+
+    @staticmethod
+    def dense(ci, co):
+        return LayerGeom("dense", 1, 1, ci, 1, 1, co)
+
+    @property
+    def weight_shape(self):
+        if self.kind == "conv":
+            return (self.k, self.k, self.CI, self.CO)
+        if self.kind == "convT":
+            return (self.k, self.k, self.CO, self.CI)
+        return (self.CI, self.CO)
+
+    def _desc(self, B: int, mode: str, groups=1, in_gs=0, w_gs=0, out_gs=0, bias_gs=0, w_ld=None) -> GatherDesc:
+        """mode: 'fwd' (x -> y), 'dgrad' (dy -> dx) or 'wgrad' (same index rule as fwd).
+        w_ld overrides the dense weight's row stride (grouped column slices of a wider matrix)."""
+        g = self
+        d = GatherDesc()
+        d.B, d.KH, d.KW, d.groups = B, g.k, g.k, groups
+        d.in_gs, d.w_gs, d.out_gs, d.bias_gs = in_gs, w_gs, out_gs, bias_gs
+        if mode == "dgrad":  # the gathered operand is dy, the produced one dx
+            d.in_gs, d.out_gs = out_gs, in_gs
+        d.in_act = d.out_act = d.aux_act = ACT_NONE
+        d.slope = LEAKY_SLOPE
+        fwd_like = mode in ("fwd", "wgrad")
+        if fwd_like:
+            d.IH, d.IW, d.C, d.OH, d.OW, d.N = g.IH, g.IW, g.CI, g.OH, g.OW, g.CO
+        else:
+            d.IH, d.IW, d.C, d.OH, d.OW, d.N = g.OH, g.OW, g.CO, g.IH, g.IW, g.CI
+        if g.kind in ("conv", "dense"):
+            ld = w_ld if w_ld is not None else g.CO
+            if fwd_like:
+                d.a, d.cs, d.off, d.d = g.s, 1, -g.pad, 1
+                d.wts, d.wcs, d.wns = g.CI * g.CO, ld, 1
+            else:
+                d.a, d.cs, d.off, d.d = 1, -1, g.pad, g.s
+                d.wts, d.wcs, d.wns = g.CI * g.CO, 1, ld
+        else:  # convT, weight [k,k,CO,CI]
+            if fwd_like:
+                d.a, d.cs, d.off, d.d = 1, 1, -g.pad, g.s
+                d.wts, d.wcs, d.wns = g.CO * g.CI, 1, g.CI
+            else:
+                d.a, d.cs, d.off, d.d = g.s, -1, g.pad, 1
+                d.wts, d.wcs, d.wns = g.CO * g.CI, g.CI, 1
+        return d
+
+
+def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
+    lib = _lib.load()
+    _lib.check(lib.pm_gather_gemm(_stream(), C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res),
+                                  _ptr(out)), "pm_gather_gemm")
+
+
+def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
+    lib = _lib.load()
+    _lib.check(lib.pm_gather_wgrad(_stream(), C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db)),
+               "pm_gather_wgrad")
+
+
+def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE, res=None, **group_kw) -> None:
+    B = group_kw.pop("B", None) or x.shape[0]
+    d = g._desc(B, "fwd", **group_kw)
+    d.in_act, d.out_act = in_act, out_act
+    gather_gemm(d, x, w, b, None, res, out)
+
+
+def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, **group_kw) -> None:
+    B = group_kw.pop("B", None) or dy.shape[0]
+    d = g._desc(B, "dgrad", **group_kw)
+    d.aux_act = aux_act if aux is not None else ACT_NONE
+    gather_gemm(d, dy, w, None, aux if aux_act != ACT_NONE else None, res, dx)
+
+
+def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, **group_kw) -> None:
+    B = group_kw.pop("B", None) or x.shape[0]
+    d = g._desc(B, "wgrad", **group_kw)
+    d.in_act = in_act
+    # conv:  dw[ky,kx,ci,co] = sum x[., sy, sx, ci] * dy[., p, q, co]
+    # convT: dw[ky,kx,co,ci] = sum xdil[., p+ky-pa, ., ci] * dy[., p, q, co]: same index rule as the forward
+    gather_wgrad(d, x, dy, dw, db)
+
+
+# ------------------------------------------------------------------------------------------
+# heads / loss / optimizer
+# ------------------------------------------------------------------------------------------
+def mask_concat(x, b, out) -> None:
+    C_, Cb = x.shape[-1], b.shape[-1]
+    R = x.numel() // C_
+    _lib.check(_lib.load().pm_mask_concat(_stream(), _ptr(x), _ptr(b), _ptr(out), R, C_, Cb), "pm_mask_concat")
+
+
+def tril_sample_kl_fwd(params, eps, z, kl) -> None:
+    B, k = eps.shape
+    _lib.check(_lib.load().pm_tril_sample_kl_fwd(_stream(), _ptr(params), _ptr(eps), _ptr(z), _ptr(kl), B, k),
+               "pm_tril_sample_kl_fwd")
+
+
+def tril_sample_kl_bwd(params, eps, dz, g_kl, dparams) -> None:
+    B, k = eps.shape
+    _lib.check(_lib.load().pm_tril_sample_kl_bwd(_stream(), _ptr(params), _ptr(eps), _ptr(dz), _ptr(g_kl),
+                                                 _ptr(dparams), B, k), "pm_tril_sample_kl_bwd")
+
+
+def tril_logprob_fwd(params, z, lp) -> None:
+    B, k = z.shape
+    _lib.check(_lib.load().pm_tril_logprob_fwd(_stream(), _ptr(params), _ptr(z), _ptr(lp), B, k), "pm_tril_logprob_fwd")
+
+
+def tril_logprob_bwd(params, z, g, dparams, dz) -> None:
+    B, k = z.shape
+    _lib.check(_lib.load().pm_tril_logprob_bwd(_stream(), _ptr(params), _ptr(z), _ptr(g), _ptr(dparams), _ptr(dz), B, k),
+               "pm_tril_logprob_bwd")
+
+
+def bernoulli_ll_fwd(logits, x, ll) -> None:
+    B = x.shape[0]
+    _lib.check(_lib.load().pm_bernoulli_ll_fwd(_stream(), _ptr(logits), _ptr(x), _ptr(ll), B, x.numel() // B),
+               "pm_bernoulli_ll_fwd")
+
+
+def bernoulli_ll_bwd(logits, x, g, dpre, act, slope=LEAKY_SLOPE) -> None:
+    B = x.shape[0]
+    _lib.check(_lib.load().pm_bernoulli_ll_bwd(_stream(), _ptr(logits), _ptr(x), _ptr(g), _ptr(dpre), B,
+                                               x.numel() // B, act, slope), "pm_bernoulli_ll_bwd")
+
+
+def normal_ll_fwd(loc, x, log_scale, ll) -> None:
+    B = x.shape[0]
+    _lib.check(_lib.load().pm_normal_ll_fwd(_stream(), _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(ll), B,
+                                            x.numel() // B), "pm_normal_ll_fwd")
+
+
+def normal_ll_bwd(loc, x, log_scale, g, dloc, d_log_scale) -> None:
+    B = x.shape[0]
+    _lib.check(_lib.load().pm_normal_ll_bwd(_stream(), _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(g), _ptr(dloc),
+                                            _ptr(d_log_scale), B, x.numel() // B), "pm_normal_ll_bwd")
+
+
+def argmm_build_input(z, ctx, inp) -> None:
+    B, k = z.shape
+    _lib.check(_lib.load().pm_argmm_build_input(_stream(), _ptr(z), _ptr(ctx), _ptr(inp), B, k, ctx.numel() // B),
+               "pm_argmm_build_input")
+
+
+def argmm_input_bwd(dinp, dz, dctx, B, k, ctx_dim, accumulate_dz, ctx=None, ctx_act=ACT_NONE) -> None:
+    _lib.check(_lib.load().pm_argmm_input_bwd(_stream(), _ptr(dinp), _ptr(dz), _ptr(dctx), B, k, ctx_dim,
+                                              int(accumulate_dz), _ptr(ctx), ctx_act, LEAKY_SLOPE),
+               "pm_argmm_input_bwd")
+
+
+def gmm_logprob_fwd(head, z, mll, nc) -> None:
+    B, k = z.shape
+    _lib.check(_lib.load().pm_gmm_logprob_fwd(_stream(), _ptr(head), _ptr(z), _ptr(mll), B, k, nc), "pm_gmm_logprob_fwd")
+
+
+def gmm_logprob_bwd(head, z, g, dhead, dz, nc, accumulate_dz) -> None:
+    B, k = z.shape
+    _lib.check(_lib.load().pm_gmm_logprob_bwd(_stream(), _ptr(head), _ptr(z), _ptr(g), _ptr(dhead), _ptr(dz), B, k, nc,
+                                              int(accumulate_dz)), "pm_gmm_logprob_bwd")
+
+
+def pmvae_loss(rec, kl, mll, cfg: _lib.LossCfg, step_dev, out, g_rec, g_kl, g_mll) -> None:
+    _lib.check(_lib.load().pm_pmvae_loss(_stream(), _ptr(rec), _ptr(kl), _ptr(mll), rec.shape[0], C.byref(cfg),
+                                         _iptr(step_dev), _ptr(out), _ptr(g_rec), _ptr(g_kl), _ptr(g_mll)),
+               "pm_pmvae_loss")
+
+
+def adam_step(p, g, m, v, n_decay, count_dev, cfg: _lib.AdamCfg) -> None:
+    _lib.check(_lib.load().pm_adam_step(_stream(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay,
+                                        _iptr(count_dev), C.byref(cfg)), "pm_adam_step")
+
+
+def counter_increment(count_dev) -> None:
+    _lib.check(_lib.load().pm_counter_increment(_stream(), _iptr(count_dev)), "pm_counter_increment")
+
+
+def normal_fill(out, seed: int, step_dev, stream_id: int = 0) -> None:
+    _lib.check(_lib.load().pm_normal_fill(_stream(), _ptr(out), out.numel(), seed & (2 ** 64 - 1), _iptr(step_dev),
+                                          stream_id), "pm_normal_fill")
+
+
+def fill_zero(t) -> None:
+    _lib.check(_lib.load().pm_fill_zero(_stream(), t.data_ptr(), t.numel() * t.element_size()), "pm_fill_zero")
+
+
+def axpy1(x, y) -> None:
+    _lib.check(_lib.load().pm_axpy1(_stream(), _ptr(x), _ptr(y), x.numel()), "pm_axpy1")
+
+
+class Graph:
+    """HIP graph of a launch sequence captured on the current stream."""
+
+    def __init__(self):
+        self._exec = C.c_void_p()
+
+    def __enter__(self):
+        _lib.check(_lib.load().pm_graph_begin(_stream()), "pm_graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = _lib.load().pm_graph_end(_stream(), C.byref(self._exec))
+        if et is None:
+            _lib.check(rc, "pm_graph_end")
+        return False
+
+    def launch(self) -> None:
+        _lib.check(_lib.load().pm_graph_launch(self._exec, _stream()), "pm_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._exec:
+                _lib.load().pm_graph_destroy(self._exec)
+        except Exception:
+            pass
+
+
+class Event:
+    """hipEvent_t recorded on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self._ev = C.c_void_p()
+        _lib.check(_lib.load().pm_event_create(C.byref(self._ev)), "pm_event_create")
+
+    def record(self) -> None:
+        _lib.check(_lib.load().pm_event_record(self._ev, _stream()), "pm_event_record")
+
+    def synchronize(self) -> None:
+        _lib.check(_lib.load().pm_event_synchronize(self._ev), "pm_event_synchronize")
+
+    def elapsed_ms(self, end: "Event") -> float:
+        ms = C.c_float()
+        _lib.check(_lib.load().pm_event_elapsed_ms(self._ev, end._ev, C.byref(ms)), "pm_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().pm_event_destroy(self._ev)
+        except Exception:
+            pass

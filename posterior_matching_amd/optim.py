@@ -1,0 +1,100 @@
+"""The optax pieces the reference's train_pm_vae.py:74-83 composes, as plain spec objects.
+
+Only the exact chain the reference builds is executable - it is lowered to ONE fused HIP kernel
+(pm_adam_step, csrc/pm_optim.hip).  Any other composition raises instead of silently running a
+different optimizer.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable, Optional
+
+
+@dataclass
+class ExponentialDecay:
+    """optax.exponential_decay(init_value, transition_steps, decay_rate), non-staircase."""
+
+    init_value: float
+    transition_steps: float
+    decay_rate: float
+
+    def __call__(self, count: int) -> float:
+        return self.init_value * self.decay_rate ** (count / self.transition_steps)
+
+
+def exponential_decay(init_value, transition_steps, decay_rate, **unsupported) -> ExponentialDecay:
+    if unsupported:
+        raise NotImplementedError(f"exponential_decay options {sorted(unsupported)} have no HIP path")
+    return ExponentialDecay(float(init_value), float(transition_steps), float(decay_rate))
+
+
+@dataclass
+class ScaleByAdam:
+    b1: float = 0.9
+    b2: float = 0.999
+    eps: float = 1e-8
+    eps_root: float = 0.0
+
+
+def scale_by_adam(b1=0.9, b2=0.999, eps=1e-8, eps_root=0.0) -> ScaleByAdam:
+    if eps_root != 0.0:
+        raise NotImplementedError("eps_root != 0")
+    return ScaleByAdam(b1, b2, eps, eps_root)
+
+
+@dataclass
+class AddDecayedWeights:
+    weight_decay: float = 0.0
+    mask: Any = None  # the reference's mask is `ndim != 1`; that is what the kernel implements
+
+
+def add_decayed_weights(weight_decay=0.0, mask=None) -> AddDecayedWeights:
+    return AddDecayedWeights(float(weight_decay), mask)
+
+
+@dataclass
+class ScaleBySchedule:
+    schedule: Callable[[int], float]
+
+
+def scale_by_schedule(schedule) -> ScaleBySchedule:
+    return ScaleBySchedule(schedule)
+
+
+@dataclass
+class Scale:
+    factor: float
+
+
+def scale(factor) -> Scale:
+    return Scale(float(factor))
+
+
+@dataclass
+class Chain:
+    adam: ScaleByAdam
+    decay: AddDecayedWeights
+    schedule: ExponentialDecay
+
+    def adam_cfg(self, grad_scale: float = 1.0):
+        from ._lib import AdamCfg
+
+        c = AdamCfg()
+        c.b1, c.b2, c.eps = self.adam.b1, self.adam.b2, self.adam.eps
+        c.weight_decay = self.decay.weight_decay
+        c.lr_init, c.lr_decay_rate = self.schedule.init_value, self.schedule.decay_rate
+        c.lr_transition_steps = self.schedule.transition_steps
+        c.grad_scale = grad_scale
+        return c
+
+
+def chain(*transforms) -> Chain:
+    """optax.chain(scale_by_adam, add_decayed_weights, scale_by_schedule(exponential_decay), scale(-1))."""
+    if (len(transforms) != 4 or not isinstance(transforms[0], ScaleByAdam)
+            or not isinstance(transforms[1], AddDecayedWeights) or not isinstance(transforms[2], ScaleBySchedule)
+            or not isinstance(transforms[2].schedule, ExponentialDecay) or not isinstance(transforms[3], Scale)
+            or transforms[3].factor != -1.0):
+        raise NotImplementedError(
+            "only chain(scale_by_adam, add_decayed_weights, scale_by_schedule(exponential_decay), scale(-1.0)) "
+            "(train_pm_vae.py:74-83) is lowered to the fused HIP optimizer")
+    return Chain(transforms[0], transforms[1], transforms[2].schedule)
