@@ -92,6 +92,9 @@ SIGNATURES = {
     "pm_event_synchronize": [_P],
     "pm_event_elapsed_ms": [_P, _P, C.POINTER(_F)],
     "pm_event_destroy": [_P],
+    "pm_query_gemm_plan": [C.POINTER(GatherDesc), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
+    "pm_query_wgrad_plan": [C.POINTER(GatherDesc), _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I),
+                            C.POINTER(_I)],
     "pm_version": [],
 }
 _OTHER_RESTYPE = {"pm_strerror": ([_I], C.c_char_p), "pm_last_error": ([], C.c_char_p)}
@@ -108,6 +111,11 @@ def load() -> C.CDLL:
         raise PmHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C posterior_matching_amd/csrc` (there is no CPU fallback)")
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import it first so that
+    # libpmhip.so binds to the SAME HIP runtime that owns torch's streams and allocations; two
+    # runtimes in one process cannot see each other's devices ("no ROCm-capable device").
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)

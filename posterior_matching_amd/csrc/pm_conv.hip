@@ -512,6 +512,45 @@ void launch_wgrad(hipStream_t s, const WgradArgs& a, dim3 grid, bool vec4, bool 
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
+struct GemmPlan { int bm, bn, vec; };
+struct WgradPlan { int rc, rn, vec, dvec, nkb, nnb, splits, chunks_per_split; };
+
+GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
+    const int M = g.M, N = g.N;
+    auto nwg = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * groups; };
+    GemmPlan p{128, 32, vec4 ? 4 : 1};
+    if (N <= 32) {
+        p.bm = 128; p.bn = 32;
+    } else if (N <= 64) {
+        p.bn = 64;
+        p.bm = nwg(128, 64) >= 256 ? 128 : 64;
+    } else {
+        if (nwg(128, 128) >= 256) { p.bm = 128; p.bn = 128; }
+        else if (nwg(64, 128) >= 256) { p.bm = 64; p.bn = 128; }
+        else if (nwg(64, 64) >= 2 * nwg(32, 128)) { p.bm = 64; p.bn = 64; }
+        else { p.bm = 32; p.bn = 128; }
+    }
+    return p;
+}
+
+WgradPlan plan_wgrad(const Geom& g, int groups, bool vec4, bool dvec4) {
+    WgradPlan p;
+    p.vec = vec4 ? 4 : 1;
+    p.dvec = dvec4 ? 4 : 1;
+    p.rc = (vec4 && g.K >= 64) ? 2 : 1;
+    p.rn = g.N > 32 ? 2 : 1;
+    p.nkb = (g.K + 32 * p.rc - 1) / (32 * p.rc);
+    p.nnb = (g.N + 32 * p.rn - 1) / (32 * p.rn);
+    const int total_chunks = (g.M + 127) / 128;
+    long long blocks = (long long)p.nkb * p.nnb * groups;
+    int splits = (int)((1024 + blocks - 1) / blocks);
+    if (splits < 1) splits = 1;
+    if (splits > total_chunks) splits = total_chunks;
+    p.chunks_per_split = (total_chunks + splits - 1) / splits;
+    p.splits = (total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    return p;
+}
+
 }  // namespace
 
 extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w,
@@ -522,19 +561,14 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     const bool vec4 = (d->C % 4 == 0) && aligned16(in) && (d->in_gs % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
-    const int M = a.g.M, N = a.g.N, G = d->groups;
-    auto nwg = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * G; };
-    if (N <= 32) {
-        launch_gemm<128, 32>(s, a, G, vec4);
-    } else if (N <= 64) {
-        if (nwg(128, 64) >= 256) launch_gemm<128, 64>(s, a, G, vec4);
-        else launch_gemm<64, 64>(s, a, G, vec4);
-    } else {
-        if (nwg(128, 128) >= 256) launch_gemm<128, 128>(s, a, G, vec4);
-        else if (nwg(64, 128) >= 256) launch_gemm<64, 128>(s, a, G, vec4);
-        else if (nwg(64, 64) >= 2 * nwg(32, 128)) launch_gemm<64, 64>(s, a, G, vec4);
-        else launch_gemm<32, 128>(s, a, G, vec4);
-    }
+    const int G = d->groups;
+    const GemmPlan p = plan_gemm(a.g, G, vec4);
+    if (p.bm == 128 && p.bn == 32) launch_gemm<128, 32>(s, a, G, vec4);
+    else if (p.bm == 128 && p.bn == 64) launch_gemm<128, 64>(s, a, G, vec4);
+    else if (p.bm == 64 && p.bn == 64) launch_gemm<64, 64>(s, a, G, vec4);
+    else if (p.bm == 128 && p.bn == 128) launch_gemm<128, 128>(s, a, G, vec4);
+    else if (p.bm == 64 && p.bn == 128) launch_gemm<64, 128>(s, a, G, vec4);
+    else launch_gemm<32, 128>(s, a, G, vec4);
     return pm_check_launch("pm_gather_gemm");
 }
 
@@ -546,22 +580,35 @@ extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, cons
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     const bool vec4 = (d->C % 4 == 0) && aligned16(gathered) && (d->in_gs % 4 == 0);
     const bool dvec4 = (d->N % 4 == 0) && aligned16(dense) && (d->out_gs % 4 == 0);
-    const int rc = (vec4 && a.g.K >= 64) ? 2 : 1;
-    const int rn = a.g.N > 32 ? 2 : 1;
-    const int nkb = (a.g.K + 32 * rc - 1) / (32 * rc);
-    const int nnb = (a.g.N + 32 * rn - 1) / (32 * rn);
-    const int total_chunks = (a.g.M + 127) / 128;
-    long long blocks = (long long)nkb * nnb * d->groups;
-    int splits = (int)((1024 + blocks - 1) / blocks);
-    if (splits < 1) splits = 1;
-    if (splits > total_chunks) splits = total_chunks;
-    a.chunks_per_split = (total_chunks + splits - 1) / splits;
-    splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    dim3 grid(nkb * nnb, splits, d->groups);
+    const WgradPlan p = plan_wgrad(a.g, d->groups, vec4, dvec4);
+    a.chunks_per_split = p.chunks_per_split;
+    dim3 grid(p.nkb * p.nnb, p.splits, d->groups);
     hipStream_t s = (hipStream_t)stream;
-    if (rc == 2 && rn == 2) launch_wgrad<2, 2>(s, a, grid, vec4, dvec4);
-    else if (rc == 2) launch_wgrad<2, 1>(s, a, grid, vec4, dvec4);
-    else if (rn == 2) launch_wgrad<1, 2>(s, a, grid, vec4, dvec4);
+    if (p.rc == 2 && p.rn == 2) launch_wgrad<2, 2>(s, a, grid, vec4, dvec4);
+    else if (p.rc == 2) launch_wgrad<2, 1>(s, a, grid, vec4, dvec4);
+    else if (p.rn == 2) launch_wgrad<1, 2>(s, a, grid, vec4, dvec4);
     else launch_wgrad<1, 1>(s, a, grid, vec4, dvec4);
     return pm_check_launch("pm_gather_wgrad");
+}
+
+// Which kernel instantiation a problem dispatches to (bench.py names its roofline row with it).
+extern "C" int pm_query_gemm_plan(const pm_gather_desc* d, int in_aligned16, int* bm, int* bn, int* vec) {
+    Geom g;
+    if (!fill_geom(d, g) || !bm || !bn || !vec) return PM_EINVAL;
+    const bool vec4 = (d->C % 4 == 0) && in_aligned16 && (d->in_gs % 4 == 0);
+    const GemmPlan p = plan_gemm(g, d->groups, vec4);
+    *bm = p.bm; *bn = p.bn; *vec = p.vec;
+    return PM_OK;
+}
+
+extern "C" int pm_query_wgrad_plan(const pm_gather_desc* d, int gathered_aligned16, int dense_aligned16, int* rc,
+                                   int* rn, int* vec, int* dvec, int* workgroups) {
+    Geom g;
+    if (!fill_geom(d, g) || !rc || !rn || !vec || !dvec || !workgroups) return PM_EINVAL;
+    const bool vec4 = (d->C % 4 == 0) && gathered_aligned16 && (d->in_gs % 4 == 0);
+    const bool dvec4 = (d->N % 4 == 0) && dense_aligned16 && (d->out_gs % 4 == 0);
+    const WgradPlan p = plan_wgrad(g, d->groups, vec4, dvec4);
+    *rc = p.rc; *rn = p.rn; *vec = p.vec; *dvec = p.dvec;
+    *workgroups = p.nkb * p.nnb * p.splits * d->groups;
+    return PM_OK;
 }

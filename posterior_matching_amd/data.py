@@ -1,0 +1,61 @@
+"""Synthetic input batches for the hot path: there is no network, so tfds
+(reference utils.py:36-121) is replaced by seeded synthetic data of the same shapes, dtypes and
+value ranges, or by user-supplied .npy arrays."""
+from __future__ import annotations
+
+from typing import Dict, Iterator, List, Mapping, Optional
+
+import numpy as np
+import torch
+
+from .masking import get_mask_generator
+
+
+def data_shape(dataset: str):
+    if "mnist" in dataset:
+        return (28, 28, 1)
+    return {"gas": (8,), "power": (6,), "hepmass": (21,), "miniboone": (43,), "bsds": (63,)}[dataset]
+
+
+class SyntheticDataset:
+    """A fixed pool of pre-generated batches, cycled.  Batches are dicts like the reference's
+    ({"image"|"features": f32[B,...], "mask": f32[B,...]}), already resident on `device`."""
+
+    def __init__(self, config: Mapping, batch_size: int, num_batches: int = 64, seed: int = 0, device="cpu",
+                 training: bool = True, arrays: Optional[np.ndarray] = None):
+        rng = np.random.default_rng(seed)
+        name = config["dataset"]
+        shape = data_shape(name)
+        self.key = "image" if len(shape) == 3 else "features"
+        gen = get_mask_generator(config["mask_generator"], seed=seed + 1, **config.get("mask_generator_kwargs", {}))
+        self.batches: List[Dict[str, torch.Tensor]] = []
+        for i in range(num_batches):
+            if arrays is not None:
+                idx = rng.integers(0, arrays.shape[0], size=batch_size)
+                x = arrays[idx].astype(np.float32)
+            elif self.key == "image":
+                # MNIST-like: ~19 % of the pixels carry ink, values in [0, 1] (utils.py:50-54: x / 255)
+                x = (rng.uniform(size=(batch_size,) + shape) * (rng.uniform(size=(batch_size,) + shape) < 0.19)).astype(np.float32)
+            else:
+                x = rng.normal(size=(batch_size,) + shape).astype(np.float32)
+                if training and "training_noise" in config:          # utils.py:108-116
+                    x = x + rng.normal(scale=config["training_noise"], size=x.shape).astype(np.float32)
+            b = gen((batch_size,) + shape)
+            self.batches.append({self.key: torch.from_numpy(x).to(device), "mask": torch.from_numpy(b).to(device)})
+        self.batch_size, self.shape = batch_size, shape
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        i = 0
+        while True:
+            yield self.batches[i % len(self.batches)]
+            i += 1
+
+
+def load_datasets(config: Mapping, device="cpu", seed: int = 0, num_batches: int = 64):
+    """Counterpart of reference utils.py:36-121 for synthetic / .npy data: (train, val)."""
+    train = SyntheticDataset(config, config["train_batch_size"], num_batches, seed, device, training=True)
+    val = SyntheticDataset(config, config["val_batch_size"], max(1, num_batches // 8), seed + 1000, device, training=False)
+    return train, val

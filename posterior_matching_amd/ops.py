@@ -27,6 +27,51 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+class KernelTimer:
+    """Brackets every C-ABI launch with HIP events on the launching stream (bench.py's live
+    per-kernel timing; never active in a captured graph)."""
+
+    def __init__(self):
+        self.records = []   # (tag, work, start_event, stop_event)
+
+    def summary(self):
+        out = {}
+        for tag, work, e0, e1 in self.records:
+            e1.synchronize()
+            ms = e0.elapsed_ms(e1)
+            r = out.setdefault(tag, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            r["calls"] += 1
+            r["ms"] += ms
+            r["flops"] += work.get("flops", 0.0)
+            r["bytes"] += work.get("bytes", 0.0)
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = t
+
+
+def _call(fname: str, *args, tag: Optional[str] = None, work: Optional[dict] = None) -> None:
+    lib = _lib.load()
+    fn = getattr(lib, fname)
+    if _timer is None:
+        _lib.check(fn(_stream(), *args), fname)
+        return
+    e0, e1 = Event(), Event()
+    e0.record()
+    _lib.check(fn(_stream(), *args), fname)
+    e1.record()
+    _timer.records.append((tag or fname, work or {}, e0, e1))
+
+
+def _nbytes(*ts) -> float:
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
+
+
 def _iptr(t: Optional[torch.Tensor]):
     if t is None:
         return None
@@ -133,16 +178,35 @@ class LayerGeom:
         return d
 
 
+def _algorithmic_flops(d: GatherDesc) -> float:
+    """2 * MACs of the layer as the reference states it: the strided side has min(IH*IW, OH*OW)
+    positions, each touching KH*KW*C*N weights (zero-dilation taps of the stride-2 transposed /
+    data-gradient forms are not algorithmic work)."""
+    pos = min(d.IH * d.IW, d.OH * d.OW) if d.d > 1 or d.a > 1 else d.OH * d.OW
+    return 2.0 * d.B * pos * d.KH * d.KW * d.C * d.N * d.groups
+
+
 def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
-    lib = _lib.load()
-    _lib.check(lib.pm_gather_gemm(_stream(), C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res),
-                                  _ptr(out)), "pm_gather_gemm")
+    tag = work = None
+    if _timer is not None:
+        bm, bn, vec = C.c_int(), C.c_int(), C.c_int()
+        _lib.load().pm_query_gemm_plan(C.byref(desc), int(inp.data_ptr() % 16 == 0), C.byref(bm), C.byref(bn),
+                                       C.byref(vec))
+        tag = f"gather_gemm_kernel<{bm.value},{bn.value},{vec.value}>"
+        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, w, aux, res, out)}
+    _call("pm_gather_gemm", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), tag=tag,
+          work=work)
 
 
 def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
-    lib = _lib.load()
-    _lib.check(lib.pm_gather_wgrad(_stream(), C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db)),
-               "pm_gather_wgrad")
+    tag = work = None
+    if _timer is not None:
+        v = [C.c_int() for _ in range(5)]
+        _lib.load().pm_query_wgrad_plan(C.byref(desc), int(gathered.data_ptr() % 16 == 0),
+                                        int(dense.data_ptr() % 16 == 0), *[C.byref(x) for x in v])
+        tag = f"gather_wgrad_kernel<{v[0].value},{v[1].value},{v[2].value},{v[3].value}>"
+        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw)}
+    _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
 
 def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE, res=None, **group_kw) -> None:
@@ -174,105 +238,90 @@ def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, **group_kw) -> Non
 def mask_concat(x, b, out) -> None:
     C_, Cb = x.shape[-1], b.shape[-1]
     R = x.numel() // C_
-    _lib.check(_lib.load().pm_mask_concat(_stream(), _ptr(x), _ptr(b), _ptr(out), R, C_, Cb), "pm_mask_concat")
+    _call("pm_mask_concat", _ptr(x), _ptr(b), _ptr(out), R, C_, Cb)
 
 
 def tril_sample_kl_fwd(params, eps, z, kl) -> None:
     B, k = eps.shape
-    _lib.check(_lib.load().pm_tril_sample_kl_fwd(_stream(), _ptr(params), _ptr(eps), _ptr(z), _ptr(kl), B, k),
-               "pm_tril_sample_kl_fwd")
+    _call("pm_tril_sample_kl_fwd", _ptr(params), _ptr(eps), _ptr(z), _ptr(kl), B, k)
 
 
 def tril_sample_kl_bwd(params, eps, dz, g_kl, dparams) -> None:
     B, k = eps.shape
-    _lib.check(_lib.load().pm_tril_sample_kl_bwd(_stream(), _ptr(params), _ptr(eps), _ptr(dz), _ptr(g_kl),
-                                                 _ptr(dparams), B, k), "pm_tril_sample_kl_bwd")
+    _call("pm_tril_sample_kl_bwd", _ptr(params), _ptr(eps), _ptr(dz), _ptr(g_kl), _ptr(dparams), B, k)
 
 
 def tril_logprob_fwd(params, z, lp) -> None:
     B, k = z.shape
-    _lib.check(_lib.load().pm_tril_logprob_fwd(_stream(), _ptr(params), _ptr(z), _ptr(lp), B, k), "pm_tril_logprob_fwd")
+    _call("pm_tril_logprob_fwd", _ptr(params), _ptr(z), _ptr(lp), B, k)
 
 
 def tril_logprob_bwd(params, z, g, dparams, dz) -> None:
     B, k = z.shape
-    _lib.check(_lib.load().pm_tril_logprob_bwd(_stream(), _ptr(params), _ptr(z), _ptr(g), _ptr(dparams), _ptr(dz), B, k),
-               "pm_tril_logprob_bwd")
+    _call("pm_tril_logprob_bwd", _ptr(params), _ptr(z), _ptr(g), _ptr(dparams), _ptr(dz), B, k)
 
 
 def bernoulli_ll_fwd(logits, x, ll) -> None:
     B = x.shape[0]
-    _lib.check(_lib.load().pm_bernoulli_ll_fwd(_stream(), _ptr(logits), _ptr(x), _ptr(ll), B, x.numel() // B),
-               "pm_bernoulli_ll_fwd")
+    _call("pm_bernoulli_ll_fwd", _ptr(logits), _ptr(x), _ptr(ll), B, x.numel() // B)
 
 
 def bernoulli_ll_bwd(logits, x, g, dpre, act, slope=LEAKY_SLOPE) -> None:
     B = x.shape[0]
-    _lib.check(_lib.load().pm_bernoulli_ll_bwd(_stream(), _ptr(logits), _ptr(x), _ptr(g), _ptr(dpre), B,
-                                               x.numel() // B, act, slope), "pm_bernoulli_ll_bwd")
+    _call("pm_bernoulli_ll_bwd", _ptr(logits), _ptr(x), _ptr(g), _ptr(dpre), B, x.numel() // B, act, slope)
 
 
 def normal_ll_fwd(loc, x, log_scale, ll) -> None:
     B = x.shape[0]
-    _lib.check(_lib.load().pm_normal_ll_fwd(_stream(), _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(ll), B,
-                                            x.numel() // B), "pm_normal_ll_fwd")
+    _call("pm_normal_ll_fwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(ll), B, x.numel() // B)
 
 
 def normal_ll_bwd(loc, x, log_scale, g, dloc, d_log_scale) -> None:
     B = x.shape[0]
-    _lib.check(_lib.load().pm_normal_ll_bwd(_stream(), _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(g), _ptr(dloc),
-                                            _ptr(d_log_scale), B, x.numel() // B), "pm_normal_ll_bwd")
+    _call("pm_normal_ll_bwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(g), _ptr(dloc), _ptr(d_log_scale), B, x.numel() // B)
 
 
 def argmm_build_input(z, ctx, inp) -> None:
     B, k = z.shape
-    _lib.check(_lib.load().pm_argmm_build_input(_stream(), _ptr(z), _ptr(ctx), _ptr(inp), B, k, ctx.numel() // B),
-               "pm_argmm_build_input")
+    _call("pm_argmm_build_input", _ptr(z), _ptr(ctx), _ptr(inp), B, k, ctx.numel() // B)
 
 
 def argmm_input_bwd(dinp, dz, dctx, B, k, ctx_dim, accumulate_dz, ctx=None, ctx_act=ACT_NONE) -> None:
-    _lib.check(_lib.load().pm_argmm_input_bwd(_stream(), _ptr(dinp), _ptr(dz), _ptr(dctx), B, k, ctx_dim,
-                                              int(accumulate_dz), _ptr(ctx), ctx_act, LEAKY_SLOPE),
-               "pm_argmm_input_bwd")
+    _call("pm_argmm_input_bwd", _ptr(dinp), _ptr(dz), _ptr(dctx), B, k, ctx_dim, int(accumulate_dz), _ptr(ctx), ctx_act, LEAKY_SLOPE)
 
 
 def gmm_logprob_fwd(head, z, mll, nc) -> None:
     B, k = z.shape
-    _lib.check(_lib.load().pm_gmm_logprob_fwd(_stream(), _ptr(head), _ptr(z), _ptr(mll), B, k, nc), "pm_gmm_logprob_fwd")
+    _call("pm_gmm_logprob_fwd", _ptr(head), _ptr(z), _ptr(mll), B, k, nc)
 
 
 def gmm_logprob_bwd(head, z, g, dhead, dz, nc, accumulate_dz) -> None:
     B, k = z.shape
-    _lib.check(_lib.load().pm_gmm_logprob_bwd(_stream(), _ptr(head), _ptr(z), _ptr(g), _ptr(dhead), _ptr(dz), B, k, nc,
-                                              int(accumulate_dz)), "pm_gmm_logprob_bwd")
+    _call("pm_gmm_logprob_bwd", _ptr(head), _ptr(z), _ptr(g), _ptr(dhead), _ptr(dz), B, k, nc, int(accumulate_dz))
 
 
 def pmvae_loss(rec, kl, mll, cfg: _lib.LossCfg, step_dev, out, g_rec, g_kl, g_mll) -> None:
-    _lib.check(_lib.load().pm_pmvae_loss(_stream(), _ptr(rec), _ptr(kl), _ptr(mll), rec.shape[0], C.byref(cfg),
-                                         _iptr(step_dev), _ptr(out), _ptr(g_rec), _ptr(g_kl), _ptr(g_mll)),
-               "pm_pmvae_loss")
+    _call("pm_pmvae_loss", _ptr(rec), _ptr(kl), _ptr(mll), rec.shape[0], C.byref(cfg), _iptr(step_dev), _ptr(out), _ptr(g_rec), _ptr(g_kl), _ptr(g_mll))
 
 
 def adam_step(p, g, m, v, n_decay, count_dev, cfg: _lib.AdamCfg) -> None:
-    _lib.check(_lib.load().pm_adam_step(_stream(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay,
-                                        _iptr(count_dev), C.byref(cfg)), "pm_adam_step")
+    _call("pm_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay, _iptr(count_dev), C.byref(cfg))
 
 
 def counter_increment(count_dev) -> None:
-    _lib.check(_lib.load().pm_counter_increment(_stream(), _iptr(count_dev)), "pm_counter_increment")
+    _call("pm_counter_increment", _iptr(count_dev))
 
 
 def normal_fill(out, seed: int, step_dev, stream_id: int = 0) -> None:
-    _lib.check(_lib.load().pm_normal_fill(_stream(), _ptr(out), out.numel(), seed & (2 ** 64 - 1), _iptr(step_dev),
-                                          stream_id), "pm_normal_fill")
+    _call("pm_normal_fill", _ptr(out), out.numel(), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
 
 
 def fill_zero(t) -> None:
-    _lib.check(_lib.load().pm_fill_zero(_stream(), t.data_ptr(), t.numel() * t.element_size()), "pm_fill_zero")
+    _call("pm_fill_zero", t.data_ptr(), t.numel() * t.element_size())
 
 
 def axpy1(x, y) -> None:
-    _lib.check(_lib.load().pm_axpy1(_stream(), _ptr(x), _ptr(y), x.numel()), "pm_axpy1")
+    _call("pm_axpy1", _ptr(x), _ptr(y), x.numel())
 
 
 class Graph:
