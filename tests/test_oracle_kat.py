@@ -9,7 +9,15 @@ import torch
 from oracle import naive_numpy as nn_
 from oracle import pm_vae_oracle as O
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _float64_default():
+    """the oracle is checked in float64; restore the default so other test modules keep float32"""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 
 def test_fill_triangular_tfp_docstring_example():
