@@ -143,7 +143,12 @@ def main():
                              f"ms/step {v_['ms'] / args.profile_steps:8.4f}  "
                              f"TFLOP/s {(v_['flops'] / (v_['ms'] * 1e-3) / 1e12) if v_['flops'] else 0:7.2f}  "
                              f"GB/s {(v_['bytes'] / (v_['ms'] * 1e-3) / 1e9):8.1f}\n")
-                fp.write(f"sum of kernel time per step: {total_ms / args.profile_steps:.4f} ms\n")
+                fp.write(f"sum of kernel time per step: {total_ms / args.profile_steps:.4f} ms\n\n")
+                calls = timer.per_call()
+                per_step = len(calls) // args.profile_steps
+                fp.write("launch order of the last profiled step:\n")
+                for tag, detail, ms, fl in calls[-per_step:]:
+                    fp.write(f"{tag:42s} {detail:52s} {ms * 1e3:9.1f} us  {fl / (ms * 1e-3) / 1e12 if fl else 0:6.2f} TFLOP/s\n")
 
     if rank == 0:
         value = world * B * args.steps / dt

@@ -83,6 +83,7 @@ SIGNATURES = {
     "pm_normal_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
     "pm_fill_zero": [_P, _P, _LL],
     "pm_axpy1": [_P, _P, _P, _LL],
+    "pm_colsum": [_P, _P, _P, _LL, _I],
     "pm_graph_begin": [_P],
     "pm_graph_end": [_P, C.POINTER(_P)],
     "pm_graph_launch": [_P, _P],

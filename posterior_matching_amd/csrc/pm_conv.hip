@@ -6,10 +6,16 @@
 //     src*d = dst*a + tap*cs + off
 // expresses all four conv flavours (see include/pmhip.h), so one kernel serves every layer.
 //
-// Tiling: a 256-thread workgroup (4 waves) owns a BM x BN output tile and walks K = KH*KW*C in
+// Tiling: a 256-thread workgroup (4 waves) owns a BM x BN output tile and walks K = taps*C in
 // chunks of 32.  The gathered operand is loaded along its contiguous channel axis (16 B per lane
 // when C % 4 == 0), staged in LDS with a 36-float row stride (conflict-free ds_read_b128) and
 // consumed as 32x32x2 MFMA fragments; register prefetch of chunk t+1 overlaps the MFMAs of t.
+//
+// Structural zeros are never multiplied: output rows are enumerated class-major, a class being
+// (p mod PY, q mod PX) with PY = PX = d for the zero-dilated forms (stride-2 transposed conv and
+// stride-2 conv data-gradient) and PY x PX = the whole output grid when the gathered grid is 1x1
+// (7x7 VALID layers).  Every tile then sees one class, and taps that no row of the tile can reach
+// (dilation holes, padding) are dropped from its K loop.
 #include "pm_common.h"
 
 namespace {
@@ -21,6 +27,7 @@ struct Geom {
     int M, K;
     int in_act, out_act, aux_act;
     float slope;
+    int PY, PX, OHc, OWc, Mc;  // class-major row order: Mc rows per class
 };
 
 struct GemmArgs {
@@ -32,6 +39,7 @@ struct GemmArgs {
     const float* res;
     float* out;
     long long in_gs, w_gs, out_gs, bias_gs;
+    int ksplit;
 };
 
 struct WgradArgs {
@@ -46,6 +54,7 @@ struct WgradArgs {
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;  // 144-byte rows: 16-B aligned, ds_read_b128 conflict-free
+constexpr int MAXTAP = 16;      // per-axis kernel extent supported by the tap lists
 
 __device__ __forceinline__ bool src_coord(int base, int kt, int cs, int d, int lim, int& s) {
     int t = base + kt * cs;
@@ -58,6 +67,28 @@ __device__ __forceinline__ bool src_coord(int base, int kt, int cs, int d, int l
     s = t;
     return t < lim;
 }
+
+// row m of the class-major enumeration -> (image b, output position p, q)
+__device__ __forceinline__ void decode_row(const Geom& g, int m, int& b, int& p, int& q) {
+    int cls = m / g.Mc;
+    int r = m - cls * g.Mc;
+    int cyi = cls / g.PX;
+    int cxi = cls - cyi * g.PX;
+    int hw = g.OHc * g.OWc;
+    b = r / hw;
+    int rem = r - b * hw;
+    int p2 = rem / g.OWc;
+    int q2 = rem - p2 * g.OWc;
+    p = p2 * g.PY + cyi;
+    q = q2 * g.PX + cxi;
+}
+
+struct TapList {  // lives in LDS: the taps a tile iterates, as a product of a ky list and a kx list
+    int ky[MAXTAP];
+    int kx[MAXTAP];
+    int nvy, nvx;
+    unsigned masky, maskx;
+};
 
 // ---- gathered-operand tile loaders: tile[row][k], rows = output positions m0.., k = kk0.. ----
 template <int BM, int BKT>
@@ -78,10 +109,9 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
         for (int j = 0; j < NP; ++j) {
             int m = m0 + r0 + j * RPP;
             if (m < g.M) {
-                int q = m % g.OW;
-                int t = m / g.OW;
-                int p = t % g.OH;
-                rb[j] = t / g.OH;
+                int b, p, q;
+                decode_row(g, m, b, p, q);
+                rb[j] = b;
                 rpy[j] = p * g.a + g.off;
                 rqx[j] = q * g.a + g.off;
             } else {
@@ -90,13 +120,28 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
             }
         }
     }
-    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0) {
+    // which ky / kx can reach a valid source pixel from any of this thread's rows
+    __device__ __forceinline__ void tap_masks(const Geom& g, unsigned& my, unsigned& mx) const {
+        my = mx = 0u;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (rb[j] < 0) continue;
+            int s;
+            for (int t = 0; t < g.KH; ++t)
+                if (src_coord(rpy[j], t, g.cs, g.d, g.IH, s)) my |= 1u << t;
+            for (int t = 0; t < g.KW; ++t)
+                if (src_coord(rqx[j], t, g.cs, g.d, g.IW, s)) mx |= 1u << t;
+        }
+    }
+    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0, int keff,
+                                         const TapList* tl) {
         int kk = kk0 + 4 * slot;
-        bool kok = kk < g.K;
-        int tap = kk / g.C;
-        int c = kk - tap * g.C;
-        int ky = tap / g.KW;
-        int kx = tap - ky * g.KW;
+        bool kok = kk < keff;
+        int tj = kk / g.C;
+        int c = kk - tj * g.C;
+        int jy = tj / tl->nvx;
+        int ky = kok ? tl->ky[jy] : 0;
+        int kx = kok ? tl->kx[tj - jy * tl->nvx] : 0;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -121,7 +166,7 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
 };
 
 template <int BM, int BKT>
-struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened over (tap, c)
+struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened over (tap, c); no tap culling
     static_assert(BKT == 32, "scalar loader walks 32 k per chunk");
     static constexpr int RPT = BM / 8;  // consecutive rows per thread
     int kslot, rg;
@@ -133,35 +178,33 @@ struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened ove
         rg = tid >> 5;
     }
     __device__ __forceinline__ void set_rows(const Geom&, int m0) { m_first = m0 + rg * RPT; }
-    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0) {
+    __device__ __forceinline__ void tap_masks(const Geom& g, unsigned& my, unsigned& mx) const {
+        my = (1u << g.KH) - 1u;
+        mx = (1u << g.KW) - 1u;
+    }
+    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0, int keff,
+                                         const TapList* tl) {
         int kk = kk0 + kslot;
-        bool kok = kk < g.K;
-        int tap = kk / g.C;
-        int c = kk - tap * g.C;
-        int ky = tap / g.KW;
-        int kx = tap - ky * g.KW;
-        int m = m_first;
-        int q = m % g.OW;
-        int t = m / g.OW;
-        int p = t % g.OH;
-        int b = t / g.OH;
+        bool kok = kk < keff;
+        int tj = kk / g.C;
+        int c = kk - tj * g.C;
+        int jy = tj / tl->nvx;
+        int ky = kok ? tl->ky[jy] : 0;
+        int kx = kok ? tl->kx[tj - jy * tl->nvx] : 0;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             float v = 0.f;
-            int sy, sx;
-            if (kok && (m + j) < g.M && src_coord(p * g.a + g.off, ky, g.cs, g.d, g.IH, sy) &&
-                src_coord(q * g.a + g.off, kx, g.cs, g.d, g.IW, sx)) {
-                size_t o = (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + c;
-                v = pm_act(in[o], g.in_act, g.slope);
-            }
-            regs[j] = v;
-            if (++q == g.OW) {
-                q = 0;
-                if (++p == g.OH) {
-                    p = 0;
-                    ++b;
+            int m = m_first + j;
+            if (kok && m < g.M) {
+                int b, p, q, sy, sx;
+                decode_row(g, m, b, p, q);
+                if (src_coord(p * g.a + g.off, ky, g.cs, g.d, g.IH, sy) &&
+                    src_coord(q * g.a + g.off, kx, g.cs, g.d, g.IW, sx)) {
+                    size_t o = (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + c;
+                    v = pm_act(in[o], g.in_act, g.slope);
                 }
             }
+            regs[j] = v;
         }
     }
     __device__ __forceinline__ void store(float* tile, int ld) {
@@ -179,6 +222,29 @@ struct LoaderSel<BM, BKT, 1> {
     typedef LoaderV1<BM, BKT> type;
 };
 
+// Builds the tile's tap list from the per-thread reachability masks (all threads must call).
+__device__ __forceinline__ void build_tap_list(const Geom& g, TapList* tl, unsigned my, unsigned mx, int tid) {
+    if (tid == 0) {
+        tl->masky = 0u;
+        tl->maskx = 0u;
+    }
+    __syncthreads();
+    if (my) atomicOr(&tl->masky, my);
+    if (mx) atomicOr(&tl->maskx, mx);
+    __syncthreads();
+    if (tid == 0) {
+        int ny = 0, nx = 0;
+        for (int t = 0; t < g.KH; ++t)
+            if (tl->masky >> t & 1u) tl->ky[ny++] = t;
+        for (int t = 0; t < g.KW; ++t)
+            if (tl->maskx >> t & 1u) tl->kx[nx++] = t;
+        tl->nvy = ny;
+        tl->nvx = nx > 0 ? nx : 1;
+        if (nx == 0) tl->nvy = 0;
+    }
+    __syncthreads();
+}
+
 // -------------------------------- forward / data-gradient ------------------------------------
 template <int BM, int BN, int VEC>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
@@ -187,9 +253,13 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     constexpr int RN = BN / (32 * WN);
     constexpr int NBE = BK * BN / 256;
     static_assert(RN >= 1, "tile too narrow for the wave layout");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    constexpr int TILE_F = (BM + BN) * LDS_LD;
+    constexpr int TL_F = (sizeof(TapList) + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float smem[TILE_F + BM + TL_F];
     float* As = smem;
     float* Bs = smem + BM * LDS_LD;
+    int* rowoff32 = reinterpret_cast<int*>(smem + TILE_F);  // B*OH*OW*N < 2^31 is checked on the host
+    TapList* tl = reinterpret_cast<TapList*>(smem + TILE_F + BM);
 
     const Geom& g = p.g;
     const int tid = threadIdx.x;
@@ -201,21 +271,46 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     const int wn = wave / WM;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int grp = blockIdx.z;
+    const int grp = blockIdx.z / p.ksplit;
+    const int ks = blockIdx.z - grp * p.ksplit;
     const float* in = p.in + (size_t)grp * p.in_gs;
     const float* w = p.w + (size_t)grp * p.w_gs;
 
     typename LoaderSel<BM, BK, VEC>::type la;
     la.init(tid);
     la.set_rows(g, m0);
+    {
+        unsigned my, mx;
+        la.tap_masks(g, my, mx);
+        build_tap_list(g, tl, my, mx, tid);
+    }
+    // output offsets of the tile's rows (class-major row order -> NHWC address), -1 = no such row
+    if (tid < BM) {
+        int m = m0 + tid;
+        int o = -1;
+        if (m < g.M) {
+            int b, pp, q;
+            decode_row(g, m, b, pp, q);
+            o = ((b * g.OH + pp) * g.OW + q) * g.N;
+        }
+        rowoff32[tid] = o;
+    }
+    __syncthreads();
+    const int nvx = tl->nvx;
+    const int keff = tl->nvy * nvx * g.C;
 
-    // weight tile: Bs[n][k] = w[kk0 + k][n0 + n]; lanes run along the contiguous weight axis
+    // weight tile: Bs[n][k] = w[tap(kk0 + k)][c][n0 + n]; lanes run along the contiguous weight axis
     const bool ncontig = (g.wns == 1);
     float breg[NBE];
     auto load_b = [&](int kk0) {
         const bool tap_uniform = (g.C % BK) == 0;
-        const int tap_u = kk0 / g.C;
-        const int c_u = kk0 - tap_u * g.C;
+        int tap_u = 0, c_u = 0;
+        if (tap_uniform && kk0 < keff) {
+            int tj = kk0 / g.C;
+            c_u = kk0 - tj * g.C;
+            int jy = tj / nvx;
+            tap_u = tl->ky[jy] * g.KW + tl->kx[tj - jy * nvx];
+        }
 #pragma unroll
         for (int j = 0; j < NBE; ++j) {
             int kl, nl;
@@ -229,14 +324,16 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
             int kk = kk0 + kl;
             int n = n0 + nl;
             float v = 0.f;
-            if (kk < g.K && n < g.N) {
+            if (kk < keff && n < g.N) {
                 int tap, c;
                 if (tap_uniform) {
                     tap = tap_u;
                     c = c_u + kl;
                 } else {
-                    tap = kk / g.C;
-                    c = kk - tap * g.C;
+                    int tj = kk / g.C;
+                    c = kk - tj * g.C;
+                    int jy = tj / nvx;
+                    tap = tl->ky[jy] * g.KW + tl->kx[tj - jy * nvx];
                 }
                 v = w[(size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns];
             }
@@ -264,15 +361,19 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
-    const int nchunks = (g.K + BK - 1) / BK;
-    la.load(g, in, 0);
-    load_b(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
+    const int nchunks = (keff + BK - 1) / BK;
+    const int cb = (int)(((long long)nchunks * ks) / p.ksplit);
+    const int ce = (int)(((long long)nchunks * (ks + 1)) / p.ksplit);
+    if (cb < ce) {
+        la.load(g, in, cb * BK, keff, tl);
+        load_b(cb * BK);
+    }
+    for (int ch = cb; ch < ce; ++ch) {
         la.store(As, LDS_LD);
         store_b();
         __syncthreads();
-        if (ch + 1 < nchunks) {
-            la.load(g, in, (ch + 1) * BK);
+        if (ch + 1 < ce) {
+            la.load(g, in, (ch + 1) * BK, keff, tl);
             load_b((ch + 1) * BK);
         }
         const float* arow = As + (wm * 32 + i) * LDS_LD + 4 * h;
@@ -303,14 +404,36 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
         float bv = bias ? bias[n] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m >= g.M) continue;
-            size_t o = (size_t)m * g.N + n;
+            int ro = rowoff32[wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+            if (ro < 0) continue;
+            size_t o = (size_t)ro + n;
+            if (p.ksplit > 1) {  // partial sum of a K slice: the epilogue kernel finishes the tile
+                atomicAdd(out + o, acc[r][e]);
+                continue;
+            }
             float v = acc[r][e] + bv;
             if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
             if (res) v += res[o];
             out[o] = pm_act(v, g.out_act, g.slope);
         }
+    }
+}
+
+// epilogue of the split-K form, over the finished sums: out = act((out + bias) * act'(aux) + res)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, long long total_per_group) {
+    const Geom& g = p.g;
+    const int grp = blockIdx.y;
+    const float* bias = p.bias ? p.bias + (size_t)grp * p.bias_gs : nullptr;
+    const float* aux = p.aux ? p.aux + (size_t)grp * p.out_gs : nullptr;
+    const float* res = p.res ? p.res + (size_t)grp * p.out_gs : nullptr;
+    float* out = p.out + (size_t)grp * p.out_gs;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total_per_group; o += stride) {
+        int n = (int)(o % g.N);
+        float v = out[o] + (bias ? bias[n] : 0.f);
+        if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
+        if (res) v += res[o];
+        out[o] = pm_act(v, g.out_act, g.slope);
     }
 }
 
@@ -326,9 +449,20 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
     constexpr int TILE = BMC * (CB + NB);
     constexpr int RED = 4 * CB * NB;
     constexpr int SMEM = TILE > RED ? TILE : RED;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    constexpr int TL_F = (sizeof(TapList) + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM + TL_F];
     float* Gs = smem;
     float* Ds = smem + BMC * CB;
+    TapList* tl = reinterpret_cast<TapList*>(smem + SMEM);  // identity: every tap, natural order
+    if (threadIdx.x < MAXTAP) {
+        tl->ky[threadIdx.x] = threadIdx.x;
+        tl->kx[threadIdx.x] = threadIdx.x;
+    }
+    if (threadIdx.x == 0) {
+        tl->nvy = p.g.KH;
+        tl->nvx = p.g.KW;
+    }
+    __syncthreads();
 
     const Geom& g = p.g;
     const int tid = threadIdx.x;
@@ -398,7 +532,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
 
     if (c_begin < c_end) {
         lg.set_rows(g, c_begin * BMC);
-        lg.load(g, gin, kk0);
+        lg.load(g, gin, kk0, g.K, tl);
         load_d(c_begin * BMC);
     }
     for (int ch = c_begin; ch < c_end; ++ch) {
@@ -407,7 +541,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
         __syncthreads();
         if (ch + 1 < c_end) {
             lg.set_rows(g, (ch + 1) * BMC);
-            lg.load(g, gin, kk0);
+            lg.load(g, gin, kk0, g.K, tl);
             load_d((ch + 1) * BMC);
         }
         const float* grow = Gs + (wave * 32 + h) * CB + i;
@@ -469,24 +603,36 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
     }
 }
 
-bool fill_geom(const pm_gather_desc* d, Geom& g) {
+bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     if (!d || d->B <= 0 || d->C <= 0 || d->N <= 0 || d->KH <= 0 || d->KW <= 0 || d->d <= 0 || d->groups <= 0)
         return false;
     if (d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0) return false;
     if (d->cs != 1 && d->cs != -1) return false;
+    if (d->KH > MAXTAP || d->KW > MAXTAP) return false;
     long long M = (long long)d->B * d->OH * d->OW;
     long long K = (long long)d->KH * d->KW * d->C;
     if (M > 0x7fffffffLL / 4 || K > 0x7fffffffLL / 4) return false;
+    if (M * d->N >= 0x7fffffffLL || (long long)d->B * d->IH * d->IW * d->C >= 0x7fffffffLL) return false;
     g.B = d->B; g.IH = d->IH; g.IW = d->IW; g.C = d->C; g.OH = d->OH; g.OW = d->OW; g.N = d->N;
     g.KH = d->KH; g.KW = d->KW; g.a = d->a; g.cs = d->cs; g.off = d->off; g.d = d->d;
     g.wts = d->wts; g.wcs = d->wcs; g.wns = d->wns; g.M = (int)M; g.K = (int)K;
     g.in_act = d->in_act; g.out_act = d->out_act; g.aux_act = d->aux_act; g.slope = d->slope;
+    g.PY = g.PX = 1;
+    if (class_major) {
+        if (d->d > 1 && d->OH % d->d == 0 && d->OW % d->d == 0) {
+            g.PY = g.PX = d->d;                      // zero-dilated forms: one class per residue
+        } else if (d->IH == 1 && d->IW == 1 && d->OH * d->OW > 1) {
+            g.PY = d->OH; g.PX = d->OW;              // 1x1 gathered grid: one class per output position
+        }
+    }
+    g.OHc = g.OH / g.PY; g.OWc = g.OW / g.PX;
+    g.Mc = g.B * g.OHc * g.OWc;
     return true;
 }
 
 template <int BM, int BN>
 void launch_gemm(hipStream_t s, const GemmArgs& a, int groups, bool vec4) {
-    dim3 grid((a.g.M + BM - 1) / BM, (a.g.N + BN - 1) / BN, groups);
+    dim3 grid((a.g.M + BM - 1) / BM, (a.g.N + BN - 1) / BN, groups * a.ksplit);
     if (vec4)
         hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 4>), grid, dim3(256), 0, s, a);
     else
@@ -512,13 +658,13 @@ void launch_wgrad(hipStream_t s, const WgradArgs& a, dim3 grid, bool vec4, bool 
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
-struct GemmPlan { int bm, bn, vec; };
+struct GemmPlan { int bm, bn, vec, ksplit; };
 struct WgradPlan { int rc, rn, vec, dvec, nkb, nnb, splits, chunks_per_split; };
 
 GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
     const int M = g.M, N = g.N;
     auto nwg = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * groups; };
-    GemmPlan p{128, 32, vec4 ? 4 : 1};
+    GemmPlan p{128, 32, vec4 ? 4 : 1, 1};
     if (N <= 32) {
         p.bm = 128; p.bn = 32;
     } else if (N <= 64) {
@@ -529,6 +675,18 @@ GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
         else if (nwg(64, 128) >= 256) { p.bm = 64; p.bn = 128; }
         else if (nwg(64, 64) >= 2 * nwg(32, 128)) { p.bm = 64; p.bn = 64; }
         else { p.bm = 32; p.bn = 128; }
+    }
+    // split K over workgroups when the tile grid cannot fill the chip and K is long
+    int taps = g.KH * g.KW;
+    if (g.PY > 1 || g.PX > 1)
+        taps = (g.IH == 1 && g.IW == 1) ? 1 : ((g.KH + g.PY - 1) / g.PY) * ((g.KW + g.PX - 1) / g.PX);
+    const int chunks = (taps * g.C + BK - 1) / BK;
+    const long long tiles = nwg(p.bm, p.bn);
+    if (groups == 1 && tiles < 128 && chunks >= 16) {
+        int ks = (int)((256 + tiles - 1) / tiles);
+        if (ks > chunks / 4) ks = chunks / 4;
+        if (ks > 32) ks = 32;
+        if (ks > 1) p.ksplit = ks;
     }
     return p;
 }
@@ -556,26 +714,37 @@ WgradPlan plan_wgrad(const Geom& g, int groups, bool vec4, bool dvec4) {
 extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w,
                               const float* bias, const float* aux, const float* res, float* out) {
     GemmArgs a;
-    if (!fill_geom(d, a.g) || !in || !w || !out) return PM_EINVAL;
+    if (!fill_geom(d, a.g, true) || !in || !w || !out) return PM_EINVAL;
     a.in = in; a.w = w; a.bias = bias; a.aux = aux; a.res = res; a.out = out;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     const bool vec4 = (d->C % 4 == 0) && aligned16(in) && (d->in_gs % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
     const int G = d->groups;
     const GemmPlan p = plan_gemm(a.g, G, vec4);
+    a.ksplit = p.ksplit;
+    if (p.ksplit > 1) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)a.g.M * a.g.N * sizeof(float), s);
+        if (e != hipSuccess) return pm_check_launch("pm_gather_gemm(memset)");
+    }
     if (p.bm == 128 && p.bn == 32) launch_gemm<128, 32>(s, a, G, vec4);
     else if (p.bm == 128 && p.bn == 64) launch_gemm<128, 64>(s, a, G, vec4);
     else if (p.bm == 64 && p.bn == 64) launch_gemm<64, 64>(s, a, G, vec4);
     else if (p.bm == 128 && p.bn == 128) launch_gemm<128, 128>(s, a, G, vec4);
     else if (p.bm == 64 && p.bn == 128) launch_gemm<64, 128>(s, a, G, vec4);
     else launch_gemm<32, 128>(s, a, G, vec4);
+    if (p.ksplit > 1) {
+        long long total = (long long)a.g.M * a.g.N;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks, G), dim3(256), 0, s, a, total);
+    }
     return pm_check_launch("pm_gather_gemm");
 }
 
 extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, const float* gathered,
                                const float* dense, float* dw, float* db) {
     WgradArgs a;
-    if (!fill_geom(d, a.g) || !gathered || !dense || !dw) return PM_EINVAL;
+    if (!fill_geom(d, a.g, false) || !gathered || !dense || !dw) return PM_EINVAL;
     a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     const bool vec4 = (d->C % 4 == 0) && aligned16(gathered) && (d->in_gs % 4 == 0);
@@ -594,7 +763,7 @@ extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, cons
 // Which kernel instantiation a problem dispatches to (bench.py names its roofline row with it).
 extern "C" int pm_query_gemm_plan(const pm_gather_desc* d, int in_aligned16, int* bm, int* bn, int* vec) {
     Geom g;
-    if (!fill_geom(d, g) || !bm || !bn || !vec) return PM_EINVAL;
+    if (!fill_geom(d, g, true) || !bm || !bn || !vec) return PM_EINVAL;
     const bool vec4 = (d->C % 4 == 0) && in_aligned16 && (d->in_gs % 4 == 0);
     const GemmPlan p = plan_gemm(g, d->groups, vec4);
     *bm = p.bm; *bn = p.bn; *vec = p.vec;
@@ -604,7 +773,7 @@ extern "C" int pm_query_gemm_plan(const pm_gather_desc* d, int in_aligned16, int
 extern "C" int pm_query_wgrad_plan(const pm_gather_desc* d, int gathered_aligned16, int dense_aligned16, int* rc,
                                    int* rn, int* vec, int* dvec, int* workgroups) {
     Geom g;
-    if (!fill_geom(d, g) || !rc || !rn || !vec || !dvec || !workgroups) return PM_EINVAL;
+    if (!fill_geom(d, g, false) || !rc || !rn || !vec || !dvec || !workgroups) return PM_EINVAL;
     const bool vec4 = (d->C % 4 == 0) && gathered_aligned16 && (d->in_gs % 4 == 0);
     const bool dvec4 = (d->N % 4 == 0) && dense_aligned16 && (d->out_gs % 4 == 0);
     const WgradPlan p = plan_wgrad(g, d->groups, vec4, dvec4);

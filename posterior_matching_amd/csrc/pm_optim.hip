@@ -94,6 +94,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ void counter_increment_kernel(int* c) { c[0] += 1; }
 
+// out[n] += sum_m x[m][n]: bias gradient of a transposed-conv layer (its weight gradient runs with
+// the roles of x and dy swapped, so the column sums of dy are taken here).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long M,
+                                                       int N, int rows_per_block) {
+    extern __shared__ float sums[];
+    for (int n = threadIdx.x; n < N; n += 256) sums[n] = 0.f;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const long long e0 = r0 * N, e1 = r1 * N;
+    // each thread walks a fixed column set when 256 % N == 0, so it can keep a private sum
+    if (256 % N == 0) {
+        float acc = 0.f;
+        for (long long e = e0 + threadIdx.x; e < e1; e += 256) acc += x[e];
+        atomicAdd(&sums[(int)((e0 + threadIdx.x) % N)], acc);
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += 256) atomicAdd(&sums[(int)(e % N)], x[e]);
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) atomicAdd(out + n, sums[n]);
+}
+
 // Philox4x32-10 counter-based generator + Box-Muller: eps ~ N(0,1) for posterior.sample
 // (vae.py:124).  Bit parity with JAX's threefry streams is not a goal; parity tests
 // pass eps explicitly.  key = (seed, stream_id), counter = (element/4, step).
@@ -190,6 +213,15 @@ extern "C" int pm_fill_zero(pm_stream_t stream, void* ptr, long long nbytes) {
         return PM_ELAUNCH;
     }
     return PM_OK;
+}
+
+extern "C" int pm_colsum(pm_stream_t stream, const float* x, float* out, long long M, int N) {
+    if (!x || !out || M <= 0 || N <= 0 || N > 8192) return PM_EINVAL;
+    int rows = 256;
+    long long blocks = (M + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream,
+                       x, out, M, N, rows);
+    return pm_check_launch("pm_colsum");
 }
 
 extern "C" int pm_axpy1(pm_stream_t stream, const float* x, float* y, long long n) {

@@ -34,6 +34,14 @@ class KernelTimer:
     def __init__(self):
         self.records = []   # (tag, work, start_event, stop_event)
 
+    def per_call(self):
+        """[(tag, detail, ms, flops)] in launch order"""
+        rows = []
+        for tag, work, e0, e1 in self.records:
+            e1.synchronize()
+            rows.append((tag, work.get("detail", ""), e0.elapsed_ms(e1), work.get("flops", 0.0)))
+        return rows
+
     def summary(self):
         out = {}
         for tag, work, e0, e1 in self.records:
@@ -178,12 +186,28 @@ class LayerGeom:
         return d
 
 
+def _valid_pairs(out_n: int, in_n: int, k: int, a: int, cs: int, off: int, d: int) -> int:
+    """number of (output coordinate, tap) pairs whose source coordinate exists"""
+    cnt = 0
+    for p in range(out_n):
+        for t in range(k):
+            v = p * a + t * cs + off
+            if v >= 0 and v % d == 0 and v // d < in_n:
+                cnt += 1
+    return cnt
+
+
 def _algorithmic_flops(d: GatherDesc) -> float:
-    """2 * MACs of the layer as the reference states it: the strided side has min(IH*IW, OH*OW)
-    positions, each touching KH*KW*C*N weights (zero-dilation taps of the stride-2 transposed /
-    data-gradient forms are not algorithmic work)."""
-    pos = min(d.IH * d.IW, d.OH * d.OW) if d.d > 1 or d.a > 1 else d.OH * d.OW
-    return 2.0 * d.B * pos * d.KH * d.KW * d.C * d.N * d.groups
+    """2 * MACs the layer needs: only (position, tap) pairs that touch a real input pixel count,
+    so neither the zero-dilation taps of the stride-2 transposed / data-gradient forms nor the
+    padding taps at the image border are claimed as work."""
+    vy = _valid_pairs(d.OH, d.IH, d.KH, d.a, d.cs, d.off, d.d)
+    vx = _valid_pairs(d.OW, d.IW, d.KW, d.a, d.cs, d.off, d.d)
+    return 2.0 * d.B * vy * vx * d.C * d.N * d.groups
+
+
+def _detail(d: GatherDesc) -> str:
+    return (f"B{d.B} in{d.IH}x{d.IW}x{d.C} out{d.OH}x{d.OW}x{d.N} k{d.KH} a{d.a} d{d.d} g{d.groups}")
 
 
 def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
@@ -193,7 +217,7 @@ def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
         _lib.load().pm_query_gemm_plan(C.byref(desc), int(inp.data_ptr() % 16 == 0), C.byref(bm), C.byref(bn),
                                        C.byref(vec))
         tag = f"gather_gemm_kernel<{bm.value},{bn.value},{vec.value}>"
-        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, w, aux, res, out)}
+        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, w, aux, res, out), "detail": _detail(desc)}
     _call("pm_gather_gemm", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), tag=tag,
           work=work)
 
@@ -205,7 +229,7 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
         _lib.load().pm_query_wgrad_plan(C.byref(desc), int(gathered.data_ptr() % 16 == 0),
                                         int(dense.data_ptr() % 16 == 0), *[C.byref(x) for x in v])
         tag = f"gather_wgrad_kernel<{v[0].value},{v[1].value},{v[2].value},{v[3].value}>"
-        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw)}
+        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
     _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
 
@@ -227,9 +251,21 @@ def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, **group_kw) -> Non
     B = group_kw.pop("B", None) or x.shape[0]
     d = g._desc(B, "wgrad", **group_kw)
     d.in_act = in_act
-    # conv:  dw[ky,kx,ci,co] = sum x[., sy, sx, ci] * dy[., p, q, co]
-    # convT: dw[ky,kx,co,ci] = sum xdil[., p+ky-pa, ., ci] * dy[., p, q, co]: same index rule as the forward
-    gather_wgrad(d, x, dy, dw, db)
+    if g.kind != "convT":
+        # dw[ky,kx,ci,co] = sum_{b,p,q} x[b, p*s+ky-pad, q*s+kx-pad, ci] * dy[b,p,q,co]
+        gather_wgrad(d, x, dy, dw, db)
+        return
+    # Transposed conv: dw[ky,kx,co,ci] = sum_{b,oy,ox} dy[b,oy,ox,co] * xdil[b,oy+ky-pa,ox+kx-pa,ci].
+    # Walking the OUTPUT grid multiplies the zeros of the dilated x (3 of 4 rows at stride 2, 48 of
+    # 49 for the 1x1 -> 7x7 layer).  Walk the INPUT grid instead with the roles swapped:
+    #   dw[ky,kx,co,ci] = sum_{b,iy,ix} dy[b, iy*s+pa-ky, ix*s+pa-kx, co] * x[b,iy,ix,ci]
+    # which is this layer's data-gradient index rule with dy gathered and x dense.
+    if in_act != ACT_NONE:
+        raise NotImplementedError("transposed-conv weight gradient with a pending input activation")
+    d = g._desc(B, "dgrad", **group_kw)
+    gather_wgrad(d, dy, x, dw, None)
+    if db is not None:
+        colsum(dy, db)
 
 
 # ------------------------------------------------------------------------------------------
@@ -318,6 +354,11 @@ def normal_fill(out, seed: int, step_dev, stream_id: int = 0) -> None:
 
 def fill_zero(t) -> None:
     _call("pm_fill_zero", t.data_ptr(), t.numel() * t.element_size())
+
+
+def colsum(x, out) -> None:
+    N = x.shape[-1]
+    _call("pm_colsum", _ptr(x), _ptr(out), x.numel() // N, N)
 
 
 def axpy1(x, y) -> None:
