@@ -87,9 +87,9 @@ class PMVAETrainStep:
         ops.counter_increment(self.step_dev)
 
     def _allreduce(self) -> None:
-        import torch.distributed as dist
+        from .parallel import allreduce_sum_
 
-        dist.all_reduce(self.model.store.flat_g)          # sum over ranks; Adam divides by world_size
+        allreduce_sum_(self.model.store.flat_g)           # sum over ranks; Adam divides by world_size
 
     # -- one optimizer step on whatever is in self.x / self.b (/ self.eps) ---------------------
     def step(self) -> None:

@@ -1,0 +1,136 @@
+"""A trainer with the constructor / fit() surface the reference uses from bax
+(train_pm_vae.py:85-102; bax itself is third-party and not in the reference tree).
+
+loss_fn must be a `PMVAELoss` (train_pm_vae.py builds it): its forward, loss, backward and the
+optimizer run as the fused HIP step of engine.PMVAETrainStep.  One process drives one GPU;
+`num_devices` must equal the torch.distributed world size (launch N processes with
+`python -m torch.distributed.run --nproc-per-node N train_pm_vae.py ...`).
+"""
+from __future__ import annotations
+
+import pickle
+from dataclasses import dataclass, field
+from typing import Any, Dict, Iterable, List, Mapping, Optional
+
+import torch
+
+from . import ops
+from .engine import PMVAETrainStep
+from .models.vae import PosteriorMatchingVAE
+from .optim import Chain
+from .parallel import allreduce_mean_scalars, init_distributed
+from .utils import Callback
+
+
+class PMVAELoss:
+    """loss_fn(step, is_training, batch) of train_pm_vae.py:58-72 as an object, so that the
+    trainer can lower it to the fused step instead of tracing Python."""
+
+    def __init__(self, config: Mapping[str, Any], model: PosteriorMatchingVAE, data_key: str = "image"):
+        self.config, self.model, self.data_key = config, model, data_key
+
+
+@dataclass
+class TrainState:
+    step: int = 0
+    params: Dict[str, torch.Tensor] = field(default_factory=dict)
+    state: Dict[str, Any] = field(default_factory=dict)       # no mutable module state in the PM-VAE
+    opt_state: Dict[str, Any] = field(default_factory=dict)
+    ema_params: Optional[Dict[str, torch.Tensor]] = None
+
+
+class CheckpointCallback(Callback):
+    """bax.callbacks.CheckpointCallback(path): pickles the TrainState at validation time
+    (train_pm_vae.py:91)."""
+
+    def __init__(self, path: str):
+        self._path = path
+
+    def on_validation_end(self, train_state: TrainState, step: int, logs) -> None:
+        with open(self._path, "wb") as fp:
+            pickle.dump(train_state, fp)
+
+
+class LearningRateLoggerCallback(Callback):
+    def __init__(self, schedule):
+        self._schedule = schedule
+
+    def on_validation_end(self, train_state, step, logs) -> None:
+        logs["learning_rate"] = self._schedule(step)
+
+
+class Trainer:
+    def __init__(self, loss_fn: PMVAELoss, optimizer: Chain, num_devices: int = 1, seed: int = 0,
+                 trainable_predicate=None, skip_nonfinite_updates: bool = False, ema_rate: Optional[float] = None,
+                 use_ema_for_eval: bool = False, use_graph: bool = True):
+        if not isinstance(loss_fn, PMVAELoss):
+            raise NotImplementedError("Trainer lowers PMVAELoss (train_pm_vae.py's loss_fn) to the fused HIP step; "
+                                      "arbitrary Python loss functions have no HIP path")
+        if trainable_predicate is not None or skip_nonfinite_updates or ema_rate is not None or use_ema_for_eval:
+            raise NotImplementedError("trainable_predicate / skip_nonfinite_updates / EMA are used by the VQ-VAE and "
+                                      "VDVAE scripts only (SURVEY.md 8a-16,20): not on the PM-VAE path")
+        self.loss_fn, self.optimizer, self.seed, self.use_graph = loss_fn, optimizer, seed, use_graph
+        self.rank, self.local_rank, self.world = init_distributed()
+        if num_devices != self.world:
+            raise ValueError(f"num_devices={num_devices} but {self.world} process(es) are running: this engine is one "
+                             "process per GPU, start it with torch.distributed.run --nproc-per-node num_devices")
+
+    def _state(self, ts: PMVAETrainStep) -> TrainState:
+        store = ts.model.store
+        return TrainState(step=int(ts.step_dev.item()), params={k: v.cpu() for k, v in store.to_dict("p").items()},
+                          opt_state={"mu": store.flat_m.cpu(), "nu": store.flat_v.cpu()})
+
+    def fit(self, train_dataset: Iterable[Dict[str, torch.Tensor]], steps: int, val_dataset=None,
+            validation_freq: Optional[int] = None, callbacks: Optional[List[Callback]] = None,
+            initial_params: Optional[Dict[str, Any]] = None, initial_state=None, log_fn=print) -> TrainState:
+        lf = self.loss_fn
+        model, key = lf.model, lf.data_key
+        it = iter(train_dataset)
+        first = next(it)
+        x0 = first[key]
+        B, x_shape = x0.shape[0], tuple(x0.shape[1:])
+        if model.store is None:
+            model.init(x_shape, device=torch.device("cuda", self.local_rank), seed=self.seed)   # same init on all ranks
+        if initial_params is not None:
+            model.load_params(initial_params)
+        dev = model.store.device
+        ts = PMVAETrainStep(model, lf.config, self.optimizer, B, x_shape, seed=self.seed, world_size=self.world,
+                            rank=self.rank, use_graph=self.use_graph)
+        callbacks = callbacks or []
+        batch = first
+        for step in range(steps):
+            ts.set_batch(batch[key].to(dev, non_blocking=True), batch["mask"].to(dev, non_blocking=True))
+            ts.step()
+            if validation_freq and ((step + 1) % validation_freq == 0 or step + 1 == steps):
+                logs = dict(ts.read_metrics())
+                logs = {f"train_{k}": v for k, v in logs.items()}
+                if val_dataset is not None:
+                    logs.update(self._validate(ts, val_dataset, key, dev))
+                state = self._state(ts)
+                if self.rank == 0:
+                    for cb in callbacks:
+                        cb.on_validation_end(state, step + 1, logs)
+                    if log_fn:
+                        log_fn(f"step {step + 1}: " + ", ".join(f"{k}={v:.5g}" for k, v in logs.items()))
+            batch = next(it)
+        ts.synchronize()
+        return self._state(ts)
+
+    def _validate(self, ts: PMVAETrainStep, val_dataset, key: str, dev) -> Dict[str, float]:
+        """loss_fn with is_training=False averaged over the validation batches (bax semantics)."""
+        sums: Dict[str, float] = {}
+        n = 0
+        batches = getattr(val_dataset, "batches", None) or list(val_dataset)
+        for i, vb in enumerate(batches):
+            x, b = vb[key].to(dev), vb["mask"].to(dev)
+            eps = torch.empty((x.shape[0], ts.model.latent_dim), device=dev)
+            with torch.cuda.stream(ts.stream):
+                ops.normal_fill(eps, self.seed + 7919, ts.step_dev, stream_id=1000 + i)
+            out = ts.evaluate(x, b, eps)
+            for k, v in out.items():
+                sums[k] = sums.get(k, 0.0) + v
+            n += 1
+        vals = torch.tensor([sums[k] / n for k in sorted(sums)], dtype=torch.float64)
+        if self.world > 1:
+            vals = allreduce_mean_scalars(vals.to(dev)).cpu()
+        return {f"val_{k}": float(v) for k, v in zip(sorted(sums), vals)}

@@ -1,0 +1,63 @@
+"""Host-side helpers with the names of the reference's posterior_matching/utils.py."""
+from __future__ import annotations
+
+import json
+import os
+from datetime import datetime
+from typing import Any, Callable, Dict, Optional
+
+from .data import load_datasets  # noqa: F401  (reference utils.py:36-121; synthetic / .npy data here)
+
+
+def configure_environment() -> None:
+    """reference utils.py:21-24 hides GPUs from TF and stops XLA pre-allocation; nothing to do here
+    beyond keeping the dmabuf IPC mode RCCL needs on this pool."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def make_run_dir(path: str = "runs", prefix: Optional[str] = None) -> str:
+    """reference utils.py:27-33: runs/<prefix>-YYYYmmdd-HHMMSS"""
+    run_id = datetime.now().strftime("%Y%m%d-%H%M%S")
+    if prefix is not None:
+        run_id = prefix + "-" + run_id
+    run_dir = os.path.join(path, run_id)
+    os.makedirs(run_dir, exist_ok=True)
+    return run_dir
+
+
+def cyclical_annealing_schedule(low_value: float, high_value: float, period: int, delay: int = 0) -> Callable[[int], float]:
+    """reference utils.py:124-136 (host copy for logging; the training step evaluates the same
+    formula on the device, csrc/pm_optim.hip beta_from_step)."""
+
+    def schedule(count: int) -> float:
+        true_count = count
+        count = min(max((count - delay) % period, 0), period // 2)
+        frac = 1 - count / (period // 2)
+        x = (low_value - high_value) * frac + high_value
+        return x * float(true_count >= delay)
+
+    return schedule
+
+
+class Callback:
+    def on_validation_step(self, train_state, key, batch) -> None:
+        pass
+
+    def on_validation_end(self, train_state, step: int, logs: Dict[str, Any]) -> None:
+        pass
+
+
+class JSONLCallback(Callback):
+    """Scalar logger in place of the reference's TensorBoardCallback (utils.py:139-151;
+    tensorflow is not available): one JSON object per validation into <path>/scalars.jsonl."""
+
+    def __init__(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        self._file = os.path.join(path, "scalars.jsonl")
+
+    def on_validation_end(self, train_state, step: int, logs: Dict[str, Any]) -> None:
+        with open(self._file, "a") as fp:
+            fp.write(json.dumps({"step": step, **{k: float(v) for k, v in logs.items()}}) + "\n")
+
+
+TensorBoardCallback = JSONLCallback

@@ -397,3 +397,53 @@ def test_full_batch_loss_and_properties():
     g1 = m.store.flat_g.clone()
     m.zero_grad(); m.backward(*[2 * t for t in g])
     assert rel_err(m.store.flat_g, 2 * g1) < 1e-5
+
+
+def test_golden_fixture_forward_and_grads():
+    """HIP path vs the committed fixture tests/golden/pm_vae_tiny.npz (self-generated by the oracle)."""
+    import os
+
+    from posterior_matching_amd.models import PosteriorMatchingVAE
+    from tests.golden.make_golden import CFG, XS
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pm_vae_tiny.npz"))
+    m = PosteriorMatchingVAE.from_config(CFG["model"], device="cuda:0")
+    m.init(XS)
+    m.load_params({k[len("param/"):]: z[k] for k in z.files if k.startswith("param/")})
+    d = dev()
+    B = z["x"].shape[0]
+    out = m(torch.tensor(z["x"]).float().to(d), torch.tensor(z["b"]).float().to(d), True,
+            eps=torch.tensor(z["eps"]).float().to(d))
+    for key in ("reconstruction_ll", "kl", "matching_ll"):
+        assert rel_err(out[key], torch.tensor(z[key])) < 1e-5, key
+    g = [torch.full((B,), v, device=d) for v in (-1.0 / B, 1.0 / B, -1.0 / B)]
+    m.zero_grad()
+    m.backward(*g)
+    gd = m.grads_dict()
+    for name, got in gd.items():
+        assert rel_err(got, torch.tensor(z["grad/" + name])) < 1e-4, name
+
+
+def test_train_script_end_to_end(tmp_path):
+    """train_pm_vae.py --config configs/pm_vae_gas.py for a few steps: runs, logs, checkpoints."""
+    import json
+    import os
+    import pickle
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "train_pm_vae.py"), "--config",
+                          os.path.join(root, "configs", "pm_vae_gas.py"), "--config.steps=30",
+                          "--config.validation_freq=15", "--config.seed=3"], cwd=tmp_path, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    run = os.path.join(tmp_path, "runs", os.listdir(os.path.join(tmp_path, "runs"))[0])
+    cfg = json.load(open(os.path.join(run, "model_config.json")))
+    assert cfg["latent_dim"] == 16
+    lines = [json.loads(l) for l in open(os.path.join(run, "tb", "scalars.jsonl"))]
+    assert [l["step"] for l in lines] == [15, 30]
+    assert all(np.isfinite(l["train_loss"]) and np.isfinite(l["val_loss"]) for l in lines)
+    sys.path.insert(0, root)
+    state = pickle.load(open(os.path.join(run, "train_state.pkl"), "rb"))
+    assert state.step == 30 and len(state.params) == 32

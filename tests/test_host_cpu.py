@@ -1,0 +1,171 @@
+"""CPU-side checks: configs, ConfigDict, masks, C-ABI symbol export, golden fixture vs oracle,
+optimizer-chain lowering, and the data-parallel glue under gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_configs_match_reference_values():
+    from posterior_matching_amd.config_dict import load_config_file
+    from tests.ref_configs import pm_vae_gas, pm_vae_mnist
+
+    for name, ref in (("pm_vae_mnist", pm_vae_mnist()), ("pm_vae_gas", pm_vae_gas())):
+        cfg = load_config_file(os.path.join(ROOT, "configs", name + ".py")).to_dict()
+        assert cfg == ref, name
+
+
+def test_config_dict_semantics():
+    from posterior_matching_amd.config_dict import ConfigDict, apply_overrides
+
+    c = ConfigDict()
+    c.a = ConfigDict()
+    c.a.b = 1
+    c.x = {"y": 2}
+    assert c.a.b == 1 and c["x"]["y"] == 2 and "a" in c and c.get("zz", 5) == 5
+    assert dict(**c.a) == {"b": 1}
+    apply_overrides(c, ["a.b=7", "x.y=[1, 2]"])
+    assert c.a.b == 7 and c.x.y == [1, 2]
+    c.lock()
+    c.a.b = 9                                   # existing keys stay writable (ml_collections semantics)
+    with pytest.raises(KeyError):
+        c.new_key = 1
+    with pytest.raises(KeyError):
+        c.a.other = 1
+
+
+def test_mask_generators():
+    from posterior_matching_amd.masking import get_mask_generator
+
+    m = get_mask_generator("MNISTMaskGenerator", seed=0)((400, 28, 28, 1))
+    assert m.shape == (400, 28, 28, 1) and m.dtype == np.float32 and set(np.unique(m)) <= {0.0, 1.0}
+    frac = m.mean(axis=(1, 2, 3))
+    assert (np.isclose(frac, 0.5, atol=1e-6).sum() >= 100)       # the four half-image masks + some others
+    assert frac.min() >= 0.0 and frac.max() <= 1.0
+    g = get_mask_generator("BernoulliMaskGenerator", seed=1)((1000, 8))
+    assert g.shape == (1000, 8) and abs(g.mean() - 0.5) < 0.03
+    with pytest.raises(KeyError):
+        get_mask_generator("CelebAMaskGenerator")
+    with pytest.raises(AssertionError):
+        get_mask_generator("MNISTMaskGenerator")((3, 784))
+
+
+def test_library_exports_every_declared_symbol():
+    """the C-ABI library loads (no GPU needed) and exports every function include/pmhip.h declares"""
+    from posterior_matching_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "pmhip.h")).read()
+    declared = set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pm_stream_t"}
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    bound = set(_lib.SIGNATURES) | set(_lib._OTHER_RESTYPE)
+    assert declared <= bound, sorted(declared - bound)
+    assert _lib.load().pm_version() >= 1
+    assert _lib.load().pm_strerror(-1).decode().startswith("invalid")
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from posterior_matching_amd.models import PosteriorMatchingVAE
+    from tests.ref_configs import pm_vae_mnist
+
+    m = PosteriorMatchingVAE.from_config(pm_vae_mnist()["model"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.init((28, 28, 1))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "posterior_matching_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# ", ""), (dirpath, f)
+
+
+def test_golden_fixture_matches_oracle():
+    from oracle import pm_vae_oracle as O
+    from tests.golden.make_golden import CFG
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "pm_vae_tiny.npz"))
+    p = {k[len("param/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, _, out = O.pm_vae_loss(leaves, CFG, torch.tensor(z["x"]), torch.tensor(z["b"]), torch.tensor(z["eps"]), 0)
+    assert loss.item() == pytest.approx(float(z["loss"]), rel=1e-12)
+    for key in ("reconstruction_ll", "kl", "matching_ll"):
+        np.testing.assert_allclose(out[key].detach().numpy(), z[key], rtol=1e-11)
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    for k, g in zip(leaves, grads):
+        np.testing.assert_allclose(g.numpy(), z["grad/" + k], rtol=1e-9, atol=1e-13)
+
+
+def test_optimizer_chain_lowering():
+    from posterior_matching_amd import optim
+
+    sch = optim.exponential_decay(init_value=1e-3, transition_steps=5000, decay_rate=0.9)
+    assert sch(5000) == pytest.approx(9e-4)
+    ch = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(1e-5), optim.scale_by_schedule(sch),
+                     optim.scale(-1.0))
+    cfg = ch.adam_cfg(grad_scale=0.5)
+    assert (cfg.b1, cfg.lr_init, cfg.grad_scale) == (pytest.approx(0.9), pytest.approx(1e-3), 0.5)
+    assert cfg.weight_decay == pytest.approx(1e-5)
+    with pytest.raises(NotImplementedError):
+        optim.chain(optim.scale_by_adam(), optim.scale(-1.0))
+
+
+_DP_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from posterior_matching_amd.parallel import init_distributed, shard_rows, allreduce_sum_, allreduce_mean_scalars
+from oracle import pm_vae_oracle as O
+from tests.golden.make_golden import CFG, XS
+import numpy as np
+
+rank, local_rank, world = init_distributed("gloo")
+assert world == 2 and dist.get_backend() == "gloo"
+rng = np.random.default_rng(7)                         # identical global batch on every rank
+G = 8
+x = torch.tensor(rng.uniform(size=(G,) + XS)); b = torch.tensor((rng.uniform(size=(G,) + XS) < 0.5) * 1.0)
+eps = torch.tensor(rng.normal(size=(G, CFG["model"]["latent_dim"])))
+p = O.init_params(CFG["model"], XS, seed=3)
+def grads(rows):
+    leaves = {{k: v.clone().requires_grad_(True) for k, v in p.items()}}
+    loss, aux, _ = O.pm_vae_loss(leaves, CFG, x[rows], b[rows], eps[rows], 0)
+    g = torch.autograd.grad(loss, list(leaves.values()))
+    return loss.detach(), torch.cat([t.reshape(-1) for t in g])
+rows = shard_rows(G, rank, world)
+assert (rows.start, rows.stop) == (rank * 4, rank * 4 + 4)
+loss_r, flat = grads(rows)
+allreduce_sum_(flat)                                    # what PMVAETrainStep._allreduce does
+flat /= world                                           # pm_adam_step's grad_scale = 1 / world
+loss_full, flat_full = grads(slice(0, G))
+assert torch.allclose(flat, flat_full, rtol=1e-10, atol=1e-14), (flat - flat_full).abs().max()
+m = allreduce_mean_scalars(torch.stack([loss_r]))
+assert torch.allclose(m[0], loss_full, rtol=1e-12)
+dist.barrier()
+if rank == 0:
+    print("DP-OK")
+dist.destroy_process_group()
+"""
+
+
+def test_data_parallel_glue_gloo_world2(tmp_path):
+    """2 ranks, gloo: shard rows -> per-rank grads -> all-reduce sum / N == full-batch gradient."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DP-OK" in out.stdout
