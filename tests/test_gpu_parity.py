@@ -446,4 +446,4 @@ def test_train_script_end_to_end(tmp_path):
     assert all(np.isfinite(l["train_loss"]) and np.isfinite(l["val_loss"]) for l in lines)
     sys.path.insert(0, root)
     state = pickle.load(open(os.path.join(run, "train_state.pkl"), "rb"))
-    assert state.step == 30 and len(state.params) == 32
+    assert state.step == 30 and len(state.params) == 37
