@@ -16,6 +16,11 @@
 // stride-2 conv data-gradient) and PY x PX = the whole output grid when the gathered grid is 1x1
 // (7x7 VALID layers).  Every tile then sees one class, and taps that no row of the tile can reach
 // (dilation holes, padding) are dropped from its K loop.
+//
+// The f32 MFMA retires 32x32x2 in 64 cycles, so a 32-deep chunk is only 16 MFMAs per wave: the
+// loaders are written to cost a few VALU instructions per row (tap decode and weight base are
+// wave-uniform scalars, per-row state is precomputed), otherwise address arithmetic - not the
+// matrix pipe - bounds the kernel.
 #include "pm_common.h"
 
 namespace {
@@ -50,22 +55,34 @@ struct WgradArgs {
     float* db;
     long long in_gs, w_gs, out_gs, bias_gs;
     int chunks_per_split;
+    int step_b, step_p, step_q;  // 128 rows = step_b images + step_p rows + step_q pixels
 };
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;  // 144-byte rows: 16-B aligned, ds_read_b128 conflict-free
 constexpr int MAXTAP = 16;      // per-axis kernel extent supported by the tap lists
+constexpr int ROW_INVALID = -(1 << 28);
 
-__device__ __forceinline__ bool src_coord(int base, int kt, int cs, int d, int lim, int& s) {
-    int t = base + kt * cs;
-    if (t < 0) return false;
-    if (d > 1) {
+// loader modes
+constexpr int MODE_TU1 = 0;  // C % 32 == 0 (every chunk inside one tap), d == 1
+constexpr int MODE_TU2 = 1;  // C % 32 == 0, d == 2
+constexpr int MODE_V4 = 2;   // C % 4 == 0, anything else
+constexpr int MODE_V1 = 3;   // scalar gathers (C = 1, 2, ...)
+
+template <int DD>
+__device__ __forceinline__ bool coord_ok(int t, int d, int lim, int& s) {
+    if (DD == 1) {
+        s = t;
+        return (unsigned)t < (unsigned)lim;
+    } else if (DD == 2) {
+        s = t >> 1;
+        return t >= 0 && !(t & 1) && s < lim;
+    } else {
+        if (t < 0) return false;
         int q = t / d;
-        if (q * d != t) return false;
-        t = q;
+        s = q;
+        return q * d == t && q < lim;
     }
-    s = t;
-    return t < lim;
 }
 
 // row m of the class-major enumeration -> (image b, output position p, q)
@@ -90,34 +107,62 @@ struct TapList {  // lives in LDS: the taps a tile iterates, as a product of a k
     unsigned masky, maskx;
 };
 
-// ---- gathered-operand tile loaders: tile[row][k], rows = output positions m0.., k = kk0.. ----
-template <int BM, int BKT>
+// ---- gathered-operand tile loaders: tile[row][k], rows = output positions, k = (tap, channel) ----
+template <int BM, int BKT, int DD>
 struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
     static constexpr int SLOTS = BKT / 4;
     static constexpr int RPP = 256 / SLOTS;
     static constexpr int NP = BM / RPP;
-    int slot, r0;
-    int rb[NP], rpy[NP], rqx[NP];
+    int slot4, r0;
+    int rbase[NP], rpy[NP], rqx[NP];
     f32x4 regs[NP];
 
     __device__ __forceinline__ void init(int tid) {
-        slot = tid % SLOTS;
+        slot4 = 4 * (tid % SLOTS);
         r0 = tid / SLOTS;
+    }
+    __device__ __forceinline__ void set_row(const Geom& g, int j, int m) {
+        if (m < g.M) {
+            int b, p, q;
+            decode_row(g, m, b, p, q);
+            rbase[j] = b * g.IH * g.IW * g.C;
+            rpy[j] = p * g.a + g.off;
+            rqx[j] = q * g.a + g.off;
+        } else {
+            rbase[j] = 0;
+            rpy[j] = ROW_INVALID;
+            rqx[j] = ROW_INVALID;
+        }
     }
     __device__ __forceinline__ void set_rows(const Geom& g, int m0) {
 #pragma unroll
+        for (int j = 0; j < NP; ++j) set_row(g, j, m0 + r0 + j * RPP);
+    }
+    // natural row order only (weight gradient): advance every row by 128 = sb images + sp rows + sq pixels
+    __device__ __forceinline__ void advance_rows(const Geom& g, int m_next0, int sb, int sp, int sq) {
+        const int img = g.IH * g.IW * g.C;
+        const int wlim = g.OW * g.a + g.off, hlim = g.OH * g.a + g.off;
+#pragma unroll
         for (int j = 0; j < NP; ++j) {
-            int m = m0 + r0 + j * RPP;
-            if (m < g.M) {
-                int b, p, q;
-                decode_row(g, m, b, p, q);
-                rb[j] = b;
-                rpy[j] = p * g.a + g.off;
-                rqx[j] = q * g.a + g.off;
-            } else {
-                rb[j] = -1;
-                rpy[j] = rqx[j] = 0;
+            if (m_next0 + r0 + j * RPP >= g.M) {
+                rpy[j] = ROW_INVALID;
+                rqx[j] = ROW_INVALID;
+                continue;
             }
+            int x = rqx[j] + sq * g.a;
+            int y = rpy[j] + sp * g.a;
+            int bb = rbase[j] + sb * img;
+            if (x >= wlim) {
+                x -= g.OW * g.a;
+                y += g.a;
+            }
+            if (y >= hlim) {
+                y -= g.OH * g.a;
+                bb += img;
+            }
+            rqx[j] = x;
+            rpy[j] = y;
+            rbase[j] = bb;
         }
     }
     // which ky / kx can reach a valid source pixel from any of this thread's rows
@@ -125,43 +170,50 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
         my = mx = 0u;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            if (rb[j] < 0) continue;
             int s;
             for (int t = 0; t < g.KH; ++t)
-                if (src_coord(rpy[j], t, g.cs, g.d, g.IH, s)) my |= 1u << t;
+                if (coord_ok<DD>(rpy[j] + t * g.cs, g.d, g.IH, s)) my |= 1u << t;
             for (int t = 0; t < g.KW; ++t)
-                if (src_coord(rqx[j], t, g.cs, g.d, g.IW, s)) mx |= 1u << t;
+                if (coord_ok<DD>(rqx[j] + t * g.cs, g.d, g.IW, s)) mx |= 1u << t;
         }
     }
-    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0, int keff,
-                                         const TapList* tl) {
-        int kk = kk0 + 4 * slot;
+    // one chunk: tap (ky, kx) and first channel cbeg are what THIS thread loads (uniform in TU modes)
+    __device__ __forceinline__ void load_tap(const Geom& g, const float* __restrict__ in, int ky, int kx, int cbeg,
+                                             bool kok) {
+        const int dyv = ky * g.cs, dxv = kx * g.cs;
+        const int c = cbeg + slot4;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            int sy, sx;
+            const bool oky = coord_ok<DD>(rpy[j] + dyv, g.d, g.IH, sy);
+            const bool okx = coord_ok<DD>(rqx[j] + dxv, g.d, g.IW, sx);
+            const bool ok = (int(oky) & int(okx) & int(kok)) != 0;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(in + (rbase[j] + (sy * g.IW + sx) * g.C + c));
+            regs[j] = v;
+        }
+        if (g.in_act != PM_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) regs[j][e] = pm_act(regs[j][e], g.in_act, g.slope);
+        }
+    }
+    // generic chunk: per-thread tap decode from the flattened k index
+    __device__ __forceinline__ void load_flat(const Geom& g, const float* __restrict__ in, int kk0, int keff,
+                                              const TapList* tl) {
+        int kk = kk0 + slot4;
         bool kok = kk < keff;
         int tj = kk / g.C;
         int c = kk - tj * g.C;
         int jy = tj / tl->nvx;
         int ky = kok ? tl->ky[jy] : 0;
         int kx = kok ? tl->kx[tj - jy * tl->nvx] : 0;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            int sy, sx;
-            if (kok && rb[j] >= 0 && src_coord(rpy[j], ky, g.cs, g.d, g.IH, sy) &&
-                src_coord(rqx[j], kx, g.cs, g.d, g.IW, sx)) {
-                size_t o = (((size_t)rb[j] * g.IH + sy) * g.IW + sx) * g.C + c;
-                v = *reinterpret_cast<const f32x4*>(in + o);
-                if (g.in_act != PM_ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = pm_act(v[e], g.in_act, g.slope);
-                }
-            }
-            regs[j] = v;
-        }
+        load_tap(g, in, ky, kx, c - slot4, kok);
     }
     __device__ __forceinline__ void store(float* tile, int ld) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j)
-            *reinterpret_cast<f32x4*>(tile + (r0 + j * RPP) * ld + 4 * slot) = regs[j];
+        for (int j = 0; j < NP; ++j) *reinterpret_cast<f32x4*>(tile + (r0 + j * RPP) * ld + slot4) = regs[j];
     }
 };
 
@@ -178,12 +230,14 @@ struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened ove
         rg = tid >> 5;
     }
     __device__ __forceinline__ void set_rows(const Geom&, int m0) { m_first = m0 + rg * RPT; }
+    __device__ __forceinline__ void advance_rows(const Geom&, int m_next0, int, int, int) { m_first = m_next0 + rg * RPT; }
     __device__ __forceinline__ void tap_masks(const Geom& g, unsigned& my, unsigned& mx) const {
         my = (1u << g.KH) - 1u;
         mx = (1u << g.KW) - 1u;
     }
-    __device__ __forceinline__ void load(const Geom& g, const float* __restrict__ in, int kk0, int keff,
-                                         const TapList* tl) {
+    __device__ __forceinline__ void load_tap(const Geom&, const float*, int, int, int, bool) {}
+    __device__ __forceinline__ void load_flat(const Geom& g, const float* __restrict__ in, int kk0, int keff,
+                                              const TapList* tl) {
         int kk = kk0 + kslot;
         bool kok = kk < keff;
         int tj = kk / g.C;
@@ -191,20 +245,31 @@ struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened ove
         int jy = tj / tl->nvx;
         int ky = kok ? tl->ky[jy] : 0;
         int kx = kok ? tl->kx[tj - jy * tl->nvx] : 0;
+        int b, p, q;
+        decode_row(g, m_first < g.M ? m_first : 0, b, p, q);
+        const bool natural = (g.PY == 1 && g.PX == 1);
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             float v = 0.f;
             int m = m_first + j;
             if (kok && m < g.M) {
-                int b, p, q, sy, sx;
-                decode_row(g, m, b, p, q);
-                if (src_coord(p * g.a + g.off, ky, g.cs, g.d, g.IH, sy) &&
-                    src_coord(q * g.a + g.off, kx, g.cs, g.d, g.IW, sx)) {
-                    size_t o = (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + c;
-                    v = pm_act(in[o], g.in_act, g.slope);
+                if (!natural) decode_row(g, m, b, p, q);
+                int sy, sx;
+                if (coord_ok<0>(p * g.a + g.off + ky * g.cs, g.d, g.IH, sy) &&
+                    coord_ok<0>(q * g.a + g.off + kx * g.cs, g.d, g.IW, sx)) {
+                    v = pm_act(in[((b * g.IH + sy) * g.IW + sx) * g.C + c], g.in_act, g.slope);
                 }
             }
             regs[j] = v;
+            if (natural) {  // next row in (b, p, q) order
+                if (++q == g.OW) {
+                    q = 0;
+                    if (++p == g.OH) {
+                        p = 0;
+                        ++b;
+                    }
+                }
+            }
         }
     }
     __device__ __forceinline__ void store(float* tile, int ld) {
@@ -213,12 +278,12 @@ struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened ove
     }
 };
 
-template <int BM, int BKT, int VEC>
+template <int BM, int BKT, int MODE>
 struct LoaderSel {
-    typedef LoaderV4<BM, BKT> type;
+    typedef LoaderV4<BM, BKT, (MODE == MODE_TU1 ? 1 : (MODE == MODE_TU2 ? 2 : 0))> type;
 };
 template <int BM, int BKT>
-struct LoaderSel<BM, BKT, 1> {
+struct LoaderSel<BM, BKT, MODE_V1> {
     typedef LoaderV1<BM, BKT> type;
 };
 
@@ -246,8 +311,9 @@ __device__ __forceinline__ void build_tap_list(const Geom& g, TapList* tl, unsig
 }
 
 // -------------------------------- forward / data-gradient ------------------------------------
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
+    constexpr bool TU = (MODE == MODE_TU1 || MODE == MODE_TU2);
     constexpr int WM = BM / 32;
     constexpr int WN = 4 / WM;
     constexpr int RN = BN / (32 * WN);
@@ -276,7 +342,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     const float* in = p.in + (size_t)grp * p.in_gs;
     const float* w = p.w + (size_t)grp * p.w_gs;
 
-    typename LoaderSel<BM, BK, VEC>::type la;
+    typename LoaderSel<BM, BK, MODE>::type la;
     la.init(tid);
     la.set_rows(g, m0);
     {
@@ -299,60 +365,48 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     const int nvx = tl->nvx;
     const int keff = tl->nvy * nvx * g.C;
 
-    // weight tile: Bs[n][k] = w[tap(kk0 + k)][c][n0 + n]; lanes run along the contiguous weight axis
+    // weight tile: Bs[n][k] = w[tap][c0 + k][n0 + n]; lanes run along the contiguous weight axis
     const bool ncontig = (g.wns == 1);
+    int boff[NBE];
+    int bkl[NBE];
     float breg[NBE];
-    auto load_b = [&](int kk0) {
-        const bool tap_uniform = (g.C % BK) == 0;
-        int tap_u = 0, c_u = 0;
-        if (tap_uniform && kk0 < keff) {
-            int tj = kk0 / g.C;
-            c_u = kk0 - tj * g.C;
-            int jy = tj / nvx;
-            tap_u = tl->ky[jy] * g.KW + tl->kx[tj - jy * nvx];
+#pragma unroll
+    for (int j = 0; j < NBE; ++j) {
+        int kl, nl;
+        if (ncontig) {
+            nl = tid % BN;
+            kl = tid / BN + (256 / BN) * j;
+        } else {
+            kl = tid & 31;
+            nl = (tid >> 5) + 8 * j;
         }
+        bkl[j] = kl | (nl << 8);
+        boff[j] = (n0 + nl < g.N) ? kl * g.wcs + (n0 + nl) * g.wns : -1;
+    }
+    auto load_b_tap = [&](int tap, int cbeg) {  // uniform tap: one scalar base per chunk
+        const float* wb = w + ((size_t)tap * g.wts + (size_t)cbeg * g.wcs);
+#pragma unroll
+        for (int j = 0; j < NBE; ++j) breg[j] = boff[j] >= 0 ? wb[boff[j]] : 0.f;
+    };
+    auto load_b_flat = [&](int kk0) {
 #pragma unroll
         for (int j = 0; j < NBE; ++j) {
-            int kl, nl;
-            if (ncontig) {
-                nl = tid % BN;
-                kl = tid / BN + (256 / BN) * j;
-            } else {
-                kl = tid & 31;
-                nl = (tid >> 5) + 8 * j;
-            }
+            int kl = bkl[j] & 255;
             int kk = kk0 + kl;
-            int n = n0 + nl;
             float v = 0.f;
-            if (kk < keff && n < g.N) {
-                int tap, c;
-                if (tap_uniform) {
-                    tap = tap_u;
-                    c = c_u + kl;
-                } else {
-                    int tj = kk / g.C;
-                    c = kk - tj * g.C;
-                    int jy = tj / nvx;
-                    tap = tl->ky[jy] * g.KW + tl->kx[tj - jy * nvx];
-                }
-                v = w[(size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns];
+            if (kk < keff && boff[j] >= 0) {
+                int tj = kk / g.C;
+                int c = kk - tj * g.C;
+                int jy = tj / nvx;
+                int tap = tl->ky[jy] * g.KW + tl->kx[tj - jy * nvx];
+                v = w[(size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)(boff[j] - kl * g.wcs)];
             }
             breg[j] = v;
         }
     };
     auto store_b = [&]() {
 #pragma unroll
-        for (int j = 0; j < NBE; ++j) {
-            int kl, nl;
-            if (ncontig) {
-                nl = tid % BN;
-                kl = tid / BN + (256 / BN) * j;
-            } else {
-                kl = tid & 31;
-                nl = (tid >> 5) + 8 * j;
-            }
-            Bs[nl * LDS_LD + kl] = breg[j];
-        }
+        for (int j = 0; j < NBE; ++j) Bs[(bkl[j] >> 8) * LDS_LD + (bkl[j] & 255)] = breg[j];
     };
 
     f32x16 acc[RN];
@@ -364,18 +418,38 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     const int nchunks = (keff + BK - 1) / BK;
     const int cb = (int)(((long long)nchunks * ks) / p.ksplit);
     const int ce = (int)(((long long)nchunks * (ks + 1)) / p.ksplit);
-    if (cb < ce) {
-        la.load(g, in, cb * BK, keff, tl);
-        load_b(cb * BK);
+    // chunk cursor of the tap-uniform modes: (jy, jx) index the tap lists, c0 is the channel offset
+    int jy = 0, jx = 0, c0 = 0;
+    if (TU) {
+        int tj = (cb * BK) / g.C;
+        c0 = cb * BK - tj * g.C;
+        jy = tj / nvx;
+        jx = tj - jy * nvx;
     }
+    auto load_chunk = [&](int ch) {
+        if constexpr (TU) {
+            const int ky = tl->ky[jy], kx = tl->kx[jx];
+            la.load_tap(g, in, ky, kx, c0, true);
+            load_b_tap(ky * g.KW + kx, c0);
+            c0 += BK;
+            if (c0 >= g.C) {
+                c0 = 0;
+                if (++jx == nvx) {
+                    jx = 0;
+                    ++jy;
+                }
+            }
+        } else {
+            la.load_flat(g, in, ch * BK, keff, tl);
+            load_b_flat(ch * BK);
+        }
+    };
+    if (cb < ce) load_chunk(cb);
     for (int ch = cb; ch < ce; ++ch) {
         la.store(As, LDS_LD);
         store_b();
         __syncthreads();
-        if (ch + 1 < ce) {
-            la.load(g, in, (ch + 1) * BK, keff, tl);
-            load_b((ch + 1) * BK);
-        }
+        if (ch + 1 < ce) load_chunk(ch + 1);
         const float* arow = As + (wm * 32 + i) * LDS_LD + 4 * h;
         const float* brow = Bs + (wn * RN * 32 + i) * LDS_LD + 4 * h;
 #pragma unroll
@@ -441,8 +515,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, long l
 // dw[kk][n] += sum_m G[m][kk] * D[m][n].  A workgroup owns a (32*RC) x (32*RN) block of dw and a
 // range of 128-row chunks of m; its 4 waves each take 32 rows of a chunk (MFMA k = 2 rows per
 // instruction), are summed through LDS at the end and added to global memory with f32 atomics.
-template <int RC, int RN, int VEC, int DVEC>
+// In the tap-uniform modes the block's tap and channel range are fixed for the whole kernel and
+// the per-row state advances incrementally from chunk to chunk.
+template <int RC, int RN, int MODE, int DVEC>
 __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
+    constexpr bool TU = (MODE == MODE_TU1 || MODE == MODE_TU2);
     constexpr int CB = 32 * RC;
     constexpr int NB = 32 * RN;
     constexpr int BMC = 128;
@@ -479,13 +556,18 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
     const float* gin = p.gathered + (size_t)grp * p.in_gs;
     const float* din = p.dense + (size_t)grp * p.out_gs;
     const bool do_bias = (p.db != nullptr) && (kkb == 0);
+    // tap-uniform modes: this block's tap and first channel
+    const int tap_u = kk0 / g.C;
+    const int c_u = kk0 - tap_u * g.C;
+    const int ky_u = tap_u / g.KW;
+    const int kx_u = tap_u - ky_u * g.KW;
 
     const int total_chunks = (g.M + BMC - 1) / BMC;
     const int c_begin = blockIdx.y * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > total_chunks) c_end = total_chunks;
 
-    typename LoaderSel<BMC, CB, VEC>::type lg;
+    typename LoaderSel<BMC, CB, MODE>::type lg;
     lg.init(tid);
 
     // dense tile loader: Ds[row][n]
@@ -494,27 +576,39 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
     constexpr int DNP = BMC / DRPP;
     const int dslot = tid % DSLOTS;
     const int dr0 = tid / DSLOTS;
+    const int dn = n0 + dslot * DVEC;
+    const bool dn_ok = dn < g.N;
     float dreg[DNP][DVEC];
     auto load_d = [&](int m0) {
 #pragma unroll
         for (int j = 0; j < DNP; ++j) {
             int m = m0 + dr0 + j * DRPP;
-            int n = n0 + dslot * DVEC;
             if (DVEC == 4) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < g.M && n < g.N) v = *reinterpret_cast<const f32x4*>(din + (size_t)m * g.N + n);
+                if (m < g.M && dn_ok) v = *reinterpret_cast<const f32x4*>(din + (size_t)m * g.N + dn);
 #pragma unroll
                 for (int e = 0; e < DVEC; ++e) dreg[j][e] = v[e];
             } else {
-                dreg[j][0] = (m < g.M && n < g.N) ? din[(size_t)m * g.N + n] : 0.f;
+                dreg[j][0] = (m < g.M && dn_ok) ? din[(size_t)m * g.N + dn] : 0.f;
             }
         }
     };
     auto store_d = [&]() {
 #pragma unroll
-        for (int j = 0; j < DNP; ++j)
-#pragma unroll
-            for (int e = 0; e < DVEC; ++e) Ds[(dr0 + j * DRPP) * NB + dslot * DVEC + e] = dreg[j][e];
+        for (int j = 0; j < DNP; ++j) {
+            if (DVEC == 4) {
+                f32x4 v = {dreg[j][0], dreg[j][1 % DVEC], dreg[j][2 % DVEC], dreg[j][3 % DVEC]};
+                *reinterpret_cast<f32x4*>(Ds + (dr0 + j * DRPP) * NB + dslot * DVEC) = v;
+            } else {
+                Ds[(dr0 + j * DRPP) * NB + dslot] = dreg[j][0];
+            }
+        }
+    };
+    auto load_g = [&]() {
+        if constexpr (TU)
+            lg.load_tap(g, gin, ky_u, kx_u, c_u, true);
+        else
+            lg.load_flat(g, gin, kk0, g.K, tl);
     };
 
     f32x16 acc[RC][RN];
@@ -532,7 +626,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
 
     if (c_begin < c_end) {
         lg.set_rows(g, c_begin * BMC);
-        lg.load(g, gin, kk0, g.K, tl);
+        load_g();
         load_d(c_begin * BMC);
     }
     for (int ch = c_begin; ch < c_end; ++ch) {
@@ -540,8 +634,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
         store_d();
         __syncthreads();
         if (ch + 1 < c_end) {
-            lg.set_rows(g, (ch + 1) * BMC);
-            lg.load(g, gin, kk0, g.K, tl);
+            lg.advance_rows(g, (ch + 1) * BMC, p.step_b, p.step_p, p.step_q);
+            load_g();
             load_d((ch + 1) * BMC);
         }
         const float* grow = Gs + (wave * 32 + h) * CB + i;
@@ -606,13 +700,19 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
 bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     if (!d || d->B <= 0 || d->C <= 0 || d->N <= 0 || d->KH <= 0 || d->KW <= 0 || d->d <= 0 || d->groups <= 0)
         return false;
-    if (d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0) return false;
+    if (d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->a <= 0) return false;
     if (d->cs != 1 && d->cs != -1) return false;
     if (d->KH > MAXTAP || d->KW > MAXTAP) return false;
     long long M = (long long)d->B * d->OH * d->OW;
     long long K = (long long)d->KH * d->KW * d->C;
     if (M > 0x7fffffffLL / 4 || K > 0x7fffffffLL / 4) return false;
+    // 32-bit element offsets inside one group's tensors and weights
     if (M * d->N >= 0x7fffffffLL || (long long)d->B * d->IH * d->IW * d->C >= 0x7fffffffLL) return false;
+    if (d->wts < 0 || d->wcs < 0 || d->wns < 0) return false;
+    long long wmax = (long long)(d->KH * d->KW - 1) * d->wts + (long long)(d->C - 1) * d->wcs +
+                     (long long)(d->N - 1) * d->wns;
+    if (wmax >= 0x7fffffffLL) return false;
+    if ((long long)(d->OH + d->OW + 2 * MAXTAP) * d->a + (d->off < 0 ? -d->off : d->off) >= (1 << 27)) return false;
     g.B = d->B; g.IH = d->IH; g.IW = d->IW; g.C = d->C; g.OH = d->OH; g.OW = d->OW; g.N = d->N;
     g.KH = d->KH; g.KW = d->KW; g.a = d->a; g.cs = d->cs; g.off = d->off; g.d = d->d;
     g.wts = d->wts; g.wcs = d->wcs; g.wns = d->wns; g.M = (int)M; g.K = (int)K;
@@ -630,41 +730,52 @@ bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     return true;
 }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+int pick_mode(const Geom& g, bool vec4, int kblock) {
+    if (!vec4) return MODE_V1;
+    if (g.C % kblock == 0 && g.d == 1) return MODE_TU1;
+    if (g.C % kblock == 0 && g.d == 2) return MODE_TU2;
+    return MODE_V4;
+}
+
 template <int BM, int BN>
-void launch_gemm(hipStream_t s, const GemmArgs& a, int groups, bool vec4) {
+void launch_gemm(hipStream_t s, const GemmArgs& a, int groups, int mode) {
     dim3 grid((a.g.M + BM - 1) / BM, (a.g.N + BN - 1) / BN, groups * a.ksplit);
-    if (vec4)
-        hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 4>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 1>), grid, dim3(256), 0, s, a);
+    switch (mode) {
+        case MODE_TU1: hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, MODE_TU1>), grid, dim3(256), 0, s, a); break;
+        case MODE_TU2: hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, MODE_TU2>), grid, dim3(256), 0, s, a); break;
+        case MODE_V4: hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, MODE_V4>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, MODE_V1>), grid, dim3(256), 0, s, a); break;
+    }
+}
+
+template <int RC, int RN, int DVEC>
+void launch_wgrad_mode(hipStream_t s, const WgradArgs& a, dim3 grid, int mode) {
+    switch (mode) {
+        case MODE_TU1: hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, MODE_TU1, DVEC>), grid, dim3(256), 0, s, a); break;
+        case MODE_TU2: hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, MODE_TU2, DVEC>), grid, dim3(256), 0, s, a); break;
+        case MODE_V4: hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, MODE_V4, DVEC>), grid, dim3(256), 0, s, a); break;
+        default:
+            if constexpr (RC == 1)  // the scalar gather loader only exists for 32-wide k blocks
+                hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, MODE_V1, DVEC>), grid, dim3(256), 0, s, a);
+            break;
+    }
 }
 
 template <int RC, int RN>
-void launch_wgrad(hipStream_t s, const WgradArgs& a, dim3 grid, bool vec4, bool dvec4) {
-    if constexpr (RC == 1) {  // the scalar gather loader only exists for 32-wide k blocks
-        if (!vec4) {
-            if (dvec4)
-                hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 1, 4>), grid, dim3(256), 0, s, a);
-            else
-                hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 1, 1>), grid, dim3(256), 0, s, a);
-            return;
-        }
-    }
-    if (dvec4)
-        hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 4, 4>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, 4, 1>), grid, dim3(256), 0, s, a);
+void launch_wgrad(hipStream_t s, const WgradArgs& a, dim3 grid, int mode, bool dvec4) {
+    if (dvec4) launch_wgrad_mode<RC, RN, 4>(s, a, grid, mode);
+    else launch_wgrad_mode<RC, RN, 1>(s, a, grid, mode);
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
-
-struct GemmPlan { int bm, bn, vec, ksplit; };
-struct WgradPlan { int rc, rn, vec, dvec, nkb, nnb, splits, chunks_per_split; };
+struct GemmPlan { int bm, bn, mode, ksplit; };
+struct WgradPlan { int rc, rn, mode, dvec, nkb, nnb, splits, chunks_per_split; };
 
 GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
     const int M = g.M, N = g.N;
     auto nwg = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * groups; };
-    GemmPlan p{128, 32, vec4 ? 4 : 1, 1};
+    GemmPlan p{128, 32, pick_mode(g, vec4, BK), 1};
     if (N <= 32) {
         p.bm = 128; p.bn = 32;
     } else if (N <= 64) {
@@ -693,9 +804,9 @@ GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
 
 WgradPlan plan_wgrad(const Geom& g, int groups, bool vec4, bool dvec4) {
     WgradPlan p;
-    p.vec = vec4 ? 4 : 1;
     p.dvec = dvec4 ? 4 : 1;
-    p.rc = (vec4 && g.K >= 64) ? 2 : 1;
+    p.rc = (vec4 && g.K >= 64 && g.C % 64 == 0) ? 2 : 1;
+    p.mode = pick_mode(g, vec4, 32 * p.rc);
     p.rn = g.N > 32 ? 2 : 1;
     p.nkb = (g.K + 32 * p.rc - 1) / (32 * p.rc);
     p.nnb = (g.N + 32 * p.rn - 1) / (32 * p.rn);
@@ -707,6 +818,15 @@ WgradPlan plan_wgrad(const Geom& g, int groups, bool vec4, bool dvec4) {
     p.chunks_per_split = (total_chunks + splits - 1) / splits;
     p.splits = (total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     return p;
+}
+
+const char* mode_name(int mode) {
+    switch (mode) {
+        case MODE_TU1: return "TU1";
+        case MODE_TU2: return "TU2";
+        case MODE_V4: return "V4";
+        default: return "V1";
+    }
 }
 
 }  // namespace
@@ -726,12 +846,12 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
         hipError_t e = hipMemsetAsync(out, 0, (size_t)a.g.M * a.g.N * sizeof(float), s);
         if (e != hipSuccess) return pm_check_launch("pm_gather_gemm(memset)");
     }
-    if (p.bm == 128 && p.bn == 32) launch_gemm<128, 32>(s, a, G, vec4);
-    else if (p.bm == 128 && p.bn == 64) launch_gemm<128, 64>(s, a, G, vec4);
-    else if (p.bm == 64 && p.bn == 64) launch_gemm<64, 64>(s, a, G, vec4);
-    else if (p.bm == 128 && p.bn == 128) launch_gemm<128, 128>(s, a, G, vec4);
-    else if (p.bm == 64 && p.bn == 128) launch_gemm<64, 128>(s, a, G, vec4);
-    else launch_gemm<32, 128>(s, a, G, vec4);
+    if (p.bm == 128 && p.bn == 32) launch_gemm<128, 32>(s, a, G, p.mode);
+    else if (p.bm == 128 && p.bn == 64) launch_gemm<128, 64>(s, a, G, p.mode);
+    else if (p.bm == 64 && p.bn == 64) launch_gemm<64, 64>(s, a, G, p.mode);
+    else if (p.bm == 128 && p.bn == 128) launch_gemm<128, 128>(s, a, G, p.mode);
+    else if (p.bm == 64 && p.bn == 128) launch_gemm<64, 128>(s, a, G, p.mode);
+    else launch_gemm<32, 128>(s, a, G, p.mode);
     if (p.ksplit > 1) {
         long long total = (long long)a.g.M * a.g.N;
         long long blocks = (total + 255) / 256;
@@ -751,33 +871,37 @@ extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, cons
     const bool dvec4 = (d->N % 4 == 0) && aligned16(dense) && (d->out_gs % 4 == 0);
     const WgradPlan p = plan_wgrad(a.g, d->groups, vec4, dvec4);
     a.chunks_per_split = p.chunks_per_split;
+    const int hw = a.g.OH * a.g.OW;
+    a.step_b = 128 / hw;
+    a.step_p = (128 - a.step_b * hw) / a.g.OW;
+    a.step_q = 128 - a.step_b * hw - a.step_p * a.g.OW;
     dim3 grid(p.nkb * p.nnb, p.splits, d->groups);
     hipStream_t s = (hipStream_t)stream;
-    if (p.rc == 2 && p.rn == 2) launch_wgrad<2, 2>(s, a, grid, vec4, dvec4);
-    else if (p.rc == 2) launch_wgrad<2, 1>(s, a, grid, vec4, dvec4);
-    else if (p.rn == 2) launch_wgrad<1, 2>(s, a, grid, vec4, dvec4);
-    else launch_wgrad<1, 1>(s, a, grid, vec4, dvec4);
+    if (p.rc == 2 && p.rn == 2) launch_wgrad<2, 2>(s, a, grid, p.mode, dvec4);
+    else if (p.rc == 2) launch_wgrad<2, 1>(s, a, grid, p.mode, dvec4);
+    else if (p.rn == 2) launch_wgrad<1, 2>(s, a, grid, p.mode, dvec4);
+    else launch_wgrad<1, 1>(s, a, grid, p.mode, dvec4);
     return pm_check_launch("pm_gather_wgrad");
 }
 
 // Which kernel instantiation a problem dispatches to (bench.py names its roofline row with it).
-extern "C" int pm_query_gemm_plan(const pm_gather_desc* d, int in_aligned16, int* bm, int* bn, int* vec) {
+extern "C" int pm_query_gemm_plan(const pm_gather_desc* d, int in_aligned16, int* bm, int* bn, int* mode) {
     Geom g;
-    if (!fill_geom(d, g, true) || !bm || !bn || !vec) return PM_EINVAL;
+    if (!fill_geom(d, g, true) || !bm || !bn || !mode) return PM_EINVAL;
     const bool vec4 = (d->C % 4 == 0) && in_aligned16 && (d->in_gs % 4 == 0);
     const GemmPlan p = plan_gemm(g, d->groups, vec4);
-    *bm = p.bm; *bn = p.bn; *vec = p.vec;
+    *bm = p.bm; *bn = p.bn; *mode = p.mode;
     return PM_OK;
 }
 
 extern "C" int pm_query_wgrad_plan(const pm_gather_desc* d, int gathered_aligned16, int dense_aligned16, int* rc,
-                                   int* rn, int* vec, int* dvec, int* workgroups) {
+                                   int* rn, int* mode, int* dvec, int* workgroups) {
     Geom g;
-    if (!fill_geom(d, g, false) || !rc || !rn || !vec || !dvec || !workgroups) return PM_EINVAL;
+    if (!fill_geom(d, g, false) || !rc || !rn || !mode || !dvec || !workgroups) return PM_EINVAL;
     const bool vec4 = (d->C % 4 == 0) && gathered_aligned16 && (d->in_gs % 4 == 0);
     const bool dvec4 = (d->N % 4 == 0) && dense_aligned16 && (d->out_gs % 4 == 0);
     const WgradPlan p = plan_wgrad(g, d->groups, vec4, dvec4);
-    *rc = p.rc; *rn = p.rn; *vec = p.vec; *dvec = p.dvec;
+    *rc = p.rc; *rn = p.rn; *mode = p.mode; *dvec = p.dvec;
     *workgroups = p.nkb * p.nnb * p.splits * d->groups;
     return PM_OK;
 }

@@ -206,6 +206,9 @@ def _algorithmic_flops(d: GatherDesc) -> float:
     return 2.0 * d.B * vy * vx * d.C * d.N * d.groups
 
 
+_MODES = {0: "TU1", 1: "TU2", 2: "V4", 3: "V1"}   # loader modes of csrc/pm_conv.hip
+
+
 def _detail(d: GatherDesc) -> str:
     return (f"B{d.B} in{d.IH}x{d.IW}x{d.C} out{d.OH}x{d.OW}x{d.N} k{d.KH} a{d.a} d{d.d} g{d.groups}")
 
@@ -216,7 +219,7 @@ def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
         bm, bn, vec = C.c_int(), C.c_int(), C.c_int()
         _lib.load().pm_query_gemm_plan(C.byref(desc), int(inp.data_ptr() % 16 == 0), C.byref(bm), C.byref(bn),
                                        C.byref(vec))
-        tag = f"gather_gemm_kernel<{bm.value},{bn.value},{vec.value}>"
+        tag = f"gather_gemm_kernel<{bm.value},{bn.value},{_MODES[vec.value]}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, w, aux, res, out), "detail": _detail(desc)}
     _call("pm_gather_gemm", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), tag=tag,
           work=work)
@@ -228,7 +231,7 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
         v = [C.c_int() for _ in range(5)]
         _lib.load().pm_query_wgrad_plan(C.byref(desc), int(gathered.data_ptr() % 16 == 0),
                                         int(dense.data_ptr() % 16 == 0), *[C.byref(x) for x in v])
-        tag = f"gather_wgrad_kernel<{v[0].value},{v[1].value},{v[2].value},{v[3].value}>"
+        tag = f"gather_wgrad_kernel<{v[0].value},{v[1].value},{_MODES[v[2].value]},{v[3].value}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
     _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
