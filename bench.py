@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
 
     import torch
@@ -73,10 +75,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)        # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     cfg, xs, B = pm_vae_mnist(), (28, 28, 1), args.batch
     model = PosteriorMatchingVAE.from_config(cfg["model"], device=dev, seed=1)    # same init on every rank

@@ -21,6 +21,7 @@
 // loaders are written to cost a few VALU instructions per row (tap decode and weight base are
 // wave-uniform scalars, per-row state is precomputed), otherwise address arithmetic - not the
 // matrix pipe - bounds the kernel.
+#include <type_traits>
 #include "pm_common.h"
 
 namespace {
@@ -115,7 +116,8 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
     static constexpr int NP = BM / RPP;
     int slot4, r0;
     int rbase[NP], rpy[NP], rqx[NP];
-    f32x4 regs[NP];
+    f32x4 regs[NP];   // raw loaded data: first touched in store(), so the loads stay in flight
+    unsigned okmask;  // bit j: row j of the pending chunk hit a real pixel
 
     __device__ __forceinline__ void init(int tid) {
         slot4 = 4 * (tid % SLOTS);
@@ -182,22 +184,24 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
                                              bool kok) {
         const int dyv = ky * g.cs, dxv = kx * g.cs;
         const int c = cbeg + slot4;
+        unsigned okm = 0u;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             int sy, sx;
             const bool oky = coord_ok<DD>(rpy[j] + dyv, g.d, g.IH, sy);
             const bool okx = coord_ok<DD>(rqx[j] + dxv, g.d, g.IW, sx);
             const bool ok = (int(oky) & int(okx) & int(kok)) != 0;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(in + (rbase[j] + (sy * g.IW + sx) * g.C + c));
-            regs[j] = v;
+            // branch-free: always load (offset c of image 0 when the tap misses), then select.  A
+            // conditional load would put an s_waitcnt behind every row and serialise the gather.
+            const int o = ok ? rbase[j] + (sy * g.IW + sx) * g.C + c : c;
+#if defined(PM_EXP) && PM_EXP == 1
+            regs[j] = f32x4{1.f, 2.f, 3.f, float(o)};
+#else
+            regs[j] = *reinterpret_cast<const f32x4*>(in + o);
+#endif
+            okm |= (ok ? 1u : 0u) << j;
         }
-        if (g.in_act != PM_ACT_NONE) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) regs[j][e] = pm_act(regs[j][e], g.in_act, g.slope);
-        }
+        okmask = okm;
     }
     // generic chunk: per-thread tap decode from the flattened k index
     __device__ __forceinline__ void load_flat(const Geom& g, const float* __restrict__ in, int kk0, int keff,
@@ -211,7 +215,25 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
         int kx = kok ? tl->kx[tj - jy * tl->nvx] : 0;
         load_tap(g, in, ky, kx, c - slot4, kok);
     }
-    __device__ __forceinline__ void store(float* tile, int ld) {
+    // zero the misses, apply the pending input activation (one uniform branch), write the tile
+    __device__ __forceinline__ void store(const Geom& g, float* tile, int ld) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const bool ok = (okmask >> j) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) regs[j][e] = ok ? regs[j][e] : 0.f;
+        }
+        if (g.in_act == PM_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) regs[j][e] = fmaxf(regs[j][e], 0.f);
+        } else if (g.in_act == PM_ACT_LEAKY) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) regs[j][e] = regs[j][e] >= 0.f ? regs[j][e] : g.slope * regs[j][e];
+        }
 #pragma unroll
         for (int j = 0; j < NP; ++j) *reinterpret_cast<f32x4*>(tile + (r0 + j * RPP) * ld + slot4) = regs[j];
     }
@@ -272,7 +294,7 @@ struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened ove
             }
         }
     }
-    __device__ __forceinline__ void store(float* tile, int ld) {
+    __device__ __forceinline__ void store(const Geom&, float* tile, int ld) {
 #pragma unroll
         for (int j = 0; j < RPT; ++j) tile[(rg * RPT + j) * ld + kslot] = regs[j];
     }
@@ -386,7 +408,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     auto load_b_tap = [&](int tap, int cbeg) {  // uniform tap: one scalar base per chunk
         const float* wb = w + ((size_t)tap * g.wts + (size_t)cbeg * g.wcs);
 #pragma unroll
-        for (int j = 0; j < NBE; ++j) breg[j] = boff[j] >= 0 ? wb[boff[j]] : 0.f;
+        for (int j = 0; j < NBE; ++j) breg[j] = wb[boff[j] >= 0 ? boff[j] : 0];  // masked in store_b
     };
     auto load_b_flat = [&](int kk0) {
 #pragma unroll
@@ -406,7 +428,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     };
     auto store_b = [&]() {
 #pragma unroll
-        for (int j = 0; j < NBE; ++j) Bs[(bkl[j] >> 8) * LDS_LD + (bkl[j] & 255)] = breg[j];
+        for (int j = 0; j < NBE; ++j) Bs[(bkl[j] >> 8) * LDS_LD + (bkl[j] & 255)] = boff[j] >= 0 ? breg[j] : 0.f;
     };
 
     f32x16 acc[RN];
@@ -446,7 +468,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     };
     if (cb < ce) load_chunk(cb);
     for (int ch = cb; ch < ce; ++ch) {
-        la.store(As, LDS_LD);
+        la.store(g, As, LDS_LD);
         store_b();
         __syncthreads();
         if (ch + 1 < ce) load_chunk(ch + 1);
@@ -460,7 +482,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
                 f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + r * 32 * LDS_LD + 8 * u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
+#if defined(PM_EXP) && PM_EXP == 2
+                    acc[r][e] += a4[e] * b4[e];
+#else
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[r], 0, 0, 0);
+#endif
             }
         }
         __syncthreads();
@@ -579,28 +605,35 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
     const int dn = n0 + dslot * DVEC;
     const bool dn_ok = dn < g.N;
     float dreg[DNP][DVEC];
+    unsigned dmask = 0u;
     auto load_d = [&](int m0) {
+        dmask = 0u;
 #pragma unroll
         for (int j = 0; j < DNP; ++j) {
             int m = m0 + dr0 + j * DRPP;
+            const bool ok = m < g.M && dn_ok;
+            const size_t o = ok ? (size_t)m * g.N + dn : 0;   // branch-free load + select
+            dmask |= (ok ? 1u : 0u) << j;
             if (DVEC == 4) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < g.M && dn_ok) v = *reinterpret_cast<const f32x4*>(din + (size_t)m * g.N + dn);
+                f32x4 v = *reinterpret_cast<const f32x4*>(din + o);
 #pragma unroll
                 for (int e = 0; e < DVEC; ++e) dreg[j][e] = v[e];
             } else {
-                dreg[j][0] = (m < g.M && dn_ok) ? din[(size_t)m * g.N + dn] : 0.f;
+                dreg[j][0] = din[o];
             }
         }
     };
     auto store_d = [&]() {
 #pragma unroll
         for (int j = 0; j < DNP; ++j) {
+            const bool ok = (dmask >> j) & 1u;
             if (DVEC == 4) {
                 f32x4 v = {dreg[j][0], dreg[j][1 % DVEC], dreg[j][2 % DVEC], dreg[j][3 % DVEC]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
                 *reinterpret_cast<f32x4*>(Ds + (dr0 + j * DRPP) * NB + dslot * DVEC) = v;
             } else {
-                Ds[(dr0 + j * DRPP) * NB + dslot] = dreg[j][0];
+                Ds[(dr0 + j * DRPP) * NB + dslot] = ok ? dreg[j][0] : 0.f;
             }
         }
     };
@@ -630,7 +663,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
         load_d(c_begin * BMC);
     }
     for (int ch = c_begin; ch < c_end; ++ch) {
-        lg.store(Gs, CB);
+        lg.store(g, Gs, CB);
         store_d();
         __syncthreads();
         if (ch + 1 < c_end) {
@@ -640,24 +673,30 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
         }
         const float* grow = Gs + (wave * 32 + h) * CB + i;
         const float* drow = Ds + (wave * 32 + h) * NB + i;
+        // two copies of the MFMA loop, selected by one uniform branch: a bias MFMA under a branch
+        // INSIDE the loop makes hipcc shuttle the bias accumulators between AGPRs and VGPRs
+        auto mma = [&](auto with_bias) {
 #pragma unroll 4
-        for (int t = 0; t < 16; ++t) {
-            float av[RC], bv[RN];
+            for (int t = 0; t < 16; ++t) {
+                float av[RC], bv[RN];
 #pragma unroll
-            for (int a = 0; a < RC; ++a) av[a] = grow[2 * t * CB + 32 * a];
+                for (int a = 0; a < RC; ++a) av[a] = grow[2 * t * CB + 32 * a];
 #pragma unroll
-            for (int b = 0; b < RN; ++b) bv[b] = drow[2 * t * NB + 32 * b];
+                for (int b = 0; b < RN; ++b) bv[b] = drow[2 * t * NB + 32 * b];
 #pragma unroll
-            for (int a = 0; a < RC; ++a)
+                for (int a = 0; a < RC; ++a)
 #pragma unroll
-                for (int b = 0; b < RN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-            if (do_bias) {
+                    for (int b = 0; b < RN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                if constexpr (decltype(with_bias)::value) {
 #pragma unroll
-                for (int b = 0; b < RN; ++b)
-                    accb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, bv[b], accb[b], 0, 0, 0);
+                    for (int b = 0; b < RN; ++b)
+                        accb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, bv[b], accb[b], 0, 0, 0);
+                }
             }
-        }
+        };
+        if (do_bias) mma(std::true_type{});
+        else mma(std::false_type{});
         __syncthreads();
     }
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single layers through the C ABI (HIP events, L2-warm, back-to-back).
+    python tools/bench_layer.py [libpath]      # optional alternative libpmhip build (experiments)
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1:
+    import posterior_matching_amd._lib as L
+
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
+import torch
+
+from posterior_matching_amd import ops
+from posterior_matching_amd.ops import ACT_LEAKY, LayerGeom
+
+CASES = [
+    ("dec5 fwd 28x28 32->32 k5", LayerGeom.conv_t(28, 28, 32, 32, 5, 1, "SAME"), "fwd"),
+    ("enc3 fwd 14x14 32->64 k5", LayerGeom.conv(14, 14, 32, 64, 5, 1, "SAME"), "fwd"),
+    ("dec3 fwd 14x14 64->32 k5", LayerGeom.conv_t(14, 14, 64, 32, 5, 1, "SAME"), "fwd"),
+    ("enc2 fwd 28->14 s2 32->32", LayerGeom.conv(28, 28, 32, 32, 5, 2, "SAME"), "fwd"),
+    ("dec4 fwd 14->28 s2 32->32", LayerGeom.conv_t(14, 14, 32, 32, 5, 2, "SAME"), "fwd"),
+    ("mlp dense 8192x256x256", LayerGeom.dense(256, 256), "fwd8192"),
+    ("dec5 wgrad", LayerGeom.conv_t(28, 28, 32, 32, 5, 1, "SAME"), "wgrad"),
+    ("enc3 wgrad", LayerGeom.conv(14, 14, 32, 64, 5, 1, "SAME"), "wgrad"),
+    ("mlp wgrad 8192x256x256", LayerGeom.dense(256, 256), "wgrad8192"),
+]
+
+
+def main():
+    d = torch.device("cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for name, g, what in CASES:
+            B = 8192 if what.endswith("8192") else 256
+            x = torch.randn((B, g.IH, g.IW, g.CI), device=d)
+            w = torch.randn(g.weight_shape, device=d) * 0.05
+            b = torch.zeros(g.CO, device=d)
+            y = torch.empty((B, g.OH, g.OW, g.CO), device=d)
+            dw, db = torch.zeros_like(w), torch.zeros_like(b)
+            if what.startswith("fwd"):
+                fn = lambda: ops.layer_forward(g, x, w, b, y, out_act=ACT_LEAKY)
+            else:
+                y.normal_()
+                fn = lambda: ops.layer_wgrad(g, x, y, dw, db)
+            for _ in range(5):
+                fn()
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record()
+            reps = 50
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_ms(e1) / reps * 1e3
+            macs = B * g.OH * g.OW * g.k * g.k * g.CI * g.CO if g.kind != "convT" or g.s == 1 else B * g.IH * g.IW * g.k * g.k * g.CI * g.CO
+            if g.kind == "conv" and g.s > 1:
+                macs = B * g.OH * g.OW * g.k * g.k * g.CI * g.CO
+            print(f"{name:30s} {us:8.1f} us  {2 * macs / us / 1e6:7.1f} TFLOP/s (nominal)")
+
+
+if __name__ == "__main__":
+    main()
