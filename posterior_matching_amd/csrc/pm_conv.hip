@@ -537,6 +537,264 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, long l
     }
 }
 
+// ----------------------- forward / data-gradient, direct-fragment form ------------------------
+// On gfx950 the f32 MFMA runs at the f32 VALU rate and (measured: kernel time = MFMA time + time
+// of everything else) does not overlap with VALU work, so every address / select / LDS-staging
+// instruction of the gathered operand is paid in full.  This form therefore never stages the
+// gathered operand: each lane loads its MFMA A fragment (row = its output position, 4 consecutive
+// channels) straight from global memory with a bounds-checked buffer load - a tap that misses the
+// image gets an out-of-range offset and the hardware returns zeros - at a cost of ~10 VALU
+// instructions per 16 MFMAs.  Weights are the only LDS traffic: GS k-steps (one k-step = one tap x
+// 32 channels) are staged per barrier, double-buffered.  Needs C % 32 == 0.
+constexpr int DGS = 4;          // k-steps staged per barrier
+constexpr int DMAXSTEPS = 256;  // k-step descriptors kept in LDS
+
+struct KStep {
+    int dy, dx;  // tap displacement in the index rule (ky*cs, kx*cs)
+    int c0;      // first channel of the step
+    int woff;    // weight offset tap*wts + c0*wcs
+};
+
+template <int RN, int DD, int IN_ACT>
+__global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
+    constexpr int NB = 32 * RN;
+    constexpr int BTILE = DGS * NB * LDS_LD;            // floats of one weight stage
+    constexpr int EPS = NB * BK / 256;                  // weight elements per thread per k-step
+    constexpr int TL_F = (sizeof(TapList) + 3) / 4;
+    constexpr int KD_F = DMAXSTEPS * (sizeof(KStep) / 4);
+    __shared__ __attribute__((aligned(16))) float smem[2 * BTILE + KD_F + TL_F];
+    float* Bs = smem;
+    KStep* kd = reinterpret_cast<KStep*>(smem + 2 * BTILE);
+    TapList* tl = reinterpret_cast<TapList*>(smem + 2 * BTILE + KD_F);
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int n0 = blockIdx.y * NB;
+    const int grp = blockIdx.z / p.ksplit;
+    const int ks = blockIdx.z - grp * p.ksplit;
+    const float* in = p.in + (size_t)grp * p.in_gs;
+    const float* w = p.w + (size_t)grp * p.w_gs;
+
+    // this lane's output row (class-major) and its source-coordinate bases
+    const int m = blockIdx.x * 128 + wave * 32 + i;
+    int rbase = 0, rpy = ROW_INVALID, rqx = ROW_INVALID, rowoff = -1;
+    if (m < g.M) {
+        int b, pp, q;
+        decode_row(g, m, b, pp, q);
+        rbase = b * g.IH * g.IW * g.C + 4 * h;
+        rpy = pp * g.a + g.off;
+        rqx = q * g.a + g.off;
+        rowoff = ((b * g.OH + pp) * g.OW + q) * g.N;
+    }
+    {
+        unsigned my = 0u, mx = 0u;
+        int s;
+        for (int t = 0; t < g.KH; ++t)
+            if (coord_ok<DD>(rpy + t * g.cs, g.d, g.IH, s)) my |= 1u << t;
+        for (int t = 0; t < g.KW; ++t)
+            if (coord_ok<DD>(rqx + t * g.cs, g.d, g.IW, s)) mx |= 1u << t;
+        build_tap_list(g, tl, my, mx, tid);
+    }
+    const int cchunks = g.C / BK;
+    const int nsteps_all = tl->nvy * tl->nvx * cchunks;
+    for (int s = tid; s < nsteps_all + DGS; s += 256) {  // DGS padding entries: safe reads past the end
+        KStep k{0, 0, 0, 0};
+        if (s < nsteps_all) {
+            int tj = s / cchunks;
+            int cc = s - tj * cchunks;
+            int jy = tj / tl->nvx;
+            int ky = tl->ky[jy], kx = tl->kx[tj - jy * tl->nvx];
+            k.dy = ky * g.cs;
+            k.dx = kx * g.cs;
+            k.c0 = cc * BK;
+            k.woff = (ky * g.KW + kx) * g.wts + cc * BK * g.wcs;
+        }
+        kd[s] = k;
+    }
+    __syncthreads();
+    const int sb = (int)(((long long)nsteps_all * ks) / p.ksplit);
+#if defined(PM_EXP) && PM_EXP == 6
+    const int se = sb;
+#else
+    const int se = (int)(((long long)nsteps_all * (ks + 1)) / p.ksplit);
+#endif
+
+    // bounds-checked view of the gathered tensor: offsets past the end read as zero
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in), 0, (int)((long long)g.B * g.IH * g.IW * g.C * 4), 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    f32x4 af[2][4];
+    auto issue_a = [&](int s, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        const KStep k = kd[s];
+        int sy, sx;
+        const bool oky = coord_ok<DD>(rpy + k.dy, g.d, g.IH, sy);
+        const bool okx = coord_ok<DD>(rqx + k.dx, g.d, g.IW, sx);
+        const int off = (rbase + (sy * g.IW + sx) * g.C + k.c0) * 4;
+        const int voff = (int(oky) & int(okx)) ? off : OOB;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#if defined(PM_EXP) && PM_EXP == 3
+            af[SET][u] = f32x4{1.f, 2.f, float(voff), 4.f};
+#else
+            af[SET][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 32 * u, 0));
+#endif
+    };
+
+    // weight stage loader: Bs[stage][step][n][k] <- w[woff(step) + k*wcs + (n0+n)*wns].  Columns
+    // past N and steps past the end load a safe address instead of being masked: their products
+    // land in accumulator columns / steps that are never stored or never executed.
+    const bool ncontig = (g.wns == 1);
+    int eo[EPS];     // element offset inside a k-step's weight block
+    int lo[EPS];     // LDS offset inside a step's Bs block
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) {
+        int e = tid + 256 * j;
+        int nl, kl;
+        if (ncontig) {
+            nl = e % NB;
+            kl = e / NB;
+        } else {
+            kl = e % BK;
+            nl = e / BK;
+        }
+        eo[j] = kl * g.wcs + (n0 + nl < g.N ? n0 + nl : 0) * g.wns;
+        lo[j] = nl * LDS_LD + kl;
+    }
+    float breg[DGS][EPS];
+    auto load_b = [&](int s0) {
+#pragma unroll
+        for (int st = 0; st < DGS; ++st) {
+            const float* wb = w + kd[s0 + st].woff;   // kd is padded: s0 + st < nsteps_all + DGS
+#pragma unroll
+#if defined(PM_EXP) && PM_EXP == 5
+            for (int j = 0; j < EPS; ++j) breg[st][j] = float(eo[j] + st);
+#else
+            for (int j = 0; j < EPS; ++j) breg[st][j] = wb[eo[j]];
+#endif
+        }
+    };
+    auto store_b = [&](float* dst) {
+#pragma unroll
+        for (int st = 0; st < DGS; ++st)
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) dst[st * NB * LDS_LD + lo[j]] = breg[st][j];
+    };
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    auto mma_step = [&](const float* bstep, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        if constexpr (IN_ACT == PM_ACT_RELU) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) af[SET][u][e] = fmaxf(af[SET][u][e], 0.f);
+        } else if constexpr (IN_ACT == PM_ACT_LEAKY) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    af[SET][u][e] = af[SET][u][e] >= 0.f ? af[SET][u][e] : g.slope * af[SET][u][e];
+        }
+        const float* brow = bstep + i * LDS_LD + 4 * h;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + r * 32 * LDS_LD + 8 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#if defined(PM_EXP) && PM_EXP == 4
+                    acc[r][e] += af[SET][u][e] * b4[e];
+#else
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[SET][u][e], b4[e], acc[r], 0, 0, 0);
+#endif
+            }
+        }
+    };
+
+    if (sb < se) {
+        load_b(sb);
+        store_b(Bs);
+        issue_a(sb, std::integral_constant<int, 0>{});
+    }
+    __syncthreads();
+    int stage = 0;
+    for (int s0 = sb; s0 < se; s0 += DGS) {
+        const float* bcur = Bs + stage * BTILE;
+        const bool more = s0 + DGS < se;
+        if (more) load_b(s0 + DGS);  // stays in flight during the MFMAs below
+        // 4 k-steps, A fragments double-buffered in registers one step ahead
+        if (s0 + 1 < se) issue_a(s0 + 1, std::integral_constant<int, 1>{});
+        mma_step(bcur, std::integral_constant<int, 0>{});
+        if (s0 + 1 < se) {
+            if (s0 + 2 < se) issue_a(s0 + 2, std::integral_constant<int, 0>{});
+            mma_step(bcur + NB * LDS_LD, std::integral_constant<int, 1>{});
+        }
+        if (s0 + 2 < se) {
+            if (s0 + 3 < se) issue_a(s0 + 3, std::integral_constant<int, 1>{});
+            mma_step(bcur + 2 * NB * LDS_LD, std::integral_constant<int, 0>{});
+        }
+        if (s0 + 3 < se) {
+            if (s0 + 4 < se) issue_a(s0 + 4, std::integral_constant<int, 0>{});
+            mma_step(bcur + 3 * NB * LDS_LD, std::integral_constant<int, 1>{});
+        }
+        if (more) store_b(Bs + (stage ^ 1) * BTILE);
+        __syncthreads();
+        stage ^= 1;
+    }
+
+    // epilogue (C/D layout: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); the row a
+    // register belongs to lives in another lane: fetch its output offset with a wave shuffle
+    const float* bias = p.bias ? p.bias + (size_t)grp * p.bias_gs : nullptr;
+    const float* aux = p.aux ? p.aux + (size_t)grp * p.out_gs : nullptr;
+    const float* res = p.res ? p.res + (size_t)grp * p.out_gs : nullptr;
+    float* out = p.out + (size_t)grp * p.out_gs;
+    int ro[16];
+#if defined(PM_EXP) && PM_EXP == 7
+    if (acc[0][0] != 123.456f) return;
+#endif
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ro[e] = __shfl(rowoff, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
+#pragma unroll
+    for (int r = 0; r < RN; ++r) {
+        int n = n0 + r * 32 + i;
+        if (n >= g.N) continue;
+        float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (ro[e] < 0) continue;
+            size_t o = (size_t)ro[e] + n;
+            if (p.ksplit > 1) {
+                atomicAdd(out + o, acc[r][e]);
+                continue;
+            }
+            float v = acc[r][e] + bv;
+            if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
+            if (res) v += res[o];
+            out[o] = pm_act(v, g.out_act, g.slope);
+        }
+    }
+}
+
+template <int RN, int DD>
+void launch_direct(hipStream_t s, const GemmArgs& a, dim3 grid) {
+    switch (a.g.in_act) {
+        case PM_ACT_RELU: hipLaunchKernelGGL((direct_gemm_kernel<RN, DD, PM_ACT_RELU>), grid, dim3(256), 0, s, a); break;
+        case PM_ACT_LEAKY: hipLaunchKernelGGL((direct_gemm_kernel<RN, DD, PM_ACT_LEAKY>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((direct_gemm_kernel<RN, DD, PM_ACT_NONE>), grid, dim3(256), 0, s, a); break;
+    }
+}
+
 // ------------------------------------ weight gradient ----------------------------------------
 // dw[kk][n] += sum_m G[m][kk] * D[m][n].  A workgroup owns a (32*RC) x (32*RN) block of dw and a
 // range of 128-row chunks of m; its 4 waves each take 32 rows of a chunk (MFMA k = 2 rows per
@@ -808,13 +1066,13 @@ void launch_wgrad(hipStream_t s, const WgradArgs& a, dim3 grid, int mode, bool d
     else launch_wgrad_mode<RC, RN, 1>(s, a, grid, mode);
 }
 
-struct GemmPlan { int bm, bn, mode, ksplit; };
+struct GemmPlan { int bm, bn, mode, ksplit; bool direct; };
 struct WgradPlan { int rc, rn, mode, dvec, nkb, nnb, splits, chunks_per_split; };
 
 GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
     const int M = g.M, N = g.N;
     auto nwg = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * groups; };
-    GemmPlan p{128, 32, pick_mode(g, vec4, BK), 1};
+    GemmPlan p{128, 32, pick_mode(g, vec4, BK), 1, false};
     if (N <= 32) {
         p.bm = 128; p.bn = 32;
     } else if (N <= 64) {
@@ -831,6 +1089,12 @@ GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
     if (g.PY > 1 || g.PX > 1)
         taps = (g.IH == 1 && g.IW == 1) ? 1 : ((g.KH + g.PY - 1) / g.PY) * ((g.KW + g.PX - 1) / g.PX);
     const int chunks = (taps * g.C + BK - 1) / BK;
+    p.direct = (p.mode == MODE_TU1 || p.mode == MODE_TU2) && g.KH * g.KW * (g.C / BK) <= DMAXSTEPS && g.KH <= 15 &&
+               g.KW <= 15 && (long long)g.B * g.IH * g.IW * g.C * 4 < 0x7ffffff0LL;
+    if (p.direct) {
+        p.bm = 128;
+        p.bn = N > 32 ? 64 : 32;
+    }
     const long long tiles = nwg(p.bm, p.bn);
     if (groups == 1 && tiles < 128 && chunks >= 16) {
         int ks = (int)((256 + tiles - 1) / tiles);
@@ -885,7 +1149,14 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
         hipError_t e = hipMemsetAsync(out, 0, (size_t)a.g.M * a.g.N * sizeof(float), s);
         if (e != hipSuccess) return pm_check_launch("pm_gather_gemm(memset)");
     }
-    if (p.bm == 128 && p.bn == 32) launch_gemm<128, 32>(s, a, G, p.mode);
+    if (p.direct) {
+        const int rn = a.g.N > 32 ? 2 : 1;
+        dim3 grid((a.g.M + 127) / 128, (a.g.N + 32 * rn - 1) / (32 * rn), G * a.ksplit);
+        if (rn == 1 && p.mode == MODE_TU1) launch_direct<1, 1>(s, a, grid);
+        else if (rn == 1) launch_direct<1, 2>(s, a, grid);
+        else if (p.mode == MODE_TU1) launch_direct<2, 1>(s, a, grid);
+        else launch_direct<2, 2>(s, a, grid);
+    } else if (p.bm == 128 && p.bn == 32) launch_gemm<128, 32>(s, a, G, p.mode);
     else if (p.bm == 128 && p.bn == 64) launch_gemm<128, 64>(s, a, G, p.mode);
     else if (p.bm == 64 && p.bn == 64) launch_gemm<64, 64>(s, a, G, p.mode);
     else if (p.bm == 128 && p.bn == 128) launch_gemm<128, 128>(s, a, G, p.mode);
@@ -929,7 +1200,7 @@ extern "C" int pm_query_gemm_plan(const pm_gather_desc* d, int in_aligned16, int
     if (!fill_geom(d, g, true) || !bm || !bn || !mode) return PM_EINVAL;
     const bool vec4 = (d->C % 4 == 0) && in_aligned16 && (d->in_gs % 4 == 0);
     const GemmPlan p = plan_gemm(g, d->groups, vec4);
-    *bm = p.bm; *bn = p.bn; *mode = p.mode;
+    *bm = p.bm; *bn = p.bn; *mode = p.mode + (p.direct ? 16 : 0);
     return PM_OK;
 }
 

@@ -219,7 +219,10 @@ def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
         bm, bn, vec = C.c_int(), C.c_int(), C.c_int()
         _lib.load().pm_query_gemm_plan(C.byref(desc), int(inp.data_ptr() % 16 == 0), C.byref(bm), C.byref(bn),
                                        C.byref(vec))
-        tag = f"gather_gemm_kernel<{bm.value},{bn.value},{_MODES[vec.value]}>"
+        if vec.value >= 16:
+            tag = f"direct_gemm_kernel<{bn.value // 32},{_MODES[vec.value - 16]}>"
+        else:
+            tag = f"gather_gemm_kernel<{bm.value},{bn.value},{_MODES[vec.value]}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, w, aux, res, out), "detail": _detail(desc)}
     _call("pm_gather_gemm", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), tag=tag,
           work=work)
