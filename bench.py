@@ -54,7 +54,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step (single stream) "
+                                                        "instead of eager launches on two overlapping streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
@@ -90,7 +91,7 @@ def main():
     model.init(xs)
     opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg.get("weight_decay", 0.0)),
                       optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
-    ts = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=world, rank=rank, use_graph=not args.no_graph)
+    ts = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=world, rank=rank, use_graph=args.graph)
     pool = SyntheticDataset(cfg["data"], B, num_batches=16, seed=100 + rank, device=dev)
     batches = pool.batches
 
@@ -121,6 +122,7 @@ def main():
     # live per-kernel timing with HIP events on the launching stream (eager, outside the timed region)
     roofline = None
     if rank == 0 and args.profile_steps > 0:
+        model.concurrent = False        # per-kernel times: one stream, so durations do not overlap
         prof = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=1, rank=0, use_graph=False)
         prof.set_batch(batches[0]["image"], batches[0]["mask"])
         prof.step()
@@ -167,7 +169,7 @@ def main():
             "config": {"workload": "configs/pm_vae_mnist.py: conv PM-VAE 28x28x1, latent 32, TriL posterior, "
                                    "AR-GMM partial posterior, Bernoulli decoder; full train step (fwd+loss+bwd+Adam)",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "hip_graph": not args.no_graph, "params": model.num_params},
+                       "launch": "hip_graph_1stream" if args.graph else "eager_2streams", "params": model.num_params},
             "aux": {"elbo": round(metrics["reconstruction_ll"] - metrics["beta"] * metrics["kl"], 4),
                     "matching_ll": round(metrics["matching_ll"], 4), "kl": round(metrics["kl"], 4),
                     "loss": round(metrics["loss"], 4)},

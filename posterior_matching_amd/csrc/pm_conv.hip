@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(in), 0, (int)((long long)g.B * g.IH * g.IW * g.C * 4), 0x00020000);
     constexpr int OOB = 0x7ffffff0;
-    f32x4 af[2][4];
+    f32x4 af[4][4];
     auto issue_a = [&](int s, auto set_tag) {
         constexpr int SET = decltype(set_tag)::value;
         const KStep k = kd[s];
@@ -722,10 +722,14 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
         }
     };
 
+    // A fragments run PD = 2 k-steps ahead of the MFMAs in 4 register sets (set = step index in its
+    // stage, so every access is a compile-time register): one step of MFMAs (1024 cycles) does not
+    // cover an L2 round trip when the whole chip is streaming.
     if (sb < se) {
         load_b(sb);
         store_b(Bs);
         issue_a(sb, std::integral_constant<int, 0>{});
+        if (sb + 1 < se) issue_a(sb + 1, std::integral_constant<int, 1>{});
     }
     __syncthreads();
     int stage = 0;
@@ -733,20 +737,19 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
         const float* bcur = Bs + stage * BTILE;
         const bool more = s0 + DGS < se;
         if (more) load_b(s0 + DGS);  // stays in flight during the MFMAs below
-        // 4 k-steps, A fragments double-buffered in registers one step ahead
-        if (s0 + 1 < se) issue_a(s0 + 1, std::integral_constant<int, 1>{});
+        if (s0 + 2 < se) issue_a(s0 + 2, std::integral_constant<int, 2>{});
         mma_step(bcur, std::integral_constant<int, 0>{});
         if (s0 + 1 < se) {
-            if (s0 + 2 < se) issue_a(s0 + 2, std::integral_constant<int, 0>{});
+            if (s0 + 3 < se) issue_a(s0 + 3, std::integral_constant<int, 3>{});
             mma_step(bcur + NB * LDS_LD, std::integral_constant<int, 1>{});
         }
         if (s0 + 2 < se) {
-            if (s0 + 3 < se) issue_a(s0 + 3, std::integral_constant<int, 1>{});
-            mma_step(bcur + 2 * NB * LDS_LD, std::integral_constant<int, 0>{});
+            if (s0 + 4 < se) issue_a(s0 + 4, std::integral_constant<int, 0>{});
+            mma_step(bcur + 2 * NB * LDS_LD, std::integral_constant<int, 2>{});
         }
         if (s0 + 3 < se) {
-            if (s0 + 4 < se) issue_a(s0 + 4, std::integral_constant<int, 0>{});
-            mma_step(bcur + 3 * NB * LDS_LD, std::integral_constant<int, 1>{});
+            if (s0 + 5 < se) issue_a(s0 + 5, std::integral_constant<int, 1>{});
+            mma_step(bcur + 3 * NB * LDS_LD, std::integral_constant<int, 3>{});
         }
         if (more) store_b(Bs + (stage ^ 1) * BTILE);
         __syncthreads();

@@ -43,8 +43,12 @@ class PMVAETrainStep:
     """Fused train step over static device buffers (x, b, eps are copied/generated in place)."""
 
     def __init__(self, model: PosteriorMatchingVAE, config: Mapping[str, Any], optimizer: Chain, batch_size: int,
-                 x_shape, seed: int = 0, world_size: int = 1, rank: int = 0, use_graph: bool = True,
+                 x_shape, seed: int = 0, world_size: int = 1, rank: int = 0, use_graph: bool = False,
                  external_eps: bool = False):
+        """use_graph=False (default): eager launches, the ELBO and posterior-matching chains overlap on
+        two HIP streams.  use_graph=True: one HIP graph replay per step; ROCm 7.2 serialises the
+        branches of a captured graph, so this form runs the two chains back to back (measured:
+        65 k vs 80 k img/s) but costs no host time per kernel."""
         if model.store is None:
             model.init(x_shape)
         dev = model.store.device
@@ -64,6 +68,8 @@ class PMVAETrainStep:
         self.g_mll = torch.zeros(batch_size, device=dev)
         self.external_eps = external_eps
         self.use_graph = use_graph
+        if use_graph:
+            model.concurrent = False
         # HIP graph capture is not allowed on the NULL stream: the step owns a side stream
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))

@@ -131,12 +131,9 @@ class TriLGaussian(_LinearHead):
         return lp
 
     def backward_log_prob(self, g: torch.Tensor, dz: Optional[torch.Tensor]):
-        """dz (when given) is ACCUMULATED into; returns d/d(pre-activation) of the feeding network."""
+        """dz (when given) is WRITTEN with d log_prob / d z; returns d/d(pre-activation) of the feeding network."""
         dprm = self.buf("dparams", self._prm.shape)
-        dz_own = self.buf("dz_lp", self._z.shape) if dz is not None else None
-        ops.tril_logprob_bwd(self._prm, self._z, g, dprm, dz_own)
-        if dz is not None:
-            ops.axpy1(dz_own, dz)
+        ops.tril_logprob_bwd(self._prm, self._z, g, dprm, dz)
         return self._linear_bwd(dprm)
 
 
@@ -202,11 +199,12 @@ class AutoregressiveGMM(Module):
         return mll
 
     def backward_log_prob(self, g: torch.Tensor, dz: Optional[torch.Tensor]):
-        """dz (when given) is ACCUMULATED into; returns d/d(pre-activation) of the partial encoder."""
+        """dz (when given) is WRITTEN with d log_prob / d z (direct + through the scan inputs);
+        returns d/d(pre-activation) of the partial encoder."""
         B, k = self._z.shape
         nc, hu = self._num_components, self._hidden_units
         dhead = self.buf("dhead", self._head.shape)
-        ops.gmm_logprob_bwd(self._head, self._z, g, dhead, dz, nc, accumulate_dz=True)
+        ops.gmm_logprob_bwd(self._head, self._z, g, dhead, dz, nc, accumulate_dz=False)
         hf = self._hfeat
         ops.layer_wgrad(self.g_head, hf.t, dhead, self.G("gmm/linear/w"), self.G("gmm/linear/b"), in_act=hf.in_act,
                         **self._group_kw(B))

@@ -31,6 +31,7 @@ class PosteriorMatchingVAE(Module):
         self._matching_ll_stop_gradients = matching_ll_stop_gradients
         self._device = device
         self._seed = seed
+        self.concurrent = True   # run the ELBO and the posterior-matching chains on two HIP streams
         self.store: Optional[ParamStore] = None
         if not isinstance(posterior_dist, TriLGaussian):
             raise NotImplementedError("posterior_dist must be TriLGaussian (the only posterior head on the hot path)")
@@ -103,27 +104,52 @@ class PosteriorMatchingVAE(Module):
         if eps is None:
             raise ValueError("eps (the reparameterisation noise, [B, latent_dim]) must be given")
         self._xin, self._b = x, b
+        # The masked (partial) encoder does not depend on the encoder -> sample -> decoder chain:
+        # run it on a second HIP stream so that the two chains fill the chip together (most layers
+        # launch only 1-2 workgroups per CU).  Under graph capture this becomes a forked branch.
+        main, side = torch.cuda.current_stream(x.device), self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            xob = self.ws.get("x_o_b", tuple(x.shape[:-1]) + (x.shape[-1] + b.shape[-1],))
+            ops.mask_concat(x, b, xob)
+            pfeat = self.partial_encoder_net(Feat(xob), is_training=is_training)
         feat = self.encoder_net(Feat(x), is_training=is_training)
         z, kl = self.posterior_dist.sample_and_kl(feat, eps)
         dec = self.decoder_net(Feat(z), is_training=is_training)
         rec = self.decoder_dist.log_prob_sum(dec, x)
-        xob = self.ws.get("x_o_b", tuple(x.shape[:-1]) + (x.shape[-1] + b.shape[-1],))
-        ops.mask_concat(x, b, xob)
-        pfeat = self.partial_encoder_net(Feat(xob), is_training=is_training)
+        main.wait_stream(side)
         mll = self.partial_posterior_dist.log_prob(pfeat, z)
         self._z = z
         return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll}
 
+    def _side_stream(self, device) -> "torch.cuda.Stream":
+        if not self.concurrent:
+            return torch.cuda.current_stream(device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
     def backward(self, g_rec: torch.Tensor, g_kl: torch.Tensor, g_mll: torch.Tensor) -> None:
         """Accumulates d loss / d params into the flat gradient buffer given the per-example
         gradients of the loss w.r.t. the three outputs (zero the buffer first: `zero_grad`)."""
-        dpre = self.decoder_dist.backward(g_rec)
+        dev = g_rec.device
+        main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+        want_dz = not self._matching_ll_stop_gradients                      # vae.py:136-137
+        dz_pm = self.ws.get("dz_matching", self._z.shape) if want_dz else None
+        side.wait_stream(main)
+        with torch.cuda.stream(side):     # posterior-matching branch: AR-GMM / TriL head + partial encoder
+            dpenc = self.partial_posterior_dist.backward_log_prob(g_mll, dz_pm)
+            dz_ready = torch.cuda.Event()
+            dz_ready.record(side)
+            self.partial_encoder_net.backward(dpenc, need_input_grad=False)
+        dpre = self.decoder_dist.backward(g_rec)                            # ELBO branch on the main stream
         dz = self.decoder_net.backward(dpre, need_input_grad=True)
-        dz_acc = None if self._matching_ll_stop_gradients else dz          # vae.py:136-137
-        dpenc = self.partial_posterior_dist.backward_log_prob(g_mll, dz_acc)
-        self.partial_encoder_net.backward(dpenc, need_input_grad=False)
+        if want_dz:
+            main.wait_event(dz_ready)
+            ops.axpy1(dz_pm, dz)
         denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
         self.encoder_net.backward(denc, need_input_grad=False)
+        main.wait_stream(side)
 
     def zero_grad(self) -> None:
         ops.fill_zero(self.store.flat_g)
