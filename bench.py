@@ -58,6 +58,9 @@ def main():
                                                         "instead of eager launches on two overlapping streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events")
+    ap.add_argument("--f32", action="store_true", help="every GEMM on the f32 MFMA (strict-parity mode) instead of the "
+                                                      "default bf16x3 split on the bf16 matrix cores")
+    ap.add_argument("--serial", action="store_true", help="one stream (clean per-kernel durations for rocprofv3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
@@ -89,6 +92,8 @@ def main():
     cfg, xs, B = pm_vae_mnist(), (28, 28, 1), args.batch
     model = PosteriorMatchingVAE.from_config(cfg["model"], device=dev, seed=1)    # same init on every rank
     model.init(xs)
+    model.store.use_bf16 = not args.f32
+    model.concurrent = not args.serial
     opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg.get("weight_decay", 0.0)),
                       optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
     ts = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=world, rank=rank, use_graph=args.graph)
@@ -165,10 +170,13 @@ def main():
             "metric": "training images/sec, PM-VAE MNIST bs=256 per GPU (ELBO / PM matching-LL in `aux`)",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3" if model.store.use_bf16 else "f32", "data": "synthetic",
             "config": {"workload": "configs/pm_vae_mnist.py: conv PM-VAE 28x28x1, latent 32, TriL posterior, "
                                    "AR-GMM partial posterior, Bernoulli decoder; full train step (fwd+loss+bwd+Adam)",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "gemm_arithmetic": ("bf16x3: operands split hi+lo bf16, 3 bf16-MFMA products, f32 accumulate "
+                                           "(fwd/dgrad); f32 MFMA (wgrad)") if model.store.use_bf16 else "f32 MFMA",
                        "launch": "hip_graph_1stream" if args.graph else "eager_2streams", "params": model.num_params},
             "aux": {"elbo": round(metrics["reconstruction_ll"] - metrics["beta"] * metrics["kl"], 4),
                     "matching_ll": round(metrics["matching_ll"], 4), "kl": round(metrics["kl"], 4),

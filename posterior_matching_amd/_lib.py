@@ -55,6 +55,17 @@ class AdamCfg(C.Structure):
     ]
 
 
+class SplitJob(C.Structure):
+    """struct pm_split_job (include/pmhip.h)."""
+
+    _fields_ = [
+        ("src_off", C.c_longlong), ("dst_off", C.c_longlong), ("plane", C.c_longlong),
+        ("taps", C.c_int), ("C", C.c_int), ("N", C.c_int), ("npad", C.c_int),
+        ("wts", C.c_int), ("wcs", C.c_int), ("wns", C.c_int),
+        ("first_block", C.c_int), ("num_blocks", C.c_int),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _LL = C.c_longlong
@@ -64,6 +75,8 @@ _F = C.c_float
 SIGNATURES = {
     "pm_gather_gemm": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
     "pm_gather_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
+    "pm_gather_gemm_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
+    "pm_split_weights": [_P, _P, _P, _P, _I, _I],
     "pm_mask_concat": [_P, _P, _P, _P, _LL, _I, _I],
     "pm_tril_sample_kl_fwd": [_P, _P, _P, _P, _P, _I, _I],
     "pm_tril_sample_kl_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],

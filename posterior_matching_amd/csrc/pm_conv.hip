@@ -798,6 +798,319 @@ void launch_direct(hipStream_t s, const GemmArgs& a, dim3 grid) {
     }
 }
 
+// ------------------ forward / data-gradient, direct form on the bf16 matrix cores -------------
+// The f32 "MFMA" of gfx950 runs on the VALU pipeline (measured: 16 MFMAs + N v_fma take the SUM of
+// their times, on one wave or across waves), so it can never beat ~64 FLOP/clk/SIMD and every
+// address instruction is stolen from it.  The bf16 MFMA is a separate pipe, 16x faster.  To keep
+// float32-grade results each operand is split into two bf16 terms, x = hi + lo with
+// hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits kept), and three products are accumulated in
+// f32:  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  (the dropped a_lo*b_lo term is ~2^-18 |ab|).
+// Relative error of a dot product ~1e-5 instead of ~1e-7: far inside the 1e-3 parity bar.
+// Weights arrive pre-split and K-contiguous (pm_split_weights, once per optimizer step); the
+// gathered operand is split in registers right after its buffer load.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BROW = 40;  // LDS row of a weight stage: 32 bf16 (64 B) + 16 B pad, in 2-byte units -> 80 B
+
+// split 8 floats into packed bf16 hi and lo vectors (2 elements per dword)
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+    u32x4 hp, lp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = j < 2 ? x0[2 * j] : x1[2 * j - 4];
+        const float a1 = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+        const float f0 = __builtin_bit_cast(float, h << 16);
+        const float f1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        hp[j] = h;
+        lp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0 - f0, a1 - f1}, bf16x2));
+    }
+    hi = __builtin_bit_cast(bf16x8, hp);
+    lo = __builtin_bit_cast(bf16x8, lp);
+}
+
+struct KStepB {
+    int dy, dx;
+    int c0;
+    int woff;  // offset (in bf16 elements) of this step's [Npad][32] hi block inside the split weights
+};
+
+template <int RN, int DD, int IN_ACT>
+__global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit,
+                                                               int npad, long long plane) {
+    constexpr int NB = 32 * RN;
+    constexpr int STEP_E = 2 * NB * BROW;               // bf16 elements of one k-step in LDS (hi rows, lo rows)
+    constexpr int BTILE = DGS * STEP_E;                 // one stage
+    constexpr int TL_F = (sizeof(TapList) + 3) / 4;
+    constexpr int KD_F = DMAXSTEPS * (sizeof(KStepB) / 4);
+    __shared__ __attribute__((aligned(16))) float smem[BTILE + KD_F + TL_F];   // 2 stages of bf16 = BTILE floats
+    __bf16* Bs = reinterpret_cast<__bf16*>(smem);
+    KStepB* kd = reinterpret_cast<KStepB*>(smem + BTILE);
+    TapList* tl = reinterpret_cast<TapList*>(smem + BTILE + KD_F);
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int n0 = blockIdx.y * NB;
+    const int grp = blockIdx.z / p.ksplit;
+    const int ks = blockIdx.z - grp * p.ksplit;
+    const float* in = p.in + (size_t)grp * p.in_gs;
+
+    const int m = blockIdx.x * 128 + wave * 32 + i;
+    int rbase = 0, rpy = ROW_INVALID, rqx = ROW_INVALID, rowoff = -1;
+    if (m < g.M) {
+        int b, pp, q;
+        decode_row(g, m, b, pp, q);
+        rbase = b * g.IH * g.IW * g.C + 8 * h;
+        rpy = pp * g.a + g.off;
+        rqx = q * g.a + g.off;
+        rowoff = ((b * g.OH + pp) * g.OW + q) * g.N;
+    }
+    {
+        unsigned my = 0u, mx = 0u;
+        int s;
+        for (int t = 0; t < g.KH; ++t)
+            if (coord_ok<DD>(rpy + t * g.cs, g.d, g.IH, s)) my |= 1u << t;
+        for (int t = 0; t < g.KW; ++t)
+            if (coord_ok<DD>(rqx + t * g.cs, g.d, g.IW, s)) mx |= 1u << t;
+        build_tap_list(g, tl, my, mx, tid);
+    }
+    const int cchunks = g.C / BK;
+    const int nsteps_all = tl->nvy * tl->nvx * cchunks;
+    for (int s = tid; s < nsteps_all + DGS; s += 256) {
+        KStepB k{0, 0, 0, 0};
+        if (s < nsteps_all) {
+            int tj = s / cchunks;
+            int cc = s - tj * cchunks;
+            int jy = tj / tl->nvx;
+            int ky = tl->ky[jy], kx = tl->kx[tj - jy * tl->nvx];
+            k.dy = ky * g.cs;
+            k.dx = kx * g.cs;
+            k.c0 = cc * BK;
+            k.woff = ((ky * g.KW + kx) * cchunks + cc) * npad * BK;
+        }
+        kd[s] = k;
+    }
+    __syncthreads();
+    const int sb = (int)(((long long)nsteps_all * ks) / p.ksplit);
+    const int se = (int)(((long long)nsteps_all * (ks + 1)) / p.ksplit);
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in), 0, (int)((long long)g.B * g.IH * g.IW * g.C * 4), 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    // lane (r, h) needs channels c0 + 16*kk + 8h + 0..7 for the two k16 MFMA steps kk = 0, 1
+    f32x4 af[4][4];
+    auto issue_a = [&](int s, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        const KStepB k = kd[s];
+        int sy, sx;
+        const bool oky = coord_ok<DD>(rpy + k.dy, g.d, g.IH, sy);
+        const bool okx = coord_ok<DD>(rqx + k.dx, g.d, g.IW, sx);
+        const int off = (rbase + (sy * g.IW + sx) * g.C + k.c0) * 4;
+        const int voff = (int(oky) & int(okx)) ? off : OOB;
+#if defined(PM_EXP) && PM_EXP == 13
+        for (int u = 0; u < 4; ++u) af[SET][u] = f32x4{1.f, 2.f, float(voff), 4.f};
+#else
+        af[SET][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        af[SET][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16, 0));
+        af[SET][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 64, 0));
+        af[SET][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 80, 0));
+#endif
+    };
+
+    // weight stage: per k-step 2*NB rows (hi then lo) of 64 bytes; 16 bytes per thread per piece
+    constexpr int PIECES = 2 * NB * 4;            // 16-byte pieces per k-step
+    constexpr int PPT = (PIECES + 255) / 256;     // pieces per thread per k-step (1 for NB=32, 2 for NB=64)
+    const __bf16* wg = wsplit + (size_t)grp * p.w_gs;
+    u32x4 breg[DGS][PPT];
+    auto load_b = [&](int s0) {
+#pragma unroll
+        for (int st = 0; st < DGS; ++st) {
+            const int wo = kd[s0 + st].woff;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;          // piece id: plane, row, quarter
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                const int nrow = n0 + row < npad ? n0 + row : 0;
+                const __bf16* src = wg + (size_t)pl * plane + wo + nrow * BK + qtr * 8;
+                breg[st][j] = *reinterpret_cast<const u32x4*>(src);
+            }
+        }
+    };
+    auto store_b = [&](__bf16* dst) {
+#pragma unroll
+        for (int st = 0; st < DGS; ++st)
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                *reinterpret_cast<u32x4*>(dst + st * STEP_E + (pl * NB + row) * BROW + qtr * 8) = breg[st][j];
+            }
+    };
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    auto mma_step = [&](const __bf16* bstep, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        if constexpr (IN_ACT == PM_ACT_RELU) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) af[SET][u][e] = fmaxf(af[SET][u][e], 0.f);
+        } else if constexpr (IN_ACT == PM_ACT_LEAKY) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    af[SET][u][e] = af[SET][u][e] >= 0.f ? af[SET][u][e] : g.slope * af[SET][u][e];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ah, al;
+#if defined(PM_EXP) && PM_EXP == 15
+            ah = __builtin_bit_cast(bf16x8, af[SET][2 * kk]);
+            al = __builtin_bit_cast(bf16x8, af[SET][2 * kk + 1]);
+#else
+            split8(af[SET][2 * kk], af[SET][2 * kk + 1], ah, al);
+#endif
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                const __bf16* brow = bstep + (r * 32 + i) * BROW + 16 * kk + 8 * h;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(brow);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(brow + NB * BROW);
+#if defined(PM_EXP) && PM_EXP == 14
+                acc[r][0] += float(ah[0]) * float(bh[0]) + float(al[1]) * float(bl[1]);
+#else
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r], 0, 0, 0);
+#endif
+            }
+        }
+    };
+
+    if (sb < se) {
+        load_b(sb);
+        store_b(Bs);
+        issue_a(sb, std::integral_constant<int, 0>{});
+        if (sb + 1 < se) issue_a(sb + 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();
+    int stage = 0;
+    for (int s0 = sb; s0 < se; s0 += DGS) {
+        const __bf16* bcur = Bs + stage * BTILE;
+        const bool more = s0 + DGS < se;
+        if (more) load_b(s0 + DGS);
+        if (s0 + 2 < se) issue_a(s0 + 2, std::integral_constant<int, 2>{});
+        mma_step(bcur, std::integral_constant<int, 0>{});
+        if (s0 + 1 < se) {
+            if (s0 + 3 < se) issue_a(s0 + 3, std::integral_constant<int, 3>{});
+            mma_step(bcur + STEP_E, std::integral_constant<int, 1>{});
+        }
+        if (s0 + 2 < se) {
+            if (s0 + 4 < se) issue_a(s0 + 4, std::integral_constant<int, 0>{});
+            mma_step(bcur + 2 * STEP_E, std::integral_constant<int, 2>{});
+        }
+        if (s0 + 3 < se) {
+            if (s0 + 5 < se) issue_a(s0 + 5, std::integral_constant<int, 1>{});
+            mma_step(bcur + 3 * STEP_E, std::integral_constant<int, 3>{});
+        }
+        if (more) store_b(Bs + (stage ^ 1) * BTILE);
+        __syncthreads();
+        stage ^= 1;
+    }
+
+    const float* bias = p.bias ? p.bias + (size_t)grp * p.bias_gs : nullptr;
+    const float* aux = p.aux ? p.aux + (size_t)grp * p.out_gs : nullptr;
+    const float* res = p.res ? p.res + (size_t)grp * p.out_gs : nullptr;
+    float* out = p.out + (size_t)grp * p.out_gs;
+    int ro[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ro[e] = __shfl(rowoff, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
+#pragma unroll
+    for (int r = 0; r < RN; ++r) {
+        int n = n0 + r * 32 + i;
+        if (n >= g.N) continue;
+        float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (ro[e] < 0) continue;
+            size_t o = (size_t)ro[e] + n;
+            if (p.ksplit > 1) {
+                atomicAdd(out + o, acc[r][e]);
+                continue;
+            }
+            float v = acc[r][e] + bv;
+            if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
+            if (res) v += res[o];
+            out[o] = pm_act(v, g.out_act, g.slope);
+        }
+    }
+}
+
+template <int RN, int DD>
+void launch_direct_bf16(hipStream_t s, const GemmArgs& a, dim3 grid, const __bf16* ws, int npad, long long plane) {
+    switch (a.g.in_act) {
+        case PM_ACT_RELU:
+            hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, DD, PM_ACT_RELU>), grid, dim3(256), 0, s, a, ws, npad, plane);
+            break;
+        case PM_ACT_LEAKY:
+            hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, DD, PM_ACT_LEAKY>), grid, dim3(256), 0, s, a, ws, npad, plane);
+            break;
+        default:
+            hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, DD, PM_ACT_NONE>), grid, dim3(256), 0, s, a, ws, npad, plane);
+            break;
+    }
+}
+
+// Pre-split, K-contiguous copy of one layer's weights for one direction:
+//   dst[plane][tap][cchunk][n < npad][32]  with plane 0 = hi, 1 = lo,  value = w[tap*wts + c*wcs + n*wns]
+struct SplitJob {
+    long long src_off;   // element offset of the layer's weights in the flat f32 parameter buffer
+    long long dst_off;   // element offset of the job's output in the bf16 buffer
+    long long plane;     // elements between the hi and lo planes
+    int taps, C, N, npad;
+    int wts, wcs, wns;
+    int first_block, num_blocks;
+};
+
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ params, __bf16* __restrict__ out,
+                                                              const SplitJob* __restrict__ jobs, int njobs) {
+    // find the job of this block (jobs are few: linear scan)
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+    const SplitJob job = jobs[j];
+    const long long total = (long long)job.taps * (job.C / BK) * job.npad * BK;
+    const long long e = ((long long)blockIdx.x - job.first_block) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int k = (int)(e % BK);
+    const int n = (int)((e / BK) % job.npad);
+    const long long tc = e / ((long long)BK * job.npad);
+    const int cc = (int)(tc % (job.C / BK));
+    const int tap = (int)(tc / (job.C / BK));
+    float v = 0.f;
+    if (n < job.N)
+        v = params[job.src_off + (long long)tap * job.wts + (long long)(cc * BK + k) * job.wcs + (long long)n * job.wns];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    out[job.dst_off + e] = hi;
+    out[job.dst_off + job.plane + e] = lo;
+}
+
 // ------------------------------------ weight gradient ----------------------------------------
 // dw[kk][n] += sum_m G[m][kk] * D[m][n].  A workgroup owns a (32*RC) x (32*RN) block of dw and a
 // range of 128-row chunks of m; its 4 waves each take 32 rows of a chunk (MFMA k = 2 rows per
@@ -1217,4 +1530,51 @@ extern "C" int pm_query_wgrad_plan(const pm_gather_desc* d, int gathered_aligned
     *rc = p.rc; *rn = p.rn; *mode = p.mode; *dvec = p.dvec;
     *workgroups = p.nkb * p.nnb * p.splits * d->groups;
     return PM_OK;
+}
+
+// ---- bf16x3 ("split bf16") direct path ----
+extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
+                                   const float* bias, const float* aux, const float* res, float* out) {
+    GemmArgs a;
+    if (!fill_geom(d, a.g, true) || !in || !wsplit || !out) return PM_EINVAL;
+    if (d->C % BK != 0 || d->groups != 1 && d->w_gs % 8 != 0) return PM_EINVAL;
+    if (!aligned16(in) || !aligned16(wsplit) || (d->in_gs % 4) != 0) return PM_EINVAL;
+    if (a.g.KH * a.g.KW * (a.g.C / BK) > DMAXSTEPS || a.g.KH > 15 || a.g.KW > 15) return PM_EINVAL;
+    if ((long long)a.g.B * a.g.IH * a.g.IW * a.g.C * 4 >= 0x7ffffff0LL) return PM_EINVAL;
+    if (d->d != 1 && d->d != 2) return PM_EINVAL;
+    a.in = in; a.w = nullptr; a.bias = bias; a.aux = aux; a.res = res; a.out = out;
+    a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = d->groups;
+    const GemmPlan p = plan_gemm(a.g, G, true);
+    a.ksplit = p.ksplit;
+    if (p.ksplit > 1) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)a.g.M * a.g.N * sizeof(float), s);
+        if (e != hipSuccess) return pm_check_launch("pm_gather_gemm_bf16(memset)");
+    }
+    const int npad = (a.g.N + 31) / 32 * 32;
+    const long long plane = (long long)a.g.KH * a.g.KW * a.g.C * npad;
+    const int rn = a.g.N > 32 ? 2 : 1;
+    dim3 grid((a.g.M + 127) / 128, (a.g.N + 32 * rn - 1) / (32 * rn), G * a.ksplit);
+    const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
+    if (rn == 1 && d->d == 1) launch_direct_bf16<1, 1>(s, a, grid, ws, npad, plane);
+    else if (rn == 1) launch_direct_bf16<1, 2>(s, a, grid, ws, npad, plane);
+    else if (d->d == 1) launch_direct_bf16<2, 1>(s, a, grid, ws, npad, plane);
+    else launch_direct_bf16<2, 2>(s, a, grid, ws, npad, plane);
+    if (p.ksplit > 1) {
+        long long total = (long long)a.g.M * a.g.N;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks, G), dim3(256), 0, s, a, total);
+    }
+    return pm_check_launch("pm_gather_gemm_bf16");
+}
+
+extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* out_bf16, const pm_split_job* jobs_dev,
+                                int njobs, int total_blocks) {
+    if (!params || !out_bf16 || !jobs_dev || njobs <= 0 || total_blocks <= 0) return PM_EINVAL;
+    static_assert(sizeof(pm_split_job) == sizeof(SplitJob), "pm_split_job layout");
+    hipLaunchKernelGGL(split_weights_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, params,
+                       reinterpret_cast<__bf16*>(out_bf16), reinterpret_cast<const SplitJob*>(jobs_dev), njobs);
+    return pm_check_launch("pm_split_weights");
 }

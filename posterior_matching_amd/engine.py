@@ -90,6 +90,7 @@ class PMVAETrainStep:
     def _update(self) -> None:
         s = self.model.store
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        s.split_all()                      # refresh the pre-split bf16 weight copies (one launch)
         ops.counter_increment(self.step_dev)
 
     def _allreduce(self) -> None:

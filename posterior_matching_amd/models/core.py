@@ -45,6 +45,9 @@ class ParamStore:
         self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
         self.n_decay = 0
         self.device = None
+        self._split_requests = []      # (param name, LayerGeom, mode, groups, group kw)
+        self._split_views = []
+        self.use_bf16 = True           # bf16x3 matrix-core path for layers that qualify
 
     def add(self, name: str, shape, fan_in: int = 0) -> None:
         """fan_in > 0: haiku TruncatedNormal(stddev = 1/sqrt(fan_in)); 0: zeros."""
@@ -87,12 +90,69 @@ class ParamStore:
             self.p[name].copy_(torch.from_numpy(host[name]))
             off += n
         self.n_decay = sum(self.offsets[n][1] for n in decayed)
+        self._build_split_plan()
+        self.split_all()
+
+    # ---- pre-split bf16 weight copies for the bf16x3 matrix-core path (pm_split_weights) ----------
+    def request_split(self, param_name: str, geom, mode: str, **group_kw) -> int:
+        """Registers a K-contiguous hi/lo bf16 copy of `param_name` for `mode` ('fwd' | 'dgrad') of
+        `geom`; returns a handle for split_view().  Must be called before allocate()."""
+        self._split_requests.append((param_name, geom, mode, group_kw))
+        return len(self._split_requests) - 1
+
+    def split_view(self, handle: int):
+        if not self.use_bf16 or not self._split_views:
+            return None
+        return self._split_views[handle]
+
+    def _build_split_plan(self) -> None:
+        import ctypes as C
+
+        from .._lib import SplitJob
+
+        jobs, views, off, blk = [], [], 0, 0
+        for pname, geom, mode, kw in self._split_requests:
+            d = geom._desc(1, mode, **{k: v for k, v in kw.items() if k != "B"})
+            groups = d.groups
+            if d.C % 32 != 0:
+                views.append(None)
+                continue
+            npad = (d.N + 31) // 32 * 32
+            plane = d.KH * d.KW * d.C * npad
+            start = off
+            for gi in range(groups):
+                j = SplitJob()
+                j.src_off = self.offsets[pname][0] + gi * d.w_gs
+                j.dst_off, j.plane = off, plane
+                j.taps, j.C, j.N, j.npad = d.KH * d.KW, d.C, d.N, npad
+                j.wts, j.wcs, j.wns = d.wts, d.wcs, d.wns
+                j.first_block, j.num_blocks = blk, (plane + 255) // 256
+                blk += j.num_blocks
+                off += 2 * plane
+                jobs.append(j)
+            views.append((start, off))
+        self._split_total_blocks = blk
+        self._split_njobs = len(jobs)
+        if not jobs:
+            self._split_views = [None] * len(views)
+            return
+        self.split_buf = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        self._split_views = [None if v is None else self.split_buf[v[0]:v[1]] for v in views]
+        raw = bytes(bytearray(b"".join(bytes(j) for j in jobs)))
+        self._split_jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+
+    def split_all(self) -> None:
+        """Refreshes every pre-split copy from the current parameters: ONE launch (after each update)."""
+        if self.use_bf16 and getattr(self, "_split_njobs", 0):
+            ops.split_weights(self.flat_p, self.split_buf, self._split_jobs_dev, self._split_njobs,
+                              self._split_total_blocks)
 
     def load_dict(self, values: Dict[str, "np.ndarray | torch.Tensor"]) -> None:
         for name, val in values.items():
             t = torch.as_tensor(np.asarray(val.detach().cpu() if isinstance(val, torch.Tensor) else val),
                                 dtype=torch.float32)
             self.p[name].copy_(t.reshape(self.p[name].shape))
+        self.split_all()
 
     def to_dict(self, which: str = "p") -> Dict[str, torch.Tensor]:
         flat = {"p": self.flat_p, "g": self.flat_g, "m": self.flat_m, "v": self.flat_v}[which]

@@ -51,12 +51,15 @@ class _LinearHead(Module):
         self.geom = LayerGeom.dense(fin, out)
         store.add(f"{prefix}/linear/w", (fin, out), fan_in=fin)
         store.add(f"{prefix}/linear/b", (out,))
+        self._ws = (store.request_split(f"{prefix}/linear/w", self.geom, "fwd"),
+                    store.request_split(f"{prefix}/linear/w", self.geom, "dgrad"))
 
     def _linear_fwd(self, feat: Feat) -> torch.Tensor:
         self._feat = feat
         B = feat.t.shape[0]
         out = self.buf("params", (B, self.geom.CO))
-        ops.layer_forward(self.geom, feat.t, self.P("linear/w"), self.P("linear/b"), out, in_act=feat.in_act, B=B)
+        ops.layer_forward(self.geom, feat.t, self.P("linear/w"), self.P("linear/b"), out, in_act=feat.in_act, B=B,
+                          wsplit=self.store.split_view(self._ws[0]))
         return out
 
     def _linear_bwd(self, dparams: torch.Tensor) -> torch.Tensor:
@@ -65,7 +68,8 @@ class _LinearHead(Module):
         B = f.t.shape[0]
         ops.layer_wgrad(self.geom, f.t, dparams, self.G("linear/w"), self.G("linear/b"), in_act=f.in_act, B=B)
         dfeat = self.buf("dfeat", (B, self.geom.CI))
-        ops.layer_dgrad(self.geom, dparams, self.P("linear/w"), dfeat, aux=f.t, aux_act=f.grad_act, B=B)
+        ops.layer_dgrad(self.geom, dparams, self.P("linear/w"), dfeat, aux=f.t, aux_act=f.grad_act, B=B,
+                        wsplit=self.store.split_view(self._ws[1]))
         return dfeat.view(f.t.shape)
 
 
@@ -174,6 +178,9 @@ class AutoregressiveGMM(Module):
         store.add(f"{prefix}/gmm/linear/w", (hu, 3 * nc * k), fan_in=hu)
         store.add(f"{prefix}/gmm/linear/b", (3 * nc * k,))
         self.g_head = LayerGeom.dense(hu, 3 * nc)   # one group = one scan step's column slice
+        gk = dict(groups=k, w_gs=3 * nc, w_ld=3 * nc * k)
+        self._ws_head = (store.request_split(f"{prefix}/gmm/linear/w", self.g_head, "fwd", **gk),
+                         store.request_split(f"{prefix}/gmm/linear/w", self.g_head, "dgrad", **gk))
 
     def _group_kw(self, B):
         k, nc, hu = self._event_dim, self._num_components, self._hidden_units
@@ -192,7 +199,7 @@ class AutoregressiveGMM(Module):
         self._hfeat = hfeat
         head = self.buf("head", (k * B, 3 * nc))
         ops.layer_forward(self.g_head, hfeat.t, self.P("gmm/linear/w"), self.P("gmm/linear/b"), head,
-                          in_act=hfeat.in_act, **self._group_kw(B))
+                          in_act=hfeat.in_act, wsplit=self.store.split_view(self._ws_head[0]), **self._group_kw(B))
         self._head = head
         mll = self.buf("mll", (B,))
         ops.gmm_logprob_fwd(head, z, mll, nc)
@@ -210,7 +217,7 @@ class AutoregressiveGMM(Module):
                         **self._group_kw(B))
         dh = self.buf("dh_last", (k * B, hu))
         ops.layer_dgrad(self.g_head, dhead, self.P("gmm/linear/w"), dh, aux=hf.t, aux_act=hf.grad_act,
-                        **self._group_kw(B))
+                        wsplit=self.store.split_view(self._ws_head[1]), **self._group_kw(B))
         dinp = self.mlp.backward(dh, need_input_grad=True)
         dctx = self.buf("dctx", (B, self._ctx_dim))
         ops.argmm_input_bwd(dinp, dz, dctx, B, k, self._ctx_dim, accumulate_dz=True, ctx=self._feat.t,

@@ -28,12 +28,15 @@ class ConvEncoder(Module):
         self.attach(store, prefix)
         h, w, c = in_shape
         self.geoms: List[LayerGeom] = []
+        self._ws = []
         n = len(self._conv_layers)
         for i, (f, k, s) in enumerate(self._conv_layers):
             g = LayerGeom.conv(h, w, c, f, k, s, "VALID" if i == n - 1 else "SAME")
             store.add(f"{prefix}/conv_{i}/w", g.weight_shape, fan_in=k * k * c)
             store.add(f"{prefix}/conv_{i}/b", (f,))
             self.geoms.append(g)
+            self._ws.append((store.request_split(f"{prefix}/conv_{i}/w", g, "fwd"),
+                             store.request_split(f"{prefix}/conv_{i}/w", g, "dgrad")))
             h, w, c = g.OH, g.OW, f
         return (h, w, c)
 
@@ -45,7 +48,8 @@ class ConvEncoder(Module):
         h = x.t
         for i, g in enumerate(self.geoms):
             out = self.buf(f"out_{i}", (B, g.OH, g.OW, g.CO))
-            ops.layer_forward(g, h, self.P(f"conv_{i}/w"), self.P(f"conv_{i}/b"), out, out_act=ACT_LEAKY)
+            ops.layer_forward(g, h, self.P(f"conv_{i}/w"), self.P(f"conv_{i}/b"), out, out_act=ACT_LEAKY,
+                              wsplit=self.store.split_view(self._ws[i][0]))
             self._outs.append(out)
             h = out
         return Feat(h, ACT_NONE, ACT_LEAKY)
@@ -59,11 +63,13 @@ class ConvEncoder(Module):
             ops.layer_wgrad(g, inp, dpre, self.G(f"conv_{i}/w"), self.G(f"conv_{i}/b"))
             if i > 0:
                 dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
-                ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY)
+                ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY,
+                                wsplit=self.store.split_view(self._ws[i][1]))
                 dpre = dprev
             elif need_input_grad:
                 dprev = self.buf("dx", (B, g.IH, g.IW, g.CI))
-                ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=self._x.t, aux_act=self._x.grad_act)
+                ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=self._x.t, aux_act=self._x.grad_act,
+                                wsplit=self.store.split_view(self._ws[i][1]))
                 return dprev
         return None
 
@@ -82,11 +88,14 @@ class ConvDecoder(Module):
         self.attach(store, prefix)
         h, w, c = 1, 1, in_shape[0]
         self.geoms = []
+        self._ws = []
         for i, (f, k, s) in enumerate(self._conv_layers):
             g = LayerGeom.conv_t(h, w, c, f, k, s, "VALID" if i == 0 else "SAME")
             store.add(f"{prefix}/conv_t_{i}/w", g.weight_shape, fan_in=k * k * c)
             store.add(f"{prefix}/conv_t_{i}/b", (f,))
             self.geoms.append(g)
+            self._ws.append((store.request_split(f"{prefix}/conv_t_{i}/w", g, "fwd"),
+                             store.request_split(f"{prefix}/conv_t_{i}/w", g, "dgrad")))
             h, w, c = g.OH, g.OW, f
         return (h, w, c)
 
@@ -98,7 +107,8 @@ class ConvDecoder(Module):
         for i, g in enumerate(self.geoms):
             out = self.buf(f"out_{i}", (B, g.OH, g.OW, g.CO))
             ops.layer_forward(g, h, self.P(f"conv_t_{i}/w"), self.P(f"conv_t_{i}/b"), out,
-                              in_act=x.in_act if i == 0 else ACT_NONE, out_act=ACT_LEAKY)
+                              in_act=x.in_act if i == 0 else ACT_NONE, out_act=ACT_LEAKY,
+                              wsplit=self.store.split_view(self._ws[i][0]))
             self._outs.append(out)
             h = out
         return Feat(h, ACT_NONE, ACT_LEAKY)
@@ -112,11 +122,13 @@ class ConvDecoder(Module):
                             in_act=ACT_NONE if i > 0 else self._x.in_act)
             if i > 0:
                 dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
-                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY)
+                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY,
+                                wsplit=self.store.split_view(self._ws[i][1]))
                 dpre = dprev
             elif need_input_grad:
                 dz = self.buf("dz", (B, g.CI))
-                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dz, aux=self._x.t, aux_act=self._x.grad_act)
+                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dz, aux=self._x.t, aux_act=self._x.grad_act,
+                                wsplit=self.store.split_view(self._ws[i][1]))
                 return dz
         return None
 
@@ -150,25 +162,37 @@ class ResidualMLP(Module):
         self.g_hid = LayerGeom.dense(hu, hu)
         store.add(f"{prefix}/linear_0/w", (fin, hu), fan_in=fin)
         store.add(f"{prefix}/linear_0/b", (hu,))
+        self._ws = {"linear_0": (store.request_split(f"{prefix}/linear_0/w", self.g_in, "fwd"),
+                                 store.request_split(f"{prefix}/linear_0/w", self.g_in, "dgrad"))}
         for k in range(self._residual_blocks):
             for j in range(2):
                 store.add(f"{prefix}/block_{k}/linear_{j}/w", (hu, hu), fan_in=hu)
                 store.add(f"{prefix}/block_{k}/linear_{j}/b", (hu,))
+                self._ws[f"block_{k}/linear_{j}"] = (
+                    store.request_split(f"{prefix}/block_{k}/linear_{j}/w", self.g_hid, "fwd"),
+                    store.request_split(f"{prefix}/block_{k}/linear_{j}/w", self.g_hid, "dgrad"))
         return (hu,)
+
+    def _wsf(self, name):
+        return self.store.split_view(self._ws[name][0])
+
+    def _wsd(self, name):
+        return self.store.split_view(self._ws[name][1])
 
     def __call__(self, x: Feat, is_training: bool = False) -> Feat:
         rows, hu = x.t.shape[0], self._hidden_units
         self._x = x
         h = self.buf("h_0", (rows, hu))
-        ops.layer_forward(self.g_in, x.t, self.P("linear_0/w"), self.P("linear_0/b"), h, in_act=x.in_act)
+        ops.layer_forward(self.g_in, x.t, self.P("linear_0/w"), self.P("linear_0/b"), h, in_act=x.in_act,
+                          wsplit=self._wsf("linear_0"))
         self._h, self._u = [h], []
         for k in range(self._residual_blocks):
             u = self.buf(f"u_{k}", (rows, hu))
             ops.layer_forward(self.g_hid, h, self.P(f"block_{k}/linear_0/w"), self.P(f"block_{k}/linear_0/b"), u,
-                              in_act=ACT_RELU)
+                              in_act=ACT_RELU, wsplit=self._wsf(f"block_{k}/linear_0"))
             hn = self.buf(f"h_{k + 1}", (rows, hu))
             ops.layer_forward(self.g_hid, u, self.P(f"block_{k}/linear_1/w"), self.P(f"block_{k}/linear_1/b"), hn,
-                              in_act=ACT_RELU, res=h)
+                              in_act=ACT_RELU, res=h, wsplit=self._wsf(f"block_{k}/linear_1"))
             self._u.append(u)
             self._h.append(hn)
             h = hn
@@ -184,16 +208,19 @@ class ResidualMLP(Module):
             ops.layer_wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),
                             in_act=ACT_RELU)
             du = self.buf(f"du_{k}", (rows, hu))
-            ops.layer_dgrad(self.g_hid, dh, self.P(f"block_{k}/linear_1/w"), du, aux=u, aux_act=ACT_RELU)
+            ops.layer_dgrad(self.g_hid, dh, self.P(f"block_{k}/linear_1/w"), du, aux=u, aux_act=ACT_RELU,
+                            wsplit=self._wsd(f"block_{k}/linear_1"))
             ops.layer_wgrad(self.g_hid, h, du, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"),
                             in_act=ACT_RELU)
             dprev = self.buf(f"dh_{k}", (rows, hu))
-            ops.layer_dgrad(self.g_hid, du, self.P(f"block_{k}/linear_0/w"), dprev, aux=h, aux_act=ACT_RELU, res=dh)
+            ops.layer_dgrad(self.g_hid, du, self.P(f"block_{k}/linear_0/w"), dprev, aux=h, aux_act=ACT_RELU, res=dh,
+                            wsplit=self._wsd(f"block_{k}/linear_0"))
             dh = dprev
         ops.layer_wgrad(self.g_in, self._x.t, dh, self.G("linear_0/w"), self.G("linear_0/b"), in_act=self._x.in_act)
         if need_input_grad:
             dx = self.buf("dx", (rows, self.g_in.CI))
-            ops.layer_dgrad(self.g_in, dh, self.P("linear_0/w"), dx, aux=self._x.t, aux_act=self._x.grad_act)
+            ops.layer_dgrad(self.g_in, dh, self.P("linear_0/w"), dx, aux=self._x.t, aux_act=self._x.grad_act,
+                            wsplit=self._wsd("linear_0"))
             return dx
         return None
 

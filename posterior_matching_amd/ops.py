@@ -228,6 +228,20 @@ def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
           work=work)
 
 
+def bf16_supported(desc: GatherDesc) -> bool:
+    """pm_gather_gemm_bf16 preconditions (include/pmhip.h)."""
+    return desc.C % 32 == 0 and desc.d in (1, 2) and desc.KH * desc.KW * (desc.C // 32) <= 256
+
+
+def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None:
+    tag = work = None
+    if _timer is not None:
+        tag = f"direct_gemm_bf16_kernel<{2 if desc.N > 32 else 1},d{desc.d}>"
+        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
+    _call("pm_gather_gemm_bf16", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
+          _ptr(out), tag=tag, work=work)
+
+
 def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
     tag = work = None
     if _timer is not None:
@@ -239,18 +253,32 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
     _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
 
-def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE, res=None, **group_kw) -> None:
+def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE, res=None, wsplit=None,
+                  **group_kw) -> None:
+    """wsplit: this layer's pre-split bf16 weights for the forward direction (ParamStore.split_view);
+    when given and the shape qualifies the layer runs on the bf16 matrix cores (bf16x3)."""
     B = group_kw.pop("B", None) or x.shape[0]
     d = g._desc(B, "fwd", **group_kw)
     d.in_act, d.out_act = in_act, out_act
-    gather_gemm(d, x, w, b, None, res, out)
+    if wsplit is not None and bf16_supported(d):
+        if d.groups > 1:
+            d.w_gs = wsplit.numel() // d.groups
+        gather_gemm_bf16(d, x, wsplit, b, None, res, out)
+    else:
+        gather_gemm(d, x, w, b, None, res, out)
 
 
-def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, **group_kw) -> None:
+def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, wsplit=None, **group_kw) -> None:
     B = group_kw.pop("B", None) or dy.shape[0]
     d = g._desc(B, "dgrad", **group_kw)
     d.aux_act = aux_act if aux is not None else ACT_NONE
-    gather_gemm(d, dy, w, None, aux if aux_act != ACT_NONE else None, res, dx)
+    aux = aux if aux_act != ACT_NONE else None
+    if wsplit is not None and bf16_supported(d):
+        if d.groups > 1:
+            d.w_gs = wsplit.numel() // d.groups
+        gather_gemm_bf16(d, dy, wsplit, None, aux, res, dx)
+    else:
+        gather_gemm(d, dy, w, None, aux, res, dx)
 
 
 def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, **group_kw) -> None:
@@ -356,6 +384,10 @@ def counter_increment(count_dev) -> None:
 
 def normal_fill(out, seed: int, step_dev, stream_id: int = 0) -> None:
     _call("pm_normal_fill", _ptr(out), out.numel(), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
+
+
+def split_weights(flat_params, out_bf16, jobs_dev, njobs: int, total_blocks: int) -> None:
+    _call("pm_split_weights", _ptr(flat_params), out_bf16.data_ptr(), jobs_dev.data_ptr(), njobs, total_blocks)
 
 
 def fill_zero(t) -> None:

@@ -40,7 +40,14 @@ def main():
             y = torch.empty((B, g.OH, g.OW, g.CO), device=d)
             dw, db = torch.zeros_like(w), torch.zeros_like(b)
             if what.startswith("fwd"):
-                fn = lambda: ops.layer_forward(g, x, w, b, y, out_act=ACT_LEAKY)
+                from posterior_matching_amd.models.core import ParamStore
+                st = ParamStore()
+                st.add("w", g.weight_shape, fan_in=1)
+                hf = st.request_split("w", g, "fwd")
+                st.allocate(d)
+                st.load_dict({"w": w.cpu()})
+                ws = st.split_view(hf) if os.environ.get("PM_BF16", "1") == "1" else None
+                fn = lambda: ops.layer_forward(g, x, w, b, y, out_act=ACT_LEAKY, wsplit=ws)
             else:
                 y.normal_()
                 fn = lambda: ops.layer_wgrad(g, x, y, dw, db)
