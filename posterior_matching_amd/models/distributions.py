@@ -66,7 +66,7 @@ class _LinearHead(Module):
         """returns the gradient w.r.t. the feeding network's last pre-activation."""
         f = self._feat
         B = f.t.shape[0]
-        ops.layer_wgrad(self.geom, f.t, dparams, self.G("linear/w"), self.G("linear/b"), in_act=f.in_act, B=B)
+        self.wgrad(self.geom, f.t, dparams, self.G("linear/w"), self.G("linear/b"), in_act=f.in_act, B=B)
         dfeat = self.buf("dfeat", (B, self.geom.CI))
         ops.layer_dgrad(self.geom, dparams, self.P("linear/w"), dfeat, aux=f.t, aux_act=f.grad_act, B=B,
                         wsplit=self.store.split_view(self._ws[1]))
@@ -213,7 +213,7 @@ class AutoregressiveGMM(Module):
         dhead = self.buf("dhead", self._head.shape)
         ops.gmm_logprob_bwd(self._head, self._z, g, dhead, dz, nc, accumulate_dz=False)
         hf = self._hfeat
-        ops.layer_wgrad(self.g_head, hf.t, dhead, self.G("gmm/linear/w"), self.G("gmm/linear/b"), in_act=hf.in_act,
+        self.wgrad(self.g_head, hf.t, dhead, self.G("gmm/linear/w"), self.G("gmm/linear/b"), in_act=hf.in_act,
                         **self._group_kw(B))
         dh = self.buf("dh_last", (k * B, hu))
         ops.layer_dgrad(self.g_head, dhead, self.P("gmm/linear/w"), dh, aux=hf.t, aux_act=hf.grad_act,

@@ -60,7 +60,7 @@ class ConvEncoder(Module):
         for i in reversed(range(len(self.geoms))):
             g = self.geoms[i]
             inp = self._outs[i - 1] if i > 0 else self._x.t
-            ops.layer_wgrad(g, inp, dpre, self.G(f"conv_{i}/w"), self.G(f"conv_{i}/b"))
+            self.wgrad(g, inp, dpre, self.G(f"conv_{i}/w"), self.G(f"conv_{i}/b"))
             if i > 0:
                 dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
                 ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY,
@@ -118,7 +118,7 @@ class ConvDecoder(Module):
         for i in reversed(range(len(self.geoms))):
             g = self.geoms[i]
             inp = self._outs[i - 1] if i > 0 else self._x.t
-            ops.layer_wgrad(g, inp, dpre, self.G(f"conv_t_{i}/w"), self.G(f"conv_t_{i}/b"),
+            self.wgrad(g, inp, dpre, self.G(f"conv_t_{i}/w"), self.G(f"conv_t_{i}/b"),
                             in_act=ACT_NONE if i > 0 else self._x.in_act)
             if i > 0:
                 dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
@@ -205,18 +205,18 @@ class ResidualMLP(Module):
         rows, hu = dh.shape[0], self._hidden_units
         for k in reversed(range(self._residual_blocks)):
             h, u = self._h[k], self._u[k]
-            ops.layer_wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),
+            self.wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),
                             in_act=ACT_RELU)
             du = self.buf(f"du_{k}", (rows, hu))
             ops.layer_dgrad(self.g_hid, dh, self.P(f"block_{k}/linear_1/w"), du, aux=u, aux_act=ACT_RELU,
                             wsplit=self._wsd(f"block_{k}/linear_1"))
-            ops.layer_wgrad(self.g_hid, h, du, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"),
+            self.wgrad(self.g_hid, h, du, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"),
                             in_act=ACT_RELU)
             dprev = self.buf(f"dh_{k}", (rows, hu))
             ops.layer_dgrad(self.g_hid, du, self.P(f"block_{k}/linear_0/w"), dprev, aux=h, aux_act=ACT_RELU, res=dh,
                             wsplit=self._wsd(f"block_{k}/linear_0"))
             dh = dprev
-        ops.layer_wgrad(self.g_in, self._x.t, dh, self.G("linear_0/w"), self.G("linear_0/b"), in_act=self._x.in_act)
+        self.wgrad(self.g_in, self._x.t, dh, self.G("linear_0/w"), self.G("linear_0/b"), in_act=self._x.in_act)
         if need_input_grad:
             dx = self.buf("dx", (rows, self.g_in.CI))
             ops.layer_dgrad(self.g_in, dh, self.P("linear_0/w"), dx, aux=self._x.t, aux_act=self._x.grad_act,

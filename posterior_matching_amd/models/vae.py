@@ -142,6 +142,7 @@ class PosteriorMatchingVAE(Module):
             dz_ready = torch.cuda.Event()
             dz_ready.record(side)
             self.partial_encoder_net.backward(dpenc, need_input_grad=False)
+            self.ws.join_aux()
         dpre = self.decoder_dist.backward(g_rec)                            # ELBO branch on the main stream
         dz = self.decoder_net.backward(dpre, need_input_grad=True)
         if want_dz:
@@ -149,6 +150,7 @@ class PosteriorMatchingVAE(Module):
             ops.axpy1(dz_pm, dz)
         denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
         self.encoder_net.backward(denc, need_input_grad=False)
+        self.ws.join_aux()
         main.wait_stream(side)
 
     def zero_grad(self) -> None:
