@@ -1537,7 +1537,7 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
                                    const float* bias, const float* aux, const float* res, float* out) {
     GemmArgs a;
     if (!fill_geom(d, a.g, true) || !in || !wsplit || !out) return PM_EINVAL;
-    if (d->C % BK != 0 || d->groups != 1 && d->w_gs % 8 != 0) return PM_EINVAL;
+    if (d->C % BK != 0 || (d->groups != 1 && d->w_gs % 8 != 0)) return PM_EINVAL;
     if (!aligned16(in) || !aligned16(wsplit) || (d->in_gs % 4) != 0) return PM_EINVAL;
     if (a.g.KH * a.g.KW * (a.g.C / BK) > DMAXSTEPS || a.g.KH > 15 || a.g.KW > 15) return PM_EINVAL;
     if ((long long)a.g.B * a.g.IH * a.g.IW * a.g.C * 4 >= 0x7ffffff0LL) return PM_EINVAL;

@@ -106,9 +106,10 @@ class ConvDecoder(Module):
         h = x.t
         for i, g in enumerate(self.geoms):
             out = self.buf(f"out_{i}", (B, g.OH, g.OW, g.CO))
+            tmp = self.buf(f"taps_{i}", (B, g.IH, g.IW, g.k * g.k)) if (g.CO == 1 and g.s == 1 and i > 0) else None
             ops.layer_forward(g, h, self.P(f"conv_t_{i}/w"), self.P(f"conv_t_{i}/b"), out,
                               in_act=x.in_act if i == 0 else ACT_NONE, out_act=ACT_LEAKY,
-                              wsplit=self.store.split_view(self._ws[i][0]))
+                              wsplit=self.store.split_view(self._ws[i][0]), tmp=tmp)
             self._outs.append(out)
             h = out
         return Feat(h, ACT_NONE, ACT_LEAKY)

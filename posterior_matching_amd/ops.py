@@ -253,13 +253,35 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
     _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
 
+def _thin_ok(d: GatherDesc) -> bool:
+    return d.groups == 1 and d.d == 1 and d.KH * d.KW * d.C <= 64 and d.N <= 32 and d.N % 8 == 0
+
+
+def thin_conv(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
+    work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
+    _call("pm_thin_conv", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), work=work)
+
+
 def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE, res=None, wsplit=None,
-                  **group_kw) -> None:
+                  tmp=None, **group_kw) -> None:
     """wsplit: this layer's pre-split bf16 weights for the forward direction (ParamStore.split_view);
-    when given and the shape qualifies the layer runs on the bf16 matrix cores (bf16x3)."""
+    when given and the shape qualifies the layer runs on the bf16 matrix cores (bf16x3).
+    tmp: [B, IH, IW, k*k] scratch for a wide -> 1-channel transposed conv (per-tap dot products)."""
     B = group_kw.pop("B", None) or x.shape[0]
     d = g._desc(B, "fwd", **group_kw)
     d.in_act, d.out_act = in_act, out_act
+    if g.kind == "convT" and g.CO == 1 and g.s == 1 and tmp is not None and res is None and in_act == ACT_NONE:
+        # out[p] = sum_tap (x[p + tap] . w[tap]):  T = x @ W' (one GEMM, N = taps) then a shifted sum
+        taps = g.k * g.k
+        dt = LayerGeom.dense(g.CI, taps)._desc(B * g.IH * g.IW, "fwd")
+        dt.wts, dt.wcs, dt.wns = 0, 1, g.CI               # W'[c][tap] = w[tap, 0, c]
+        gather_gemm(dt, x, w, None, None, None, tmp)
+        work = {"bytes": _nbytes(tmp, out), "detail": _detail(d)}
+        _call("pm_tap_shift_add", C.byref(d), _ptr(tmp), taps, _ptr(b), _ptr(out), work=work)
+        return
+    if _thin_ok(d):
+        thin_conv(d, x, w, b, None, res, out)
+        return
     if wsplit is not None and bf16_supported(d):
         if d.groups > 1:
             d.w_gs = wsplit.numel() // d.groups
@@ -273,6 +295,9 @@ def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, w
     d = g._desc(B, "dgrad", **group_kw)
     d.aux_act = aux_act if aux is not None else ACT_NONE
     aux = aux if aux_act != ACT_NONE else None
+    if _thin_ok(d):
+        thin_conv(d, dy, w, None, aux, res, dx)
+        return
     if wsplit is not None and bf16_supported(d):
         if d.groups > 1:
             d.w_gs = wsplit.numel() // d.groups
