@@ -1430,10 +1430,14 @@ WgradPlan plan_wgrad(const Geom& g, int groups, bool vec4, bool dvec4) {
     p.nkb = (g.K + 32 * p.rc - 1) / (32 * p.rc);
     p.nnb = (g.N + 32 * p.rn - 1) / (32 * p.rn);
     const int total_chunks = (g.M + 127) / 128;
+    // m-splits: enough workgroups to fill the chip (~4 per CU), but every workgroup should walk
+    // several 128-row chunks - its LDS reduction and atomics are a fixed cost per workgroup
     long long blocks = (long long)p.nkb * p.nnb * groups;
     int splits = (int)((1024 + blocks - 1) / blocks);
+    int max_splits = total_chunks / 4;
+    if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    if (splits > total_chunks) splits = total_chunks;
     p.chunks_per_split = (total_chunks + splits - 1) / splits;
     p.splits = (total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     return p;
