@@ -236,7 +236,7 @@ def bf16_supported(desc: GatherDesc) -> bool:
 def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None:
     tag = work = None
     if _timer is not None:
-        tag = f"direct_gemm_bf16_kernel<{2 if desc.N > 32 else 1},d{desc.d}>"
+        tag = f"direct_gemm_bf16_kernel<{2 if desc.N > 32 else 1}, {desc.d}, {desc.in_act}>"   # template args
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
     _call("pm_gather_gemm_bf16", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
           _ptr(out), tag=tag, work=work)
