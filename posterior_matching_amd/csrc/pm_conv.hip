@@ -108,6 +108,22 @@ struct TapList {  // lives in LDS: the taps a tile iterates, as a product of a k
     unsigned masky, maskx;
 };
 
+// hi/lo bf16 split of a float4 -> two packed 8-byte values
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float a0 = x[2 * j], a1 = x[2 * j + 1];
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a0, a1}, bf16x2_t));
+        const float f0 = __builtin_bit_cast(float, h << 16);
+        const float f1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        hi[j] = h;
+        lo[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a0 - f0, a1 - f1}, bf16x2_t));
+    }
+}
+
 // ---- gathered-operand tile loaders: tile[row][k], rows = output positions, k = (tap, channel) ----
 template <int BM, int BKT, int DD>
 struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
@@ -236,6 +252,24 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) *reinterpret_cast<f32x4*>(tile + (r0 + j * RPP) * ld + slot4) = regs[j];
+    }
+    // same, but the tile is written as two bf16 planes (hi, lo) with row stride ld elements
+    __device__ __forceinline__ void store_split(const Geom& g, short* hi, short* lo, int ld) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const bool ok = (okmask >> j) & 1u;
+            f32x4 v = regs[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = ok ? v[e] : 0.f;
+                if (g.in_act == PM_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                else if (g.in_act == PM_ACT_LEAKY) v[e] = v[e] >= 0.f ? v[e] : g.slope * v[e];
+            }
+            u32x2 h2, l2;
+            split4(v, h2, l2);
+            *reinterpret_cast<u32x2*>(hi + (r0 + j * RPP) * ld + slot4) = h2;
+            *reinterpret_cast<u32x2*>(lo + (r0 + j * RPP) * ld + slot4) = l2;
+        }
     }
 };
 
@@ -1310,6 +1344,211 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
     }
 }
 
+// ----------------------- weight gradient on the bf16 matrix cores (bf16x3) ---------------------
+// Same decomposition as gather_wgrad_kernel, but the two 128-row tiles are converted ONCE at
+// staging time into hi / lo bf16 planes and every MFMA operand is a transposed LDS read
+// (ds_read_b64_tr_b16: 4 rows x 16 columns delivered column-major), because both operands of
+// dw = G^T D run along the reduction axis m, which is the slow axis of the NHWC tiles.
+//   A[c][k = m] = G[m][c]   B[k = m][n] = D[m][n]   dw[c][n] += A_hi B_hi + A_hi B_lo + A_lo B_hi
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const short* base0, int row_stride_elems) {
+    // two transposed reads: rows +0..3 and +4..7 of this lane group's 8-row slab
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base0 + 4 * row_stride_elems));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int RC, int RN, int DD>
+__global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
+    constexpr int CB = 32 * RC;
+    constexpr int NB = 32 * RN;
+    constexpr int BMC = 128;
+    constexpr int GS = CB + 8;   // bf16 elements per LDS row (16 B pad)
+    constexpr int DS = NB + 8;
+    constexpr int TILE_S = 2 * BMC * (GS + DS);          // shorts: hi+lo planes of both tiles
+    constexpr int RED_F = 4 * CB * NB;                   // floats of the cross-wave reduction
+    constexpr int SMEM_F = (TILE_S / 2 > RED_F) ? TILE_S / 2 : RED_F;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
+    short* Gh = reinterpret_cast<short*>(smem);
+    short* Gl = Gh + BMC * GS;
+    short* Dh = Gl + BMC * GS;
+    short* Dl = Dh + BMC * DS;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int nkb = (g.K + CB - 1) / CB;
+    const int kkb = blockIdx.x % nkb;
+    const int nb = blockIdx.x / nkb;
+    const int kk0 = kkb * CB;
+    const int n0 = nb * NB;
+    const int grp = blockIdx.z;
+    const float* gin = p.gathered + (size_t)grp * p.in_gs;
+    const float* din = p.dense + (size_t)grp * p.out_gs;
+    const bool do_bias = (p.db != nullptr) && (kkb == 0);
+    const int tap_u = kk0 / g.C;
+    const int c_u = kk0 - tap_u * g.C;
+    const int ky_u = tap_u / g.KW;
+    const int kx_u = tap_u - ky_u * g.KW;
+
+    const int total_chunks = (g.M + BMC - 1) / BMC;
+    const int c_begin = blockIdx.y * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    LoaderV4<BMC, CB, DD> lg;
+    lg.init(tid);
+
+    constexpr int DSLOTS = NB / 4;
+    constexpr int DRPP = 256 / DSLOTS;
+    constexpr int DNP = BMC / DRPP;
+    const int dslot = tid % DSLOTS;
+    const int dr0 = tid / DSLOTS;
+    const int dn = n0 + dslot * 4;
+    const bool dn_ok = dn < g.N;
+    f32x4 dreg[DNP];
+    unsigned dmask = 0u;
+    auto load_d = [&](int m0) {
+        dmask = 0u;
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            int m = m0 + dr0 + j * DRPP;
+            const bool ok = m < g.M && dn_ok;
+            const size_t o = ok ? (size_t)m * g.N + dn : 0;
+            dmask |= (ok ? 1u : 0u) << j;
+            dreg[j] = *reinterpret_cast<const f32x4*>(din + o);
+        }
+    };
+    auto store_d = [&]() {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            const bool ok = (dmask >> j) & 1u;
+            f32x4 v = dreg[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            u32x2 h2, l2;
+            split4(v, h2, l2);
+            *reinterpret_cast<u32x2*>(Dh + (dr0 + j * DRPP) * DS + dslot * 4) = h2;
+            *reinterpret_cast<u32x2*>(Dl + (dr0 + j * DRPP) * DS + dslot * 4) = l2;
+        }
+    };
+
+    f32x16 acc[RC][RN];
+    f32x16 accb[RN];
+#pragma unroll
+    for (int a = 0; a < RC; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < RN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[b][e] = 0.f;
+
+    // transposed-read lane geometry: 16-lane group gq reads rows +q, columns 16*(gq&1) + 4*pq
+    const int gq = lane >> 4;
+    const int q = (lane & 15) >> 2;
+    const int pq = lane & 3;
+    const int tr_row = 8 * (gq >> 1) + q;          // + 16*ks + 32*wave
+    const int tr_col = 16 * (gq & 1) + 4 * pq;     // + 32*block
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    if (c_begin < c_end) {
+        lg.set_rows(g, c_begin * BMC);
+        lg.load_tap(g, gin, ky_u, kx_u, c_u, true);
+        load_d(c_begin * BMC);
+    }
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        lg.store_split(g, Gh, Gl, GS);
+        store_d();
+        __syncthreads();
+        if (ch + 1 < c_end) {
+            lg.advance_rows(g, (ch + 1) * BMC, p.step_b, p.step_p, p.step_q);
+            lg.load_tap(g, gin, ky_u, kx_u, c_u, true);
+            load_d((ch + 1) * BMC);
+        }
+        auto mma = [&](auto with_bias) {
+#pragma unroll
+            for (int ksx = 0; ksx < 2; ++ksx) {
+                const int row = wave * 32 + 16 * ksx + tr_row;
+                bf16x8 ah[RC], al[RC], bh[RN], bl[RN];
+#pragma unroll
+                for (int a = 0; a < RC; ++a) {
+                    ah[a] = tr_frag(Gh + row * GS + 32 * a + tr_col, GS);
+                    al[a] = tr_frag(Gl + row * GS + 32 * a + tr_col, GS);
+                }
+#pragma unroll
+                for (int b = 0; b < RN; ++b) {
+                    bh[b] = tr_frag(Dh + row * DS + 32 * b + tr_col, DS);
+                    bl[b] = tr_frag(Dl + row * DS + 32 * b + tr_col, DS);
+                }
+#pragma unroll
+                for (int a = 0; a < RC; ++a)
+#pragma unroll
+                    for (int b = 0; b < RN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+                if constexpr (decltype(with_bias)::value) {
+#pragma unroll
+                    for (int b = 0; b < RN; ++b) {
+                        accb[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bh[b], accb[b], 0, 0, 0);
+                        accb[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bl[b], accb[b], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        if (do_bias) mma(std::true_type{});
+        else mma(std::false_type{});
+        __syncthreads();
+    }
+
+    float* red = smem;
+#pragma unroll
+    for (int a = 0; a < RC; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int cl = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                int nl = b * 32 + i;
+                red[wave * CB * NB + cl * NB + nl] = acc[a][b][e];
+            }
+    __syncthreads();
+    float* dw = p.dw + (size_t)grp * p.w_gs;
+    for (int e = tid; e < CB * NB; e += 256) {
+        int cl = e / NB;
+        int nl = e - cl * NB;
+        int kk = kk0 + cl;
+        int n = n0 + nl;
+        if (kk < g.K && n < g.N) {
+            float s = red[e] + red[CB * NB + e] + red[2 * CB * NB + e] + red[3 * CB * NB + e];
+            int tap = kk / g.C;
+            int c = kk - tap * g.C;
+            atomicAdd(dw + (size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
+        }
+    }
+    if (do_bias && h == 0) {
+        float* db = p.db + (size_t)grp * p.bias_gs;
+#pragma unroll
+        for (int b = 0; b < RN; ++b) {
+            int n = n0 + b * 32 + i;
+            if (n < g.N) atomicAdd(db + n, accb[b][0]);
+        }
+    }
+}
+
 bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     if (!d || d->B <= 0 || d->C <= 0 || d->N <= 0 || d->KH <= 0 || d->KW <= 0 || d->d <= 0 || d->groups <= 0)
         return false;
@@ -1581,4 +1820,34 @@ extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* o
     hipLaunchKernelGGL(split_weights_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, params,
                        reinterpret_cast<__bf16*>(out_bf16), reinterpret_cast<const SplitJob*>(jobs_dev), njobs);
     return pm_check_launch("pm_split_weights");
+}
+
+extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d, const float* gathered,
+                                    const float* dense, float* dw, float* db) {
+    WgradArgs a;
+    if (!fill_geom(d, a.g, false) || !gathered || !dense || !dw) return PM_EINVAL;
+    if (d->C % 32 != 0 || d->N % 4 != 0 || (d->d != 1 && d->d != 2)) return PM_EINVAL;
+    if (!aligned16(gathered) || !aligned16(dense) || d->in_gs % 4 != 0 || d->out_gs % 4 != 0) return PM_EINVAL;
+    a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db;
+    a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    const WgradPlan p = plan_wgrad(a.g, d->groups, true, true);
+    a.chunks_per_split = p.chunks_per_split;
+    const int hw = a.g.OH * a.g.OW;
+    a.step_b = 128 / hw;
+    a.step_p = (128 - a.step_b * hw) / a.g.OW;
+    a.step_q = 128 - a.step_b * hw - a.step_p * a.g.OW;
+    dim3 grid(p.nkb * p.nnb, p.splits, d->groups);
+    hipStream_t s = (hipStream_t)stream;
+    const int dd = d->d;
+#define PM_WB(RCv, RNv)                                                                                            \
+    do {                                                                                                            \
+        if (dd == 1) hipLaunchKernelGGL((gather_wgrad_bf16_kernel<RCv, RNv, 1>), grid, dim3(256), 0, s, a);         \
+        else hipLaunchKernelGGL((gather_wgrad_bf16_kernel<RCv, RNv, 2>), grid, dim3(256), 0, s, a);                 \
+    } while (0)
+    if (p.rc == 2 && p.rn == 2) PM_WB(2, 2);
+    else if (p.rc == 2) PM_WB(2, 1);
+    else if (p.rn == 2) PM_WB(1, 2);
+    else PM_WB(1, 1);
+#undef PM_WB
+    return pm_check_launch("pm_gather_wgrad_bf16");
 }

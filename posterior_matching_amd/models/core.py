@@ -224,6 +224,7 @@ class Module:
         enqueued so far on the current stream)."""
         cur = torch.cuda.current_stream(self.ws.device)
         aux = self.ws.aux_stream()
+        kw.setdefault("bf16", self.store.use_bf16)
         if aux is cur:
             ops.layer_wgrad(*args, **kw)
             return

@@ -242,7 +242,18 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None
           _ptr(out), tag=tag, work=work)
 
 
-def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db) -> None:
+USE_BF16_WGRAD = True   # weight gradients on the bf16 matrix cores when the shape qualifies
+
+
+def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False) -> None:
+    if (bf16 and USE_BF16_WGRAD and desc.C % 32 == 0 and desc.N % 4 == 0 and desc.d in (1, 2)
+            and gathered.data_ptr() % 16 == 0 and dense.data_ptr() % 16 == 0):
+        tag = work = None
+        if _timer is not None:
+            tag = f"gather_wgrad_bf16_kernel<{2 if desc.C % 64 == 0 and desc.KH * desc.KW * desc.C >= 64 else 1}, {2 if desc.N > 32 else 1}, {desc.d}>"
+            work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
+        _call("pm_gather_wgrad_bf16", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
+        return
     tag = work = None
     if _timer is not None:
         v = [C.c_int() for _ in range(5)]
@@ -306,13 +317,13 @@ def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, w
         gather_gemm(d, dy, w, None, aux, res, dx)
 
 
-def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, **group_kw) -> None:
+def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, bf16: bool = True, **group_kw) -> None:
     B = group_kw.pop("B", None) or x.shape[0]
     d = g._desc(B, "wgrad", **group_kw)
     d.in_act = in_act
     if g.kind != "convT":
         # dw[ky,kx,ci,co] = sum_{b,p,q} x[b, p*s+ky-pad, q*s+kx-pad, ci] * dy[b,p,q,co]
-        gather_wgrad(d, x, dy, dw, db)
+        gather_wgrad(d, x, dy, dw, db, bf16=bf16)
         return
     # Transposed conv: dw[ky,kx,co,ci] = sum_{b,oy,ox} dy[b,oy,ox,co] * xdil[b,oy+ky-pa,ox+kx-pa,ci].
     # Walking the OUTPUT grid multiplies the zeros of the dilated x (3 of 4 rows at stride 2, 48 of
@@ -322,7 +333,7 @@ def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, **group_kw) -> Non
     if in_act != ACT_NONE:
         raise NotImplementedError("transposed-conv weight gradient with a pending input activation")
     d = g._desc(B, "dgrad", **group_kw)
-    gather_wgrad(d, dy, x, dw, None)
+    gather_wgrad(d, dy, x, dw, None, bf16=bf16)
     if db is not None:
         colsum(dy, db)
 

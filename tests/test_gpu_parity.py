@@ -101,9 +101,13 @@ def test_layer_fwd_dgrad_wgrad(kind, B, H, ci, co, k, s, padding):
         ops.layer_dgrad(geom, dpre, wd, dx2, wsplit=st.split_view(hd))
         assert rel_err(dx2, xr.grad) < 3e-5
     dwd, dbd = torch.zeros_like(wd), torch.zeros_like(bd)
-    ops.layer_wgrad(geom, xd, dpre, dwd, dbd)
+    ops.layer_wgrad(geom, xd, dpre, dwd, dbd, bf16=False)          # f32 MFMA
     assert rel_err(dwd, wr.grad) < 2e-6
     assert rel_err(dbd, br.grad) < 1e-5
+    dwd.zero_(); dbd.zero_()
+    ops.layer_wgrad(geom, xd, dpre, dwd, dbd, bf16=True)           # bf16x3 where the shape qualifies
+    assert rel_err(dwd, wr.grad) < 3e-5
+    assert rel_err(dbd, br.grad) < 3e-5
 
 
 def test_epilogue_aux_res_inact():
