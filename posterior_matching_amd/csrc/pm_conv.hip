@@ -872,7 +872,8 @@ struct KStepB {
     int woff;  // offset (in bf16 elements) of this step's [Npad][32] hi block inside the split weights
 };
 
-template <int RN, int DD, int IN_ACT>
+// DENSE: 1x1 problem on a 1x1 grid (hk.Linear): no taps, no coordinates - rows are plain matrix rows.
+template <int RN, int DD, int IN_ACT, bool DENSE>
 __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit,
                                                                int npad, long long plane) {
     constexpr int NB = 32 * RN;
@@ -898,15 +899,24 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
 
     const int m = blockIdx.x * 128 + wave * 32 + i;
     int rbase = 0, rpy = ROW_INVALID, rqx = ROW_INVALID, rowoff = -1;
-    if (m < g.M) {
-        int b, pp, q;
-        decode_row(g, m, b, pp, q);
-        rbase = b * g.IH * g.IW * g.C + 8 * h;
-        rpy = pp * g.a + g.off;
-        rqx = q * g.a + g.off;
-        rowoff = ((b * g.OH + pp) * g.OW + q) * g.N;
-    }
-    {
+    const int cchunks = g.C / BK;
+    int nsteps_all;
+    if constexpr (DENSE) {
+        if (m < g.M) {
+            rbase = m * g.C + 8 * h;
+            rpy = rqx = 0;
+            rowoff = m * g.N;
+        }
+        nsteps_all = cchunks;
+    } else {
+        if (m < g.M) {
+            int b, pp, q;
+            decode_row(g, m, b, pp, q);
+            rbase = b * g.IH * g.IW * g.C + 8 * h;
+            rpy = pp * g.a + g.off;
+            rqx = q * g.a + g.off;
+            rowoff = ((b * g.OH + pp) * g.OW + q) * g.N;
+        }
         unsigned my = 0u, mx = 0u;
         int s;
         for (int t = 0; t < g.KH; ++t)
@@ -914,12 +924,16 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
         for (int t = 0; t < g.KW; ++t)
             if (coord_ok<DD>(rqx + t * g.cs, g.d, g.IW, s)) mx |= 1u << t;
         build_tap_list(g, tl, my, mx, tid);
+        nsteps_all = tl->nvy * tl->nvx * cchunks;
     }
-    const int cchunks = g.C / BK;
-    const int nsteps_all = tl->nvy * tl->nvx * cchunks;
     for (int s = tid; s < nsteps_all + DGS; s += 256) {
         KStepB k{0, 0, 0, 0};
-        if (s < nsteps_all) {
+        if (DENSE) {
+            if (s < nsteps_all) {
+                k.c0 = s * BK;
+                k.woff = s * npad * BK;
+            }
+        } else if (s < nsteps_all) {
             int tj = s / cchunks;
             int cc = s - tj * cchunks;
             int jy = tj / tl->nvx;
@@ -1098,17 +1112,20 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
 
 template <int RN, int DD>
 void launch_direct_bf16(hipStream_t s, const GemmArgs& a, dim3 grid, const __bf16* ws, int npad, long long plane) {
-    switch (a.g.in_act) {
-        case PM_ACT_RELU:
-            hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, DD, PM_ACT_RELU>), grid, dim3(256), 0, s, a, ws, npad, plane);
-            break;
-        case PM_ACT_LEAKY:
-            hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, DD, PM_ACT_LEAKY>), grid, dim3(256), 0, s, a, ws, npad, plane);
-            break;
-        default:
-            hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, DD, PM_ACT_NONE>), grid, dim3(256), 0, s, a, ws, npad, plane);
-            break;
+    const Geom& g = a.g;
+    const bool dense = DD == 1 && g.KH == 1 && g.KW == 1 && g.IH == 1 && g.IW == 1 && g.OH == 1 && g.OW == 1 &&
+                       g.a == 1 && g.off == 0;
+#define PM_LB(ACT)                                                                                                   \
+    do {                                                                                                              \
+        if (dense) hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, 1, ACT, true>), grid, dim3(256), 0, s, a, ws, npad, plane); \
+        else hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, DD, ACT, false>), grid, dim3(256), 0, s, a, ws, npad, plane);     \
+    } while (0)
+    switch (g.in_act) {
+        case PM_ACT_RELU: PM_LB(PM_ACT_RELU); break;
+        case PM_ACT_LEAKY: PM_LB(PM_ACT_LEAKY); break;
+        default: PM_LB(PM_ACT_NONE); break;
     }
+#undef PM_LB
 }
 
 // Pre-split, K-contiguous copy of one layer's weights for one direction:

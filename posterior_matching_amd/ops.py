@@ -236,7 +236,9 @@ def bf16_supported(desc: GatherDesc) -> bool:
 def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None:
     tag = work = None
     if _timer is not None:
-        tag = f"direct_gemm_bf16_kernel<{2 if desc.N > 32 else 1}, {desc.d}, {desc.in_act}>"   # template args
+        dense = desc.KH == desc.KW == desc.IH == desc.IW == desc.OH == desc.OW == 1 and desc.d == 1
+        tag = (f"direct_gemm_bf16_kernel<{2 if desc.N > 32 else 1}, {desc.d}, {desc.in_act}, "
+               f"{'true' if dense else 'false'}>")   # template args
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
     _call("pm_gather_gemm_bf16", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
           _ptr(out), tag=tag, work=work)
