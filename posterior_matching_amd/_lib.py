@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpmhip.so")
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+AUX_AFTER_RES = 16  # PM_AUX_AFTER_RES (include/pmhip.h)
 LEAKY_SLOPE = 0.01  # jax.nn.leaky_relu default negative_slope
 
 
@@ -87,8 +88,12 @@ SIGNATURES = {
     "pm_tril_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
     "pm_bernoulli_ll_fwd": [_P, _P, _P, _P, _I, _I],
     "pm_bernoulli_ll_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F],
-    "pm_normal_ll_fwd": [_P, _P, _P, _P, _P, _I, _I],
-    "pm_normal_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
+    "pm_normal_ll_fwd": [_P, _P, _P, _P, _P, _I, _I, _F],
+    "pm_normal_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F],
+    "pm_vq_select": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "pm_vq_ema_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F],
+    "pm_vq_lookup": [_P, _P, _P, _P, _I, _I, _I],
+    "pm_vqvae_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
     "pm_argmm_build_input": [_P, _P, _P, _P, _I, _I, _I],
     "pm_argmm_input_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _F],
     "pm_gmm_logprob_fwd": [_P, _P, _P, _P, _I, _I, _I],

@@ -24,6 +24,20 @@ __device__ __forceinline__ float pm_dact(float v, int act, float slope) {
     return 1.f;
 }
 
+// The shared epilogue of every gather-GEMM / thin kernel:
+//   out = act( v * act'(aux) + res )            (default)
+//   out = act( (v + res) * act'(aux) )          (aux_act | PM_AUX_AFTER_RES)
+// The second form is the data gradient into a tensor that was stored AFTER its activation and
+// also feeds a residual path (relu(enc_3) entering ConvResidualStack, reference vqvae.py:215-217).
+__device__ __forceinline__ float pm_epilogue(float v, const float* __restrict__ aux, const float* __restrict__ res,
+                                             size_t o, int aux_act, int out_act, float slope) {
+    const bool after = (aux_act & PM_AUX_AFTER_RES) != 0;
+    if (res && after) v += res[o];
+    if (aux) v *= pm_dact(aux[o], aux_act & (PM_AUX_AFTER_RES - 1), slope);
+    if (res && !after) v += res[o];
+    return pm_act(v, out_act, slope);
+}
+
 __device__ __forceinline__ float pm_softplus(float x) {  // logaddexp(x, 0)
     return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
 }

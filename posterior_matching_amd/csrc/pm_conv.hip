@@ -546,9 +546,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
                 continue;
             }
             float v = acc[r][e] + bv;
-            if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
-            if (res) v += res[o];
-            out[o] = pm_act(v, g.out_act, g.slope);
+            out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
         }
     }
 }
@@ -565,9 +563,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, long l
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total_per_group; o += stride) {
         int n = (int)(o % g.N);
         float v = out[o] + (bias ? bias[n] : 0.f);
-        if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
-        if (res) v += res[o];
-        out[o] = pm_act(v, g.out_act, g.slope);
+        out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
     }
 }
 
@@ -816,9 +812,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
                 continue;
             }
             float v = acc[r][e] + bv;
-            if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
-            if (res) v += res[o];
-            out[o] = pm_act(v, g.out_act, g.slope);
+            out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
         }
     }
 }
@@ -1103,9 +1097,7 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
                 continue;
             }
             float v = acc[r][e] + bv;
-            if (aux) v *= pm_dact(aux[o], g.aux_act, g.slope);
-            if (res) v += res[o];
-            out[o] = pm_act(v, g.out_act, g.slope);
+            out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
         }
     }
 }

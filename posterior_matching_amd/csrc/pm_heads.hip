@@ -203,11 +203,12 @@ __global__ __launch_bounds__(256) void bernoulli_ll_bwd_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void normal_ll_fwd_kernel(const float* __restrict__ loc, const float* __restrict__ x,
                                                               const float* __restrict__ log_scale,
-                                                              float* __restrict__ ll, int D) {
+                                                              float* __restrict__ ll, int D, float scale_eps) {
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * D;
-    const float ls = log_scale[0];
-    const float inv = expf(-ls);
+    const float sigma = expf(log_scale[0]) + scale_eps;
+    const float inv = 1.f / sigma;
+    const float ls = logf(sigma);
     float s = 0.f;
     for (int j = threadIdx.x; j < D; j += 256) {
         float u = (x[base + j] - loc[base + j]) * inv;
@@ -220,19 +221,20 @@ __global__ __launch_bounds__(256) void normal_ll_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void normal_ll_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ x,
                                                               const float* __restrict__ log_scale,
                                                               const float* __restrict__ g, float* __restrict__ dloc,
-                                                              float* __restrict__ d_log_scale, int D) {
+                                                              float* __restrict__ d_log_scale, int D, float scale_eps) {
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * D;
-    const float inv = expf(-log_scale[0]);
+    const float e = expf(log_scale[0]);
+    const float inv = 1.f / (e + scale_eps);
     const float gb = g[blockIdx.x];
     float s = 0.f;
     for (int j = threadIdx.x; j < D; j += 256) {
         float u = (x[base + j] - loc[base + j]) * inv;
         dloc[base + j] = gb * u * inv;
-        s += gb * (u * u - 1.f);  // d/d log_scale of -0.5 u^2 - log_scale
+        s += gb * (u * u - 1.f);  // sigma * d/d sigma of (-0.5 u^2 - log sigma)
     }
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) atomicAdd(d_log_scale, s);
+    if (threadIdx.x == 0) atomicAdd(d_log_scale, s * e * inv);  // d sigma / d log_scale = exp(log_scale)
 }
 
 __global__ __launch_bounds__(256) void mask_concat_kernel(const float* __restrict__ x, const float* __restrict__ b,
@@ -411,17 +413,18 @@ extern "C" int pm_bernoulli_ll_bwd(pm_stream_t stream, const float* logits, cons
 }
 
 extern "C" int pm_normal_ll_fwd(pm_stream_t stream, const float* loc, const float* x, const float* log_scale,
-                                float* ll, int B, int D) {
+                                float* ll, int B, int D, float scale_eps) {
     if (!loc || !x || !log_scale || !ll || B <= 0 || D <= 0) return PM_EINVAL;
-    hipLaunchKernelGGL(normal_ll_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, x, log_scale, ll, D);
+    hipLaunchKernelGGL(normal_ll_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, x, log_scale, ll, D,
+                       scale_eps);
     return pm_check_launch("pm_normal_ll_fwd");
 }
 
 extern "C" int pm_normal_ll_bwd(pm_stream_t stream, const float* loc, const float* x, const float* log_scale,
-                                const float* g, float* dloc, float* d_log_scale, int B, int D) {
+                                const float* g, float* dloc, float* d_log_scale, int B, int D, float scale_eps) {
     if (!loc || !x || !log_scale || !g || !dloc || !d_log_scale || B <= 0 || D <= 0) return PM_EINVAL;
     hipLaunchKernelGGL(normal_ll_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, x, log_scale, g, dloc,
-                       d_log_scale, D);
+                       d_log_scale, D, scale_eps);
     return pm_check_launch("pm_normal_ll_bwd");
 }
 

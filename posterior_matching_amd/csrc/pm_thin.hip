@@ -80,9 +80,7 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(ThinArgs t, const float*
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float v = acc[e] + (bias ? bias[ng * 8 + e] : 0.f);
-        if (aux) v *= pm_dact(aux[o + e], t.aux_act, t.slope);
-        if (res) v += res[o + e];
-        out[o + e] = pm_act(v, t.out_act, t.slope);
+        out[o + e] = pm_epilogue(v, aux, res, o + e, t.aux_act, t.out_act, t.slope);
     }
 }
 

@@ -1,0 +1,193 @@
+// Vector quantisation with EMA codebook updates: hk.nets.VectorQuantizerEMA as the reference's
+// VQVAE uses it (posterior_matching/models/vqvae.py:66-72,80; third party dm-haiku 0.0.5, SURVEY.md
+// Appendix A5).  The distance GEMM z @ emb runs in the gather-GEMM engine (pm_conv.hip, f32: the
+// argmin must see exact f32 products); everything here is HBM-bound row work:
+//   select : dist = |z|^2 - 2 z.e + |e|^2 -> first argmin -> lookup, commitment gradient, counts, dw
+//   ema    : the two zero-debiased EMAs, Laplace smoothing and the new codebook
+//   loss   : reconstruction / commitment loss, perplexity
+#include "pm_common.h"
+
+namespace {
+
+// e2[k] = sum_d emb[d,k]^2 ; zero counts[K] and dw[D*K]
+__global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ emb, float* __restrict__ e2,
+                                                       float* __restrict__ counts, float* __restrict__ dw, int D, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < K) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) {
+            float e = emb[(size_t)d * K + i];
+            s = fmaf(e, e, s);
+        }
+        e2[i] = s;
+        counts[i] = 0.f;
+    }
+    if (dw)
+        for (int j = i; j < D * K; j += gridDim.x * 256) dw[j] = 0.f;
+}
+
+// One wave per row of z.
+__global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict__ z, const float* __restrict__ emb,
+                                                         const float* __restrict__ dots, const float* __restrict__ e2,
+                                                         int* __restrict__ idx_out, float* __restrict__ quant,
+                                                         float* __restrict__ commit_grad, float* __restrict__ sqerr,
+                                                         float* __restrict__ counts, float* __restrict__ dw, int N, int D,
+                                                         int K, float commit_coef) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* zr = z + (size_t)row * D;
+    float x2 = 0.f;
+    for (int d = lane; d < D; d += 64) x2 = fmaf(zr[d], zr[d], x2);
+    x2 = pm_wave_sum(x2);
+    // nearest code; ties -> lowest index (argmax(-dist) returns the first maximum)
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    const float* dr = dots + (size_t)row * K;
+    for (int k = lane; k < K; k += 64) {
+        const float dist = x2 - 2.f * dr[k] + e2[k];
+        if (dist < best) { best = dist; bi = k; }      // k ascends within a lane: strict < keeps the first
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (bi >= K) bi = 0;                                // all-NaN row: argmax of NaNs is index 0
+    float se = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float q = emb[(size_t)d * K + bi];
+        const float zv = zr[d];
+        const float diff = q - zv;
+        se = fmaf(diff, diff, se);
+        quant[(size_t)row * D + d] = q;
+        if (commit_grad) commit_grad[(size_t)row * D + d] = -commit_coef * diff;
+        if (dw) atomicAdd(dw + (size_t)d * K + bi, zv);
+    }
+    se = pm_wave_sum(se);
+    if (lane == 0) {
+        idx_out[row] = bi;
+        sqerr[row] = se;
+        atomicAdd(counts + bi, 1.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_lookup_kernel(const int* __restrict__ idx, const float* __restrict__ emb,
+                                                         float* __restrict__ quant, long long total, int D, int K) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long n = i / D;
+    const int d = (int)(i - n * D);
+    quant[i] = emb[(size_t)d * K + idx[n]];
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = pm_wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    return s;
+}
+
+// single workgroup: K and D*K are a few thousand elements
+__global__ __launch_bounds__(1024) void vq_ema_kernel(const float* __restrict__ counts, const float* __restrict__ dw,
+                                                       float* __restrict__ cs_hidden, float* __restrict__ cs_avg,
+                                                       float* __restrict__ dw_hidden, float* __restrict__ dw_avg,
+                                                       float* __restrict__ emb, int* __restrict__ counter, int D, int K,
+                                                       float decay, float epsilon) {
+    __shared__ float red[16];
+    const int t = counter[0] + 1;
+    const float debias = 1.f / (1.f - powf(decay, (float)t));
+    float part = 0.f;
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        const float h = cs_hidden[k] * decay + counts[k] * (1.f - decay);
+        cs_hidden[k] = h;
+        const float a = h * debias;
+        cs_avg[k] = a;
+        part += a;
+    }
+    const float n = block_sum_1024(part, red);
+    for (int j = threadIdx.x; j < D * K; j += 1024) {
+        const int k = j % K;
+        const float h = dw_hidden[j] * decay + dw[j] * (1.f - decay);
+        dw_hidden[j] = h;
+        const float a = h * debias;
+        dw_avg[j] = a;
+        const float cs = (cs_avg[k] + epsilon) / (n + (float)K * epsilon) * n;   // cs_avg: visible after the block sum's barriers
+        emb[j] = a / cs;
+    }
+    if (threadIdx.x == 0) counter[0] = t;
+}
+
+__global__ __launch_bounds__(1024) void vqvae_loss_kernel(const float* __restrict__ ll, const float* __restrict__ sqerr,
+                                                           const float* __restrict__ counts, int B, int N, int D, int K,
+                                                           float commitment_cost, float grad_scale,
+                                                           float* __restrict__ out, float* __restrict__ g_ll) {
+    __shared__ float red[16];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < B; i += 1024) {
+        a += ll[i];
+        if (g_ll) g_ll[i] = -grad_scale;
+    }
+    for (int i = threadIdx.x; i < N; i += 1024) b += sqerr[i];
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        const float p = counts[k] / (float)N;
+        c += p * logf(p + 1e-10f);
+    }
+    a = block_sum_1024(a, red);
+    b = block_sum_1024(b, red);
+    c = block_sum_1024(c, red);
+    if (threadIdx.x == 0) {
+        const float rec = -a / (float)B;
+        const float vq = commitment_cost * b / ((float)N * (float)D);
+        out[0] = rec + vq;
+        out[1] = rec;
+        out[2] = vq;
+        out[3] = expf(-c);
+    }
+}
+
+}  // namespace
+
+extern "C" int pm_vq_select(pm_stream_t stream, const float* z, const float* emb, const float* dots, float* e2,
+                            int* idx, float* quant, float* commit_grad, float* sqerr, float* counts, float* dw, int N,
+                            int D, int K, float commit_coef) {
+    if (!z || !emb || !dots || !e2 || !idx || !quant || !sqerr || !counts || N <= 0 || D <= 0 || K <= 0)
+        return PM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int pb = dw ? (D * K + 255) / 256 : (K + 255) / 256;
+    hipLaunchKernelGGL(vq_prep_kernel, dim3(pb), dim3(256), 0, s, emb, e2, counts, dw, D, K);
+    hipLaunchKernelGGL(vq_select_kernel, dim3((N + 3) / 4), dim3(256), 0, s, z, emb, dots, e2, idx, quant, commit_grad,
+                       sqerr, counts, dw, N, D, K, commit_coef);
+    return pm_check_launch("pm_vq_select");
+}
+
+extern "C" int pm_vq_ema_update(pm_stream_t stream, const float* counts, const float* dw, float* cs_hidden,
+                                float* cs_avg, float* dw_hidden, float* dw_avg, float* emb, int* counter, int D, int K,
+                                float decay, float epsilon) {
+    if (!counts || !dw || !cs_hidden || !cs_avg || !dw_hidden || !dw_avg || !emb || !counter || D <= 0 || K <= 0)
+        return PM_EINVAL;
+    hipLaunchKernelGGL(vq_ema_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, dw, cs_hidden, cs_avg,
+                       dw_hidden, dw_avg, emb, counter, D, K, decay, epsilon);
+    return pm_check_launch("pm_vq_ema_update");
+}
+
+extern "C" int pm_vq_lookup(pm_stream_t stream, const int* idx, const float* emb, float* quant, int N, int D, int K) {
+    if (!idx || !emb || !quant || N <= 0 || D <= 0 || K <= 0) return PM_EINVAL;
+    const long long total = (long long)N * D;
+    hipLaunchKernelGGL(vq_lookup_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx,
+                       emb, quant, total, D, K);
+    return pm_check_launch("pm_vq_lookup");
+}
+
+extern "C" int pm_vqvae_loss(pm_stream_t stream, const float* ll, const float* sqerr, const float* counts, int B, int N,
+                             int D, int K, float commitment_cost, float grad_scale, float* out, float* g_ll) {
+    if (!ll || !sqerr || !counts || !out || B <= 0 || N <= 0 || D <= 0 || K <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(vqvae_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ll, sqerr, counts, B, N, D, K,
+                       commitment_cost, grad_scale, out, g_ll);
+    return pm_check_launch("pm_vqvae_loss");
+}

@@ -163,3 +163,69 @@ class PMVAETrainStep:
         self.stream.synchronize()
         v = metrics.cpu().tolist()
         return {"loss": v[0], "reconstruction_ll": v[1], "kl": v[2], "matching_ll": v[3], "beta": v[4]}
+
+
+class VQVAETrainStep:
+    """train_vqvae.py:67-111 as one launch sequence: VQVAE forward (EMA codebook update inside, as in
+    haiku) -> loss -> backward -> [gradient all-reduce] -> Adam -> step += 1."""
+
+    def __init__(self, model, optimizer: Chain, batch_size: int, x_shape, world_size: int = 1, rank: int = 0,
+                 use_graph: bool = False):
+        if model.store is None:
+            model.init(x_shape)
+        dev = model.store.device
+        self.model, self.opt, self.B = model, optimizer, batch_size
+        self.world_size, self.rank = world_size, rank
+        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.x = torch.zeros((batch_size,) + tuple(x_shape), device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.use_graph = use_graph and world_size == 1
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        self._graph: Optional[ops.Graph] = None
+
+    def _sequence(self) -> None:
+        m, s = self.model, self.model.store
+        m(self.x, is_training=True)
+        m.zero_grad()
+        m.backward()
+        if self.world_size > 1:
+            from .parallel import allreduce_sum_
+
+            allreduce_sum_(s.flat_g)
+        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        s.split_all()
+        ops.counter_increment(self.step_dev)
+
+    def step(self) -> None:
+        with torch.cuda.stream(self.stream):
+            if not self.use_graph:
+                self._sequence()
+            elif self._graph is None:
+                self._sequence()                    # eager once: every workspace buffer exists before capture
+                self.stream.synchronize()
+                self._graph = ops.Graph()
+                with self._graph:
+                    self._sequence()
+            else:
+                self._graph.launch()
+
+    def set_batch(self, x: torch.Tensor) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def read_metrics(self) -> Dict[str, float]:
+        self.stream.synchronize()
+        v = self.model.metrics.cpu().tolist()
+        return {"loss": v[0], "reconstruction_loss": v[1], "vq_loss": v[2], "perplexity": v[3]}
+
+    def evaluate(self, x: torch.Tensor) -> Dict[str, float]:
+        """loss_fn with is_training=False: no EMA update, no gradients."""
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(self.stream):
+            self.model(x, is_training=False)
+        return self.read_metrics()

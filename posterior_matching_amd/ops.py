@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, LEAKY_SLOPE, GatherDesc  # noqa: F401
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, AUX_AFTER_RES, LEAKY_SLOPE, GatherDesc  # noqa: F401
 
 
 def _stream() -> int:
@@ -379,14 +379,41 @@ def bernoulli_ll_bwd(logits, x, g, dpre, act, slope=LEAKY_SLOPE) -> None:
     _call("pm_bernoulli_ll_bwd", _ptr(logits), _ptr(x), _ptr(g), _ptr(dpre), B, x.numel() // B, act, slope)
 
 
-def normal_ll_fwd(loc, x, log_scale, ll) -> None:
+def normal_ll_fwd(loc, x, log_scale, ll, scale_eps: float = 0.0) -> None:
     B = x.shape[0]
-    _call("pm_normal_ll_fwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(ll), B, x.numel() // B)
+    _call("pm_normal_ll_fwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(ll), B, x.numel() // B, scale_eps)
 
 
-def normal_ll_bwd(loc, x, log_scale, g, dloc, d_log_scale) -> None:
+def normal_ll_bwd(loc, x, log_scale, g, dloc, d_log_scale, scale_eps: float = 0.0) -> None:
     B = x.shape[0]
-    _call("pm_normal_ll_bwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(g), _ptr(dloc), _ptr(d_log_scale), B, x.numel() // B)
+    _call("pm_normal_ll_bwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(g), _ptr(dloc), _ptr(d_log_scale), B,
+          x.numel() // B, scale_eps)
+
+
+# ---- vector quantisation (hk.nets.VectorQuantizerEMA, reference vqvae.py:66-72,80) -----------------
+def vq_select(z, emb, dots, e2, idx, quant, commit_grad, sqerr, counts, dw, commit_coef: float) -> None:
+    """z [N,D], emb [D,K], dots [N,K] = z @ emb."""
+    D, K = emb.shape
+    N = z.numel() // D
+    work = {"bytes": _nbytes(z, dots, quant, commit_grad), "detail": f"N{N} D{D} K{K}"}
+    _call("pm_vq_select", _ptr(z), _ptr(emb), _ptr(dots), _ptr(e2), _iptr(idx), _ptr(quant), _ptr(commit_grad),
+          _ptr(sqerr), _ptr(counts), _ptr(dw), N, D, K, commit_coef, work=work)
+
+
+def vq_ema_update(counts, dw, cs_hidden, cs_avg, dw_hidden, dw_avg, emb, counter, decay: float, epsilon: float) -> None:
+    D, K = emb.shape
+    _call("pm_vq_ema_update", _ptr(counts), _ptr(dw), _ptr(cs_hidden), _ptr(cs_avg), _ptr(dw_hidden), _ptr(dw_avg),
+          _ptr(emb), _iptr(counter), D, K, decay, epsilon)
+
+
+def vq_lookup(idx, emb, quant) -> None:
+    D, K = emb.shape
+    _call("pm_vq_lookup", _iptr(idx), _ptr(emb), _ptr(quant), idx.numel(), D, K)
+
+
+def vqvae_loss(ll, sqerr, counts, D: int, commitment_cost: float, grad_scale: float, out, g_ll) -> None:
+    _call("pm_vqvae_loss", _ptr(ll), _ptr(sqerr), _ptr(counts), ll.numel(), sqerr.numel(), D, counts.numel(),
+          commitment_cost, grad_scale, _ptr(out), _ptr(g_ll))
 
 
 def argmm_build_input(z, ctx, inp) -> None:

@@ -98,3 +98,14 @@ def chain(*transforms) -> Chain:
             "only chain(scale_by_adam, add_decayed_weights, scale_by_schedule(exponential_decay), scale(-1.0)) "
             "(train_pm_vae.py:74-83) is lowered to the fused HIP optimizer")
     return Chain(transforms[0], transforms[1], transforms[2].schedule)
+
+
+def adam(learning_rate, b1=0.9, b2=0.999, eps=1e-8, eps_root=0.0) -> Chain:
+    """optax.adam(lr) = chain(scale_by_adam, scale(-lr)) (train_vqvae.py:82): the same fused kernel with
+    a constant schedule and no weight decay."""
+    if callable(learning_rate):
+        if not isinstance(learning_rate, ExponentialDecay):
+            raise NotImplementedError("optax.adam(schedule): only exponential_decay schedules are lowered")
+        return Chain(scale_by_adam(b1, b2, eps, eps_root), AddDecayedWeights(0.0), learning_rate)
+    return Chain(scale_by_adam(b1, b2, eps, eps_root), AddDecayedWeights(0.0),
+                 ExponentialDecay(float(learning_rate), 1.0, 1.0))

@@ -41,3 +41,15 @@ def pm_vae_gas():
         "steps": 200000, "validation_freq": 1000, "save_final_state": True, "weight_decay": 0.00001,
         "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 5000},
     }
+
+
+def vqvae_mnist():
+    """configs/vqvae_mnist.py:4-30 of the reference (stage-1 VQ-VAE; BASELINE quotes it at batch 256)."""
+    return {
+        "data": {"dataset": "mnist", "train_split": "train", "validation_split": "test",
+                 "train_batch_size": 32, "val_batch_size": 32},
+        "model": {"embedding_dim": 64, "num_embeddings": 256, "hidden_units": 32, "residual_hidden_units": 32,
+                  "residual_blocks": 2, "decay": 0.99, "use_ema": True, "commitment_cost": 0.25,
+                  "output_channels": 1},
+        "steps": 60000, "validation_freq": 1000, "learning_rate": 3e-4,
+    }

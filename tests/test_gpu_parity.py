@@ -43,6 +43,10 @@ CONV_CASES = [
     ("convT", 2, 14, 64, 32, 5, 1, "SAME"), ("convT", 2, 14, 32, 32, 5, 2, "SAME"),
     ("convT", 2, 28, 32, 1, 5, 1, "SAME"), ("convT", 2, 6, 8, 4, 4, 2, "SAME"),
     ("dense", 37, 1, 192, 256, 1, 1, "VALID"), ("dense", 300, 1, 16, 8, 1, 1, "VALID"),
+    # VQ-VAE layers (reference vqvae.py:151-249 at configs/vqvae_mnist.py sizes)
+    ("conv", 8, 28, 1, 16, 4, 2, "SAME"), ("conv", 8, 14, 16, 32, 4, 2, "SAME"), ("conv", 32, 7, 32, 32, 3, 1, "SAME"),
+    ("conv", 32, 7, 32, 32, 1, 1, "SAME"), ("conv", 32, 7, 32, 64, 1, 1, "SAME"), ("conv", 32, 7, 64, 32, 3, 1, "SAME"),
+    ("convT", 8, 7, 32, 16, 4, 2, "SAME"), ("convT", 8, 14, 16, 1, 4, 2, "SAME"),
 ]
 
 
