@@ -10,6 +10,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern thread_local char pm_err_text[256];
 int pm_check_launch(const char* what);
+// Zero-fill by a plain kernel (ptr and nbytes multiples of 4).  hipMemsetAsync is avoided on purpose:
+// captured as a memset node of a HIP graph on ROCm 7.2 it was observed to leave every fourth dword
+// of the range non-zero on replay (tests/test_gpu_vqvae.py::test_vqvae_train_steps_match_oracle).
+int pm_zero_async(hipStream_t stream, void* ptr, size_t nbytes);
 
 __device__ __forceinline__ float pm_act(float v, int act, float slope) {
     if (act == PM_ACT_LEAKY) return v >= 0.f ? v : slope * v;  // jax.nn.leaky_relu: where(x >= 0, x, a*x)

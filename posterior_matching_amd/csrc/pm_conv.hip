@@ -1714,8 +1714,7 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
     const GemmPlan p = plan_gemm(a.g, G, vec4);
     a.ksplit = p.ksplit;
     if (p.ksplit > 1) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)a.g.M * a.g.N * sizeof(float), s);
-        if (e != hipSuccess) return pm_check_launch("pm_gather_gemm(memset)");
+        if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
     }
     if (p.direct) {
         const int rn = a.g.N > 32 ? 2 : 1;
@@ -1801,8 +1800,7 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
     const GemmPlan p = plan_gemm(a.g, G, true);
     a.ksplit = p.ksplit;
     if (p.ksplit > 1) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)a.g.M * a.g.N * sizeof(float), s);
-        if (e != hipSuccess) return pm_check_launch("pm_gather_gemm_bf16(memset)");
+        if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
     }
     const int npad = (a.g.N + 31) / 32 * 32;
     const long long plane = (long long)a.g.KH * a.g.KW * a.g.C * npad;

@@ -205,14 +205,32 @@ extern "C" int pm_normal_fill(pm_stream_t stream, float* out, long long n, unsig
     return pm_check_launch("pm_normal_fill");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(unsigned* __restrict__ p, size_t nwords) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nwords; i += stride) {
+        if (i + 4 <= nwords && (reinterpret_cast<uintptr_t>(p + i) & 15) == 0) {
+            *reinterpret_cast<uint4*>(p + i) = uint4{0u, 0u, 0u, 0u};
+        } else {
+            for (size_t j = i; j < nwords && j < i + 4; ++j) p[j] = 0u;
+        }
+    }
+}
+}  // namespace
+
+int pm_zero_async(hipStream_t stream, void* ptr, size_t nbytes) {
+    if (!ptr || nbytes == 0 || (nbytes & 3) || (reinterpret_cast<uintptr_t>(ptr) & 3)) return PM_EINVAL;
+    const size_t nwords = nbytes / 4;
+    size_t blocks = (nwords / 4 + 255) / 256 + 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<unsigned*>(ptr),
+                       nwords);
+    return pm_check_launch("pm_zero_async");
+}
+
 extern "C" int pm_fill_zero(pm_stream_t stream, void* ptr, long long nbytes) {
     if (!ptr || nbytes <= 0) return PM_EINVAL;
-    hipError_t e = hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        snprintf(pm_err_text, sizeof(pm_err_text), "pm_fill_zero: %s", hipGetErrorString(e));
-        return PM_ELAUNCH;
-    }
-    return PM_OK;
+    return pm_zero_async((hipStream_t)stream, ptr, (size_t)nbytes);
 }
 
 extern "C" int pm_colsum(pm_stream_t stream, const float* x, float* out, long long M, int N) {

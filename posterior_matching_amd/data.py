@@ -27,7 +27,9 @@ class SyntheticDataset:
         name = config["dataset"]
         shape = data_shape(name)
         self.key = "image" if len(shape) == 3 else "features"
-        gen = get_mask_generator(config["mask_generator"], seed=seed + 1, **config.get("mask_generator_kwargs", {}))
+        gen = None                                          # stage-1 VQ-VAE batches carry no mask (utils.py:338-350)
+        if config.get("mask_generator") is not None:
+            gen = get_mask_generator(config["mask_generator"], seed=seed + 1, **config.get("mask_generator_kwargs", {}))
         self.batches: List[Dict[str, torch.Tensor]] = []
         for i in range(num_batches):
             if arrays is not None:
@@ -40,8 +42,10 @@ class SyntheticDataset:
                 x = rng.normal(size=(batch_size,) + shape).astype(np.float32)
                 if training and "training_noise" in config:          # utils.py:108-116
                     x = x + rng.normal(scale=config["training_noise"], size=x.shape).astype(np.float32)
-            b = gen((batch_size,) + shape)
-            self.batches.append({self.key: torch.from_numpy(x).to(device), "mask": torch.from_numpy(b).to(device)})
+            batch = {self.key: torch.from_numpy(x).to(device)}
+            if gen is not None:
+                batch["mask"] = torch.from_numpy(gen((batch_size,) + shape)).to(device)
+            self.batches.append(batch)
         self.batch_size, self.shape = batch_size, shape
 
     def __len__(self):

@@ -284,17 +284,26 @@ class VectorQuantizerEMA(Module):
         return out
 
 
-class _VQOutput(dict):
-    """vq_output dict of the reference; `encodings` (one-hot [N,K]) is materialised on first access -
-    the training step itself only needs the code counts."""
+class _LazyDict(dict):
+    """A dict whose listed keys are computed on first access.  The training step never touches
+    them, so no torch kernel (and no allocation) happens inside a captured launch sequence."""
+
+    def __init__(self, lazy, **kw):
+        super().__init__(**kw)
+        self._lazy = dict(lazy)
 
     def __missing__(self, key):
-        if key == "encodings":
-            idx = self["encoding_indices"].reshape(-1).long()
-            v = torch.nn.functional.one_hot(idx, self["_K"]).to(torch.float32)
+        if key in self._lazy:
+            v = self._lazy[key]()
             self[key] = v
             return v
         raise KeyError(key)
+
+    def keys(self):
+        return list(super().keys()) + [k for k in self._lazy if not super().__contains__(k)]
+
+    def __contains__(self, key):
+        return super().__contains__(key) or key in self._lazy
 
 
 class VQVAE(Module):
@@ -376,10 +385,15 @@ class VQVAE(Module):
                        gs / B, self.metrics, g_ll)
         self._vq, self._g_ll = vq, g_ll
         m = self.metrics
-        vq_out = _VQOutput(quantize=vq["quantize"], loss=m[2], perplexity=m[3],
-                           encoding_indices=vq["encoding_indices"], _K=self.config["num_embeddings"])
-        return {"loss": m[0], "vq_output": vq_out, "z": z, "reconstruction": loc, "reconstruction_loss": m[1],
-                "scale": torch.exp(self.store.p["decoder/log_scale"]) + ConvResidualDecoder.SCALE_EPS, "ll": ll}
+        K, idx = self.config["num_embeddings"], vq["encoding_indices"]
+        # `encodings` (one-hot [N,K]) and `scale` are derived views for callers; the step itself only
+        # needs the code counts and log_scale
+        vq_out = _LazyDict(
+            {"encodings": lambda: torch.nn.functional.one_hot(idx.reshape(-1).long(), K).to(torch.float32)},
+            quantize=vq["quantize"], loss=m[2], perplexity=m[3], encoding_indices=idx)
+        log_scale = self.store.p["decoder/log_scale"]
+        return _LazyDict({"scale": lambda: torch.exp(log_scale) + ConvResidualDecoder.SCALE_EPS},
+                         loss=m[0], vq_output=vq_out, z=z, reconstruction=loc, reconstruction_loss=m[1], ll=ll)
 
     def backward(self) -> None:
         """Accumulates d loss / d params of the last is_training=True call into the flat gradient

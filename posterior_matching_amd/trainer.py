@@ -1,8 +1,9 @@
 """A trainer with the constructor / fit() surface the reference uses from bax
 (train_pm_vae.py:85-102; bax itself is third-party and not in the reference tree).
 
-loss_fn must be a `PMVAELoss` (train_pm_vae.py builds it): its forward, loss, backward and the
-optimizer run as the fused HIP step of engine.PMVAETrainStep.  One process drives one GPU;
+loss_fn must be a `PMVAELoss` (train_pm_vae.py builds it) or a `VQVAELoss` (train_vqvae.py): its
+forward, loss, backward and the optimizer run as the fused HIP step of engine.PMVAETrainStep /
+engine.VQVAETrainStep.  One process drives one GPU;
 `num_devices` must equal the torch.distributed world size (launch N processes with
 `python -m torch.distributed.run --nproc-per-node N train_pm_vae.py ...`).
 """
@@ -15,8 +16,9 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional
 import torch
 
 from . import ops
-from .engine import PMVAETrainStep
+from .engine import PMVAETrainStep, VQVAETrainStep
 from .models.vae import PosteriorMatchingVAE
+from .models.vqvae import VQVAE
 from .optim import Chain
 from .parallel import allreduce_mean_scalars, init_distributed
 from .utils import Callback
@@ -27,6 +29,14 @@ class PMVAELoss:
     trainer can lower it to the fused step instead of tracing Python."""
 
     def __init__(self, config: Mapping[str, Any], model: PosteriorMatchingVAE, data_key: str = "image"):
+        self.config, self.model, self.data_key = config, model, data_key
+
+
+class VQVAELoss:
+    """loss_fn(step, is_training, batch) of train_vqvae.py:67-75 as an object: returns out["loss"] with
+    aux perplexity / reconstruction_loss / vq_loss."""
+
+    def __init__(self, config: Mapping[str, Any], model: VQVAE, data_key: str = "image"):
         self.config, self.model, self.data_key = config, model, data_key
 
 
@@ -63,9 +73,10 @@ class Trainer:
     def __init__(self, loss_fn: PMVAELoss, optimizer: Chain, num_devices: int = 1, seed: int = 0,
                  trainable_predicate=None, skip_nonfinite_updates: bool = False, ema_rate: Optional[float] = None,
                  use_ema_for_eval: bool = False, use_graph: bool = True):
-        if not isinstance(loss_fn, PMVAELoss):
-            raise NotImplementedError("Trainer lowers PMVAELoss (train_pm_vae.py's loss_fn) to the fused HIP step; "
-                                      "arbitrary Python loss functions have no HIP path")
+        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss)):
+            raise NotImplementedError("Trainer lowers PMVAELoss / VQVAELoss (the loss_fn of train_pm_vae.py / "
+                                      "train_vqvae.py) to the fused HIP step; arbitrary Python loss functions have "
+                                      "no HIP path")
         if trainable_predicate is not None or skip_nonfinite_updates or ema_rate is not None or use_ema_for_eval:
             raise NotImplementedError("trainable_predicate / skip_nonfinite_updates / EMA are used by the VQ-VAE and "
                                       "VDVAE scripts only (SURVEY.md 8a-16,20): not on the PM-VAE path")
@@ -75,10 +86,11 @@ class Trainer:
             raise ValueError(f"num_devices={num_devices} but {self.world} process(es) are running: this engine is one "
                              "process per GPU, start it with torch.distributed.run --nproc-per-node num_devices")
 
-    def _state(self, ts: PMVAETrainStep) -> TrainState:
+    def _state(self, ts) -> TrainState:
         store = ts.model.store
+        state = {k: v.cpu() for k, v in ts.model.state_dict().items()} if isinstance(ts.model, VQVAE) else {}
         return TrainState(step=int(ts.step_dev.item()), params={k: v.cpu() for k, v in store.to_dict("p").items()},
-                          opt_state={"mu": store.flat_m.cpu(), "nu": store.flat_v.cpu()})
+                          state=state, opt_state={"mu": store.flat_m.cpu(), "nu": store.flat_v.cpu()})
 
     def fit(self, train_dataset: Iterable[Dict[str, torch.Tensor]], steps: int, val_dataset=None,
             validation_freq: Optional[int] = None, callbacks: Optional[List[Callback]] = None,
@@ -93,13 +105,25 @@ class Trainer:
             model.init(x_shape, device=torch.device("cuda", self.local_rank), seed=self.seed)   # same init on all ranks
         if initial_params is not None:
             model.load_params(initial_params)
+        if initial_state is not None and isinstance(model, VQVAE):
+            model.load_state(initial_state)
         dev = model.store.device
-        ts = PMVAETrainStep(model, lf.config, self.optimizer, B, x_shape, seed=self.seed, world_size=self.world,
-                            rank=self.rank, use_graph=self.use_graph)
+        is_vq = isinstance(lf, VQVAELoss)
+        if is_vq:
+            if self.world > 1:
+                model.vq.cross_replica_axis = "i"          # psum of the EMA statistics across ranks
+            ts = VQVAETrainStep(model, self.optimizer, B, x_shape, world_size=self.world, rank=self.rank,
+                                use_graph=self.use_graph)
+        else:
+            ts = PMVAETrainStep(model, lf.config, self.optimizer, B, x_shape, seed=self.seed, world_size=self.world,
+                                rank=self.rank, use_graph=self.use_graph)
         callbacks = callbacks or []
         batch = first
         for step in range(steps):
-            ts.set_batch(batch[key].to(dev, non_blocking=True), batch["mask"].to(dev, non_blocking=True))
+            if is_vq:
+                ts.set_batch(batch[key].to(dev, non_blocking=True))
+            else:
+                ts.set_batch(batch[key].to(dev, non_blocking=True), batch["mask"].to(dev, non_blocking=True))
             ts.step()
             if validation_freq and ((step + 1) % validation_freq == 0 or step + 1 == steps):
                 logs = dict(ts.read_metrics())
@@ -111,22 +135,26 @@ class Trainer:
                     for cb in callbacks:
                         cb.on_validation_end(state, step + 1, logs)
                     if log_fn:
-                        log_fn(f"step {step + 1}: " + ", ".join(f"{k}={v:.5g}" for k, v in logs.items()))
+                        log_fn(f"step {step + 1}: " + ", ".join(f"{k}={v:.5g}" for k, v in logs.items()
+                                                                 if getattr(v, "ndim", 0) == 0))
             batch = next(it)
         ts.synchronize()
         return self._state(ts)
 
-    def _validate(self, ts: PMVAETrainStep, val_dataset, key: str, dev) -> Dict[str, float]:
+    def _validate(self, ts, val_dataset, key: str, dev) -> Dict[str, float]:
         """loss_fn with is_training=False averaged over the validation batches (bax semantics)."""
         sums: Dict[str, float] = {}
         n = 0
         batches = getattr(val_dataset, "batches", None) or list(val_dataset)
         for i, vb in enumerate(batches):
-            x, b = vb[key].to(dev), vb["mask"].to(dev)
-            eps = torch.empty((x.shape[0], ts.model.latent_dim), device=dev)
-            with torch.cuda.stream(ts.stream):
-                ops.normal_fill(eps, self.seed + 7919, ts.step_dev, stream_id=1000 + i)
-            out = ts.evaluate(x, b, eps)
+            if isinstance(ts, VQVAETrainStep):
+                out = ts.evaluate(vb[key].to(dev))
+            else:
+                x, b = vb[key].to(dev), vb["mask"].to(dev)
+                eps = torch.empty((x.shape[0], ts.model.latent_dim), device=dev)
+                with torch.cuda.stream(ts.stream):
+                    ops.normal_fill(eps, self.seed + 7919, ts.step_dev, stream_id=1000 + i)
+                out = ts.evaluate(x, b, eps)
             for k, v in out.items():
                 sums[k] = sums.get(k, 0.0) + v
             n += 1

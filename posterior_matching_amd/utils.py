@@ -56,8 +56,16 @@ class JSONLCallback(Callback):
         self._file = os.path.join(path, "scalars.jsonl")
 
     def on_validation_end(self, train_state, step: int, logs: Dict[str, Any]) -> None:
+        import numpy as np
+
+        scalars = {}
+        for k, v in logs.items():
+            if getattr(v, "ndim", 0) > 0:            # image summaries (train_vqvae.py's reconstructions)
+                np.save(os.path.join(os.path.dirname(self._file), f"{k}_{step}.npy"), np.asarray(v))
+            else:
+                scalars[k] = float(v)
         with open(self._file, "a") as fp:
-            fp.write(json.dumps({"step": step, **{k: float(v) for k, v in logs.items()}}) + "\n")
+            fp.write(json.dumps({"step": step, **scalars}) + "\n")
 
 
 TensorBoardCallback = JSONLCallback

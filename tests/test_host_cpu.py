@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_configs_match_reference_values():
     from posterior_matching_amd.config_dict import load_config_file
-    from tests.ref_configs import pm_vae_gas, pm_vae_mnist
+    from tests.ref_configs import pm_vae_gas, pm_vae_mnist, vqvae_mnist
 
-    for name, ref in (("pm_vae_mnist", pm_vae_mnist()), ("pm_vae_gas", pm_vae_gas())):
+    for name, ref in (("pm_vae_mnist", pm_vae_mnist()), ("pm_vae_gas", pm_vae_gas()), ("vqvae_mnist", vqvae_mnist())):
         cfg = load_config_file(os.path.join(ROOT, "configs", name + ".py")).to_dict()
         assert cfg == ref, name
 
@@ -106,6 +106,24 @@ def test_golden_fixture_matches_oracle():
     grads = torch.autograd.grad(loss, list(leaves.values()))
     for k, g in zip(leaves, grads):
         np.testing.assert_allclose(g.numpy(), z["grad/" + k], rtol=1e-9, atol=1e-13)
+
+
+def test_vqvae_golden_fixture_matches_oracle():
+    from oracle import vqvae_oracle as VO
+    from tests.golden.make_golden_vqvae import CFG
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "vqvae_tiny.npz"))
+    p = {k[len("param/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    st = {k[len("state/"):]: torch.tensor(z[k]) for k in z.files if k.startswith("state/")}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, aux, out, new_state = VO.vqvae_loss(leaves, st, CFG, torch.tensor(z["x"]), True)
+    assert loss.item() == pytest.approx(float(z["loss"]), rel=1e-12)
+    assert aux["perplexity"].item() == pytest.approx(float(z["perplexity"]), rel=1e-12)
+    assert np.array_equal(out["vq_output"]["encoding_indices"].numpy(), z["encoding_indices"])
+    for k, g in zip(leaves, torch.autograd.grad(loss, list(leaves.values()))):
+        np.testing.assert_allclose(g.numpy(), z["grad/" + k], rtol=1e-9, atol=1e-13)
+    for k, v in new_state.items():
+        np.testing.assert_allclose(v.numpy(), z["new_state/" + k], rtol=1e-12)
 
 
 def test_optimizer_chain_lowering():

@@ -192,3 +192,121 @@ def test_gradcheck_small_model():
             flat[idx] = old
             fd = (lp - lm) / 2e-6
             assert grads[name].reshape(-1)[idx].item() == pytest.approx(fd, rel=2e-5, abs=1e-8), name
+
+
+# ----------------------------------------------------------------------------------------------
+# VQ-VAE oracle (oracle/vqvae_oracle.py) - SURVEY.md 8c item (x)
+# ----------------------------------------------------------------------------------------------
+def _vq_state(D, K, gen, decay_counter=0):
+    from oracle import vqvae_oracle as VO
+
+    st = VO.init_state({"embedding_dim": D, "num_embeddings": K}, seed=int(torch.randint(0, 1000, (1,), generator=gen)))
+    return st
+
+
+def test_vq_quantize_rows_are_codebook_rows_and_straight_through():
+    from oracle import vqvae_oracle as VO
+
+    gen = torch.Generator().manual_seed(0)
+    D, K = 8, 13
+    st = _vq_state(D, K, gen)
+    z = (torch.randn((5, 3, 3, D), generator=gen) * 0.4).requires_grad_(True)
+    out, new = VO.vector_quantizer_ema(st, z, 0.25, 0.99, True)
+    E = st["vq/embeddings"]
+    q = out["quantize"].detach().reshape(-1, D)
+    idx = out["encoding_indices"].reshape(-1)
+    assert torch.allclose(q, E.t()[idx], atol=1e-15)                    # rows of quantize are codebook rows
+    # brute-force nearest neighbour (cdist) agrees with the |x|^2 - 2xE + |e|^2 form
+    assert torch.equal(idx, torch.cdist(z.detach().reshape(-1, D), E.t()).argmin(1))
+    w = torch.randn(out["quantize"].shape, generator=gen)
+    (out["quantize"] * w).sum().backward()
+    assert torch.allclose(z.grad, w)                                    # straight-through: d quantize / d z = I
+    assert 1.0 <= out["perplexity"].item() <= K
+    assert out["encodings"].sum(1).eq(1).all() and out["encodings"].shape == (45, K)
+    assert out["loss"].item() == pytest.approx(0.25 * ((q.reshape(z.shape) - z.detach()) ** 2).mean().item())
+
+
+def test_vq_perplexity_extremes():
+    from oracle import vqvae_oracle as VO
+
+    D, K = 4, 6
+    st = VO.init_state({"embedding_dim": D, "num_embeddings": K}, seed=1)
+    E = st["vq/embeddings"]
+    same = E[:, 2].reshape(1, D).repeat(12, 1)
+    out, _ = VO.vector_quantizer_ema(st, same, 0.25, 0.99, False)
+    assert out["perplexity"].item() == pytest.approx(1.0, abs=1e-8)
+    each = E.t().repeat(2, 1)                                           # every code used equally often
+    out, _ = VO.vector_quantizer_ema(st, each, 0.25, 0.99, False)
+    assert out["perplexity"].item() == pytest.approx(K, rel=1e-8)
+
+
+def test_vq_ema_decay_zero_is_one_kmeans_step():
+    """decay 0: hidden = value, debias 1/(1-0) = 1, so the new codebook is the (Laplace-smoothed)
+    mean of the vectors assigned to each code - one batch k-means step."""
+    from oracle import vqvae_oracle as VO
+
+    gen = torch.Generator().manual_seed(3)
+    D, K = 5, 4
+    st = VO.init_state({"embedding_dim": D, "num_embeddings": K}, seed=4)
+    z = torch.randn((400, D), generator=gen) * 0.5
+    out, new = VO.vector_quantizer_ema(st, z, 0.25, 0.0, True)
+    idx = out["encoding_indices"]
+    for k in range(K):
+        members = z[idx == k]
+        assert len(members) > 0
+        n = 400.0
+        cs = (len(members) + 1e-5) / (n + K * 1e-5) * n
+        assert torch.allclose(new["vq/embeddings"][:, k], members.sum(0) / cs, atol=1e-12)
+        assert torch.allclose(new["vq/embeddings"][:, k], members.mean(0), rtol=1e-4)
+    assert int(new["vq/ema_dw/counter"]) == 1 and int(st["vq/ema_dw/counter"]) == 0     # input state untouched
+
+
+def test_vq_ema_zero_debias_by_hand():
+    from oracle import vqvae_oracle as VO
+
+    st = {"e/hidden": torch.zeros(2), "e/average": torch.zeros(2), "e/counter": torch.tensor(0)}
+    a1 = VO.ema_update(st, "e", torch.tensor([1.0, 3.0]), 0.9)
+    assert torch.allclose(a1, torch.tensor([1.0, 3.0]))                 # first average = first value
+    a2 = VO.ema_update(st, "e", torch.tensor([2.0, 3.0]), 0.9)
+    # hidden = 0.9*0.1*[1,3] + 0.1*[2,3]; / (1 - 0.81)
+    assert torch.allclose(a2, torch.tensor([(0.09 + 0.2) / 0.19, (0.27 + 0.3) / 0.19]))
+
+
+def test_vqvae_shapes_and_param_count():
+    from oracle import vqvae_oracle as VO
+    from tests.ref_configs import vqvae_mnist
+
+    cfg = vqvae_mnist()
+    assert O.same_padding(28, 4, 2) == (1, 1) and O.same_padding(14, 4, 2) == (1, 1)
+    assert O.conv_transpose_padding(4, 2, "SAME") == (2, 2)
+    p = VO.init_params(cfg["model"], 1)
+    assert sum(t.numel() for t in p.values()) == 88002                  # SURVEY.md 8a row 12: 40 464 + 47 538
+    st = VO.init_state(cfg["model"])
+    x = torch.rand(2, 28, 28, 1)
+    out, _ = VO.vqvae_forward(p, st, cfg["model"], x, False)
+    assert out["z"].shape == (2, 7, 7, 64) and out["reconstruction"].shape == (2, 28, 28, 1)
+    assert out["vq_output"]["encoding_indices"].shape == (2, 7, 7)
+    # at init log_scale = 0: scale = 1 + 1e-5
+    ll = O.normal_log_prob(x, out["reconstruction"], torch.tensor(1.0 + 1e-5)).reshape(2, -1).sum(1)
+    assert out["reconstruction_loss"].item() == pytest.approx(-ll.mean().item(), rel=1e-12)
+
+
+def test_vqvae_gradcheck_small():
+    """finite differences (float64) through encoder -> straight-through VQ -> decoder -> loss"""
+    from oracle import vqvae_oracle as VO
+    from tests.golden.make_golden_vqvae import CFG
+
+    p = VO.init_params(CFG["model"], 1, seed=3)
+    st = VO.init_state(CFG["model"], seed=4)
+    x = torch.rand(2, 12, 12, 1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, _, out, _ = VO.vqvae_loss(leaves, st, CFG, x, True)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    gen = torch.Generator().manual_seed(0)
+    for name in ("decoder/dec_2/w", "decoder/log_scale", "decoder/res3x3_0/w", "decoder/dec_1/b"):
+        d = torch.randn(p[name].shape, generator=gen)
+        h = 1e-6
+        lp = VO.vqvae_loss({**p, name: p[name] + h * d}, st, CFG, x, True)[0]
+        lm = VO.vqvae_loss({**p, name: p[name] - h * d}, st, CFG, x, True)[0]
+        fd = (lp - lm).item() / (2 * h)
+        assert fd == pytest.approx((grads[name] * d).sum().item(), rel=1e-5), name
