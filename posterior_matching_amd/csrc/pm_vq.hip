@@ -26,50 +26,93 @@ __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ 
         for (int j = i; j < D * K; j += gridDim.x * 256) dw[j] = 0.f;
 }
 
-// One wave per row of z.
-__global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict__ z, const float* __restrict__ emb,
-                                                         const float* __restrict__ dots, const float* __restrict__ e2,
-                                                         int* __restrict__ idx_out, float* __restrict__ quant,
-                                                         float* __restrict__ commit_grad, float* __restrict__ sqerr,
-                                                         float* __restrict__ counts, float* __restrict__ dw, int N, int D,
-                                                         int K, float commit_coef) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const float* zr = z + (size_t)row * D;
-    float x2 = 0.f;
-    for (int d = lane; d < D; d += 64) x2 = fmaf(zr[d], zr[d], x2);
-    x2 = pm_wave_sum(x2);
-    // nearest code; ties -> lowest index (argmax(-dist) returns the first maximum)
-    float best = INFINITY;
-    int bi = 0x7fffffff;
-    const float* dr = dots + (size_t)row * K;
-    for (int k = lane; k < K; k += 64) {
-        const float dist = x2 - 2.f * dr[k] + e2[k];
-        if (dist < best) { best = dist; bi = k; }      // k ascends within a lane: strict < keeps the first
-    }
+// A 16-lane group per row of z (4 rows in flight per wave), VQ_ITERS rows per group.  The EMA
+// statistics (dw[:, idx] += z, counts[idx] += 1) are accumulated in an LDS copy of the [D, K] table
+// first: early in training a handful of codes takes every row (perplexity 2-5), and 800 k global
+// atomics onto ~300 addresses serialise in L2 (measured: 135 us for N = 12544).  Only the columns a
+// workgroup touched are flushed to global memory.
+constexpr int VQ_WAVES = 8;
+constexpr int VQ_ITERS = 2;   // rows per 16-lane group -> 8 waves x 4 groups x 2 = 64 rows per workgroup
+constexpr int VQ_ROWS_PER_WG = VQ_WAVES * 4 * VQ_ITERS;
+
+__device__ __forceinline__ float group16_sum(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool LDS_STATS>
+__global__ __launch_bounds__(64 * VQ_WAVES) void vq_select_kernel(
+    const float* __restrict__ z, const float* __restrict__ emb, const float* __restrict__ dots,
+    const float* __restrict__ e2, int* __restrict__ idx_out, float* __restrict__ quant,
+    float* __restrict__ commit_grad, float* __restrict__ sqerr, float* __restrict__ counts, float* __restrict__ dw,
+    int N, int D, int K, float commit_coef) {
+    extern __shared__ float vq_smem[];
+    float* dwl = vq_smem;                                      // [D][K]   (LDS_STATS && dw)
+    float* cntl = vq_smem + (LDS_STATS && dw ? D * K : 0);     // [K]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int sl = lane & 15;                                  // lane within the row's group
+    if (LDS_STATS) {
+        if (dw)
+            for (int j = threadIdx.x; j < D * K; j += 64 * VQ_WAVES) dwl[j] = 0.f;
+        for (int k = threadIdx.x; k < K; k += 64 * VQ_WAVES) cntl[k] = 0.f;
+        __syncthreads();
     }
-    if (bi >= K) bi = 0;                                // all-NaN row: argmax of NaNs is index 0
-    float se = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float q = emb[(size_t)d * K + bi];
-        const float zv = zr[d];
-        const float diff = q - zv;
-        se = fmaf(diff, diff, se);
-        quant[(size_t)row * D + d] = q;
-        if (commit_grad) commit_grad[(size_t)row * D + d] = -commit_coef * diff;
-        if (dw) atomicAdd(dw + (size_t)d * K + bi, zv);
+    const int row0 = blockIdx.x * VQ_ROWS_PER_WG + (wave * 4 + (lane >> 4)) * VQ_ITERS;
+    for (int rr = 0; rr < VQ_ITERS; ++rr) {
+        const int row = row0 + rr;
+        const bool live = row < N;                             // uniform within the 16-lane group
+        const int rrow = live ? row : 0;                       // dead groups redo row 0 and store nothing
+        const float* zr = z + (size_t)rrow * D;
+        float x2 = 0.f;
+        for (int d = sl; d < D; d += 16) x2 = fmaf(zr[d], zr[d], x2);
+        x2 = group16_sum(x2);
+        // nearest code; ties -> lowest index (argmax(-dist) returns the first maximum)
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+        const float* dr = dots + (size_t)rrow * K;
+        for (int k = sl; k < K; k += 16) {
+            const float dist = x2 - 2.f * dr[k] + e2[k];
+            if (dist < best) { best = dist; bi = k; }          // k ascends within a lane: strict < keeps the first
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (bi >= K) bi = 0;                                   // all-NaN row: argmax of NaNs is index 0
+        float se = 0.f;
+        for (int d = sl; d < D; d += 16) {
+            const float q = emb[(size_t)d * K + bi];
+            const float zv = zr[d];
+            const float diff = q - zv;
+            se = fmaf(diff, diff, se);
+            if (live) {
+                quant[(size_t)row * D + d] = q;
+                if (commit_grad) commit_grad[(size_t)row * D + d] = -commit_coef * diff;
+                if (dw) {
+                    if (LDS_STATS) atomicAdd(dwl + d * K + bi, zv);
+                    else atomicAdd(dw + (size_t)d * K + bi, zv);
+                }
+            }
+        }
+        se = group16_sum(se);
+        if (sl == 0 && live) {
+            idx_out[row] = bi;
+            sqerr[row] = se;
+            if (LDS_STATS) atomicAdd(cntl + bi, 1.f);
+            else atomicAdd(counts + bi, 1.f);
+        }
     }
-    se = pm_wave_sum(se);
-    if (lane == 0) {
-        idx_out[row] = bi;
-        sqerr[row] = se;
-        atomicAdd(counts + bi, 1.f);
+    if (LDS_STATS) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += 64 * VQ_WAVES)
+            if (cntl[k] > 0.f) atomicAdd(counts + k, cntl[k]);
+        if (dw)
+            for (int j = threadIdx.x; j < D * K; j += 64 * VQ_WAVES)
+                if (cntl[j % K] > 0.f) atomicAdd(dw + j, dwl[j]);
     }
 }
 
@@ -161,8 +204,22 @@ extern "C" int pm_vq_select(pm_stream_t stream, const float* z, const float* emb
     hipStream_t s = (hipStream_t)stream;
     const int pb = dw ? (D * K + 255) / 256 : (K + 255) / 256;
     hipLaunchKernelGGL(vq_prep_kernel, dim3(pb), dim3(256), 0, s, emb, e2, counts, dw, D, K);
-    hipLaunchKernelGGL(vq_select_kernel, dim3((N + 3) / 4), dim3(256), 0, s, z, emb, dots, e2, idx, quant, commit_grad,
-                       sqerr, counts, dw, N, D, K, commit_coef);
+    const int rows_per_wg = VQ_ROWS_PER_WG;
+    const dim3 grid((N + rows_per_wg - 1) / rows_per_wg), block(64 * VQ_WAVES);
+    const size_t lds = ((dw ? (size_t)D * K : 0) + K) * sizeof(float);
+    if (lds <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {   // > 64 KB of dynamic LDS needs the opt-in (K = 512, D = 64 is 130 KB)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_select_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(vq_select_kernel<true>, grid, block, lds, s, z, emb, dots, e2, idx, quant, commit_grad, sqerr,
+                           counts, dw, N, D, K, commit_coef);
+    } else {
+        hipLaunchKernelGGL(vq_select_kernel<false>, grid, block, 0, s, z, emb, dots, e2, idx, quant, commit_grad, sqerr,
+                           counts, dw, N, D, K, commit_coef);
+    }
     return pm_check_launch("pm_vq_select");
 }
 
