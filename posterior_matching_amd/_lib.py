@@ -35,6 +35,7 @@ class GatherDesc(C.Structure):
         ("in_gs", C.c_longlong), ("w_gs", C.c_longlong), ("out_gs", C.c_longlong), ("bias_gs", C.c_longlong),
         ("in_act", C.c_int), ("out_act", C.c_int), ("aux_act", C.c_int),
         ("slope", C.c_float),
+        ("off_x", C.c_int), ("kws", C.c_int),
     ]
 
 
@@ -64,6 +65,7 @@ class SplitJob(C.Structure):
         ("taps", C.c_int), ("C", C.c_int), ("N", C.c_int), ("npad", C.c_int),
         ("wts", C.c_int), ("wcs", C.c_int), ("wns", C.c_int),
         ("first_block", C.c_int), ("num_blocks", C.c_int),
+        ("kw", C.c_int), ("kws", C.c_int),
     ]
 
 

@@ -28,8 +28,8 @@ namespace {
 
 struct Geom {
     int B, IH, IW, C, OH, OW, N, KH, KW;
-    int a, cs, off, d;
-    int wts, wcs, wns;
+    int a, cs, off, offx, d;   // off: row (y) offset of the index rule, offx: column (x) offset
+    int wts, wcs, wns, kws;    // kws: taps per kernel ROW in the weight layout (>= KW; sub-kernels of masked convs)
     int M, K;
     int in_act, out_act, aux_act;
     float slope;
@@ -145,7 +145,7 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
             decode_row(g, m, b, p, q);
             rbase[j] = b * g.IH * g.IW * g.C;
             rpy[j] = p * g.a + g.off;
-            rqx[j] = q * g.a + g.off;
+            rqx[j] = q * g.a + g.offx;
         } else {
             rbase[j] = 0;
             rpy[j] = ROW_INVALID;
@@ -159,7 +159,7 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
     // natural row order only (weight gradient): advance every row by 128 = sb images + sp rows + sq pixels
     __device__ __forceinline__ void advance_rows(const Geom& g, int m_next0, int sb, int sp, int sq) {
         const int img = g.IH * g.IW * g.C;
-        const int wlim = g.OW * g.a + g.off, hlim = g.OH * g.a + g.off;
+        const int wlim = g.OW * g.a + g.offx, hlim = g.OH * g.a + g.off;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             if (m_next0 + r0 + j * RPP >= g.M) {
@@ -312,7 +312,7 @@ struct LoaderV1 {  // any C (used for C = 1, 2): scalar gathers, k flattened ove
                 if (!natural) decode_row(g, m, b, p, q);
                 int sy, sx;
                 if (coord_ok<0>(p * g.a + g.off + ky * g.cs, g.d, g.IH, sy) &&
-                    coord_ok<0>(q * g.a + g.off + kx * g.cs, g.d, g.IW, sx)) {
+                    coord_ok<0>(q * g.a + g.offx + kx * g.cs, g.d, g.IW, sx)) {
                     v = pm_act(in[((b * g.IH + sy) * g.IW + sx) * g.C + c], g.in_act, g.slope);
                 }
             }
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
                 int tj = kk / g.C;
                 int c = kk - tj * g.C;
                 int jy = tj / nvx;
-                int tap = tl->ky[jy] * g.KW + tl->kx[tj - jy * nvx];
+                int tap = tl->ky[jy] * g.kws + tl->kx[tj - jy * nvx];
                 v = w[(size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)(boff[j] - kl * g.wcs)];
             }
             breg[j] = v;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
         if constexpr (TU) {
             const int ky = tl->ky[jy], kx = tl->kx[jx];
             la.load_tap(g, in, ky, kx, c0, true);
-            load_b_tap(ky * g.KW + kx, c0);
+            load_b_tap(ky * g.kws + kx, c0);
             c0 += BK;
             if (c0 >= g.C) {
                 c0 = 0;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
         decode_row(g, m, b, pp, q);
         rbase = b * g.IH * g.IW * g.C + 4 * h;
         rpy = pp * g.a + g.off;
-        rqx = q * g.a + g.off;
+        rqx = q * g.a + g.offx;
         rowoff = ((b * g.OH + pp) * g.OW + q) * g.N;
     }
     {
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
             k.dy = ky * g.cs;
             k.dx = kx * g.cs;
             k.c0 = cc * BK;
-            k.woff = (ky * g.KW + kx) * g.wts + cc * BK * g.wcs;
+            k.woff = (ky * g.kws + kx) * g.wts + cc * BK * g.wcs;
         }
         kd[s] = k;
     }
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
             decode_row(g, m, b, pp, q);
             rbase = b * g.IH * g.IW * g.C + 8 * h;
             rpy = pp * g.a + g.off;
-            rqx = q * g.a + g.off;
+            rqx = q * g.a + g.offx;
             rowoff = ((b * g.OH + pp) * g.OW + q) * g.N;
         }
         unsigned my = 0u, mx = 0u;
@@ -1106,7 +1106,7 @@ template <int RN, int DD>
 void launch_direct_bf16(hipStream_t s, const GemmArgs& a, dim3 grid, const __bf16* ws, int npad, long long plane) {
     const Geom& g = a.g;
     const bool dense = DD == 1 && g.KH == 1 && g.KW == 1 && g.IH == 1 && g.IW == 1 && g.OH == 1 && g.OW == 1 &&
-                       g.a == 1 && g.off == 0;
+                       g.a == 1 && g.off == 0 && g.offx == 0;
 #define PM_LB(ACT)                                                                                                   \
     do {                                                                                                              \
         if (dense) hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, 1, ACT, true>), grid, dim3(256), 0, s, a, ws, npad, plane); \
@@ -1129,6 +1129,7 @@ struct SplitJob {
     int taps, C, N, npad;
     int wts, wcs, wns;
     int first_block, num_blocks;
+    int kw, kws;         // compact tap t reads weight-layout tap (t / kw) * kws + t % kw
 };
 
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ params, __bf16* __restrict__ out,
@@ -1147,7 +1148,8 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     const int tap = (int)(tc / (job.C / BK));
     float v = 0.f;
     if (n < job.N)
-        v = params[job.src_off + (long long)tap * job.wts + (long long)(cc * BK + k) * job.wcs + (long long)n * job.wns];
+        v = params[job.src_off + (long long)((tap / job.kw) * job.kws + tap % job.kw) * job.wts +
+                   (long long)(cc * BK + k) * job.wcs + (long long)n * job.wns];
     const __bf16 hi = (__bf16)v;
     const __bf16 lo = (__bf16)(v - (float)hi);
     out[job.dst_off + e] = hi;
@@ -1340,7 +1342,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
             float s = red[e] + red[CB * NB + e] + red[2 * CB * NB + e] + red[3 * CB * NB + e];
             int tap = kk / g.C;
             int c = kk - tap * g.C;
-            atomicAdd(dw + (size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
+            const int wtap = (tap / g.KW) * g.kws + tap % g.KW;   // compact tap -> tap of the weight layout
+            atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
         }
     }
     if (do_bias && h == 0) {
@@ -1545,7 +1548,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
             float s = red[e] + red[CB * NB + e] + red[2 * CB * NB + e] + red[3 * CB * NB + e];
             int tap = kk / g.C;
             int c = kk - tap * g.C;
-            atomicAdd(dw + (size_t)tap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
+            const int wtap = (tap / g.KW) * g.kws + tap % g.KW;   // compact tap -> tap of the weight layout
+            atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
         }
     }
     if (do_bias && h == 0) {
@@ -1570,13 +1574,16 @@ bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     // 32-bit element offsets inside one group's tensors and weights
     if (M * d->N >= 0x7fffffffLL || (long long)d->B * d->IH * d->IW * d->C >= 0x7fffffffLL) return false;
     if (d->wts < 0 || d->wcs < 0 || d->wns < 0) return false;
-    long long wmax = (long long)(d->KH * d->KW - 1) * d->wts + (long long)(d->C - 1) * d->wcs +
+    if (d->kws < d->KW) return false;
+    long long wmax = (long long)((d->KH - 1) * d->kws + d->KW - 1) * d->wts + (long long)(d->C - 1) * d->wcs +
                      (long long)(d->N - 1) * d->wns;
     if (wmax >= 0x7fffffffLL) return false;
-    if ((long long)(d->OH + d->OW + 2 * MAXTAP) * d->a + (d->off < 0 ? -d->off : d->off) >= (1 << 27)) return false;
+    if ((long long)(d->OH + d->OW + 2 * MAXTAP) * d->a + (d->off < 0 ? -d->off : d->off) +
+            (d->off_x < 0 ? -d->off_x : d->off_x) >= (1 << 27))
+        return false;
     g.B = d->B; g.IH = d->IH; g.IW = d->IW; g.C = d->C; g.OH = d->OH; g.OW = d->OW; g.N = d->N;
-    g.KH = d->KH; g.KW = d->KW; g.a = d->a; g.cs = d->cs; g.off = d->off; g.d = d->d;
-    g.wts = d->wts; g.wcs = d->wcs; g.wns = d->wns; g.M = (int)M; g.K = (int)K;
+    g.KH = d->KH; g.KW = d->KW; g.a = d->a; g.cs = d->cs; g.off = d->off; g.offx = d->off_x; g.d = d->d;
+    g.wts = d->wts; g.wcs = d->wcs; g.wns = d->wns; g.kws = d->kws; g.M = (int)M; g.K = (int)K;
     g.in_act = d->in_act; g.out_act = d->out_act; g.aux_act = d->aux_act; g.slope = d->slope;
     g.PY = g.PX = 1;
     if (class_major) {

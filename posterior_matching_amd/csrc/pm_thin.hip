@@ -20,6 +20,7 @@ struct ThinArgs {
 bool fill_thin(const pm_gather_desc* d, ThinArgs& t) {
     if (!d || d->groups != 1 || d->d != 1 || d->B <= 0 || d->a <= 0) return false;
     if (d->cs != 1 && d->cs != -1) return false;
+    if (d->off_x != d->off || d->kws != d->KW) return false;   // no sub-kernel form here
     long long M = (long long)d->B * d->OH * d->OW;
     if (M >= 0x7fffffffLL / 64 || (long long)d->B * d->IH * d->IW * d->C >= 0x7fffffffLL) return false;
     t.B = d->B; t.IH = d->IH; t.IW = d->IW; t.C = d->C; t.OH = d->OH; t.OW = d->OW; t.N = d->N;

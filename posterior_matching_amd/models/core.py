@@ -126,6 +126,7 @@ class ParamStore:
                 j.dst_off, j.plane = off, plane
                 j.taps, j.C, j.N, j.npad = d.KH * d.KW, d.C, d.N, npad
                 j.wts, j.wcs, j.wns = d.wts, d.wcs, d.wns
+                j.kw, j.kws = d.KW, d.kws
                 j.first_block, j.num_blocks = blk, (plane + 255) // 256
                 blk += j.num_blocks
                 off += 2 * plane

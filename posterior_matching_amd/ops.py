@@ -122,6 +122,13 @@ class LayerGeom:
     k: int = 1
     s: int = 1
     pad: int = 0  # pad_lo (conv) or pad_a (convT)
+    # masked convolution (PixelCNN `w *= mask`, reference pixel_cnn.py:392-422): the stored weight is
+    # [full_kh, full_kw, CI, CO]; only rows [0, kh) x columns [0, kw) of it are walked
+    kh: int = 0      # 0: square kernel k x k
+    kw: int = 0
+    pad_x: int = -1  # -1: same as pad
+    full_kh: int = 0
+    full_kw: int = 0
 
     @staticmethod
     def conv(ih, iw, ci, co, k, s, padding):
@@ -144,10 +151,26 @@ class LayerGeom:
     def dense(ci, co):
         return LayerGeom("dense", 1, 1, ci, 1, 1, co)
 
+    @staticmethod
+    def masked_conv(ih, iw, ci, co, full_kh, full_kw, valid_rows, valid_cols):
+        """Stride-1 SAME conv whose kernel mask keeps rows [0, valid_rows) x columns [0, valid_cols)
+        (every mask _make_kernel_constraint builds for num_hierarchies = 1 has this top-left form)."""
+        py, px = same_padding(ih, full_kh, 1)[0], same_padding(iw, full_kw, 1)[0]
+        return LayerGeom("conv", ih, iw, ci, ih, iw, co, k=0, s=1, pad=py, kh=valid_rows, kw=valid_cols, pad_x=px,
+                         full_kh=full_kh, full_kw=full_kw)
+
+    @property
+    def KH(self):
+        return self.kh or self.k
+
+    @property
+    def KW(self):
+        return self.kw or self.k
+
     @property
     def weight_shape(self):
         if self.kind == "conv":
-            return (self.k, self.k, self.CI, self.CO)
+            return (self.full_kh or self.k, self.full_kw or self.k, self.CI, self.CO)
         if self.kind == "convT":
             return (self.k, self.k, self.CO, self.CI)
         return (self.CI, self.CO)
@@ -157,7 +180,8 @@ class LayerGeom:
         w_ld overrides the dense weight's row stride (grouped column slices of a wider matrix)."""
         g = self
         d = GatherDesc()
-        d.B, d.KH, d.KW, d.groups = B, g.k, g.k, groups
+        d.B, d.KH, d.KW, d.groups = B, g.KH, g.KW, groups
+        d.kws = g.full_kw or g.KW
         d.in_gs, d.w_gs, d.out_gs, d.bias_gs = in_gs, w_gs, out_gs, bias_gs
         if mode == "dgrad":  # the gathered operand is dy, the produced one dx
             d.in_gs, d.out_gs = out_gs, in_gs
@@ -183,6 +207,9 @@ class LayerGeom:
             else:
                 d.a, d.cs, d.off, d.d = g.s, -1, g.pad, 1
                 d.wts, d.wcs, d.wns = g.CO * g.CI, g.CI, 1
+        d.off_x = d.off
+        if g.pad_x >= 0 and g.pad_x != g.pad:
+            d.off_x = -g.pad_x if fwd_like else g.pad_x
         return d
 
 
@@ -202,7 +229,7 @@ def _algorithmic_flops(d: GatherDesc) -> float:
     so neither the zero-dilation taps of the stride-2 transposed / data-gradient forms nor the
     padding taps at the image border are claimed as work."""
     vy = _valid_pairs(d.OH, d.IH, d.KH, d.a, d.cs, d.off, d.d)
-    vx = _valid_pairs(d.OW, d.IW, d.KW, d.a, d.cs, d.off, d.d)
+    vx = _valid_pairs(d.OW, d.IW, d.KW, d.a, d.cs, d.off_x, d.d)
     return 2.0 * d.B * vy * vx * d.C * d.N * d.groups
 
 

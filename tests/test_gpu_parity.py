@@ -510,3 +510,70 @@ def test_train_script_end_to_end(tmp_path):
     sys.path.insert(0, root)
     state = pickle.load(open(os.path.join(run, "train_state.pkl"), "rb"))
     assert state.step == 30 and len(state.params) == 37
+
+
+# ----------------------------------------------------------------------------------------------
+# masked convolutions (PixelCNN, reference pixel_cnn.py:392-422): sub-kernel form of the index rule
+# ----------------------------------------------------------------------------------------------
+MASKED_CASES = [
+    # B, H, Cin, Cout, full kernel, valid rows, valid cols     (pixel_cnn.py:392-422 with receptive field 3x3)
+    (3, 7, 256, 128, (3, 3), 2, 3),    # vertical stack
+    (3, 7, 256, 256, (3, 3), 2, 2),    # horizontal stack, 2F -> 2F
+    (2, 7, 128, 128, (5, 3), 2, 3),    # vertical_stack_init
+    (2, 7, 128, 128, (3, 3), 1, 3),    # horizontal_stack_up
+    (2, 7, 128, 128, (3, 3), 2, 1),    # horizontal_stack_left
+    (5, 16, 64, 32, (3, 3), 2, 2),     # CelebA-sized grid
+    (2, 7, 24, 40, (3, 3), 2, 2),      # C not a multiple of 32: f32 gather loaders
+]
+
+
+@pytest.mark.parametrize("B,H,ci,co,full,vr,vc", MASKED_CASES)
+@pytest.mark.parametrize("bf16x3", [False, True])
+def test_masked_conv_fwd_dgrad_wgrad(B, H, ci, co, full, vr, vc, bf16x3):
+    from posterior_matching_amd import ops
+    from posterior_matching_amd._lib import SplitJob
+    from posterior_matching_amd.ops import ACT_NONE, LayerGeom
+
+    gen = torch.Generator().manual_seed(B * 1000 + ci + vr * 10 + vc)
+    geom = LayerGeom.masked_conv(H, H, ci, co, full[0], full[1], vr, vc)
+    assert geom.weight_shape == (full[0], full[1], ci, co)
+    x = g32((B, H, H, ci), gen)
+    w = g32(geom.weight_shape, gen, 1.0 / math.sqrt(full[0] * full[1] * ci))
+    bias, dy = g32((co,), gen, 0.1), g32((B, H, H, co), gen)
+    mask = torch.zeros(full + (1, 1), dtype=F64)
+    mask[:vr, :vc] = 1.0
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    y = O.conv2d(xr, wr * mask, br, 1, "SAME")
+    y.backward(dy)
+
+    d = dev()
+    xd, wd, bd, dyd = x.float().to(d), w.float().to(d), bias.float().to(d), dy.float().to(d)
+    ws_f = ws_d = None
+    if bf16x3 and ci % 32 == 0 and co % 32 == 0:
+        def split(mode):
+            desc = geom._desc(1, mode)
+            npad = (desc.N + 31) // 32 * 32
+            plane = desc.KH * desc.KW * desc.C * npad
+            j = SplitJob()
+            j.src_off, j.dst_off, j.plane = 0, 0, plane
+            j.taps, j.C, j.N, j.npad = desc.KH * desc.KW, desc.C, desc.N, npad
+            j.wts, j.wcs, j.wns, j.kw, j.kws = desc.wts, desc.wcs, desc.wns, desc.KW, desc.kws
+            j.first_block, j.num_blocks = 0, (plane + 255) // 256
+            out = torch.zeros(2 * plane, dtype=torch.bfloat16, device=d)
+            jobs = torch.frombuffer(bytearray(bytes(j)), dtype=torch.uint8).to(d)
+            ops.split_weights(wd.reshape(-1), out, jobs, 1, j.num_blocks)
+            return out
+        ws_f, ws_d = split("fwd"), split("dgrad")
+    tol = 3e-5 if ws_f is not None else 2e-6
+    yd = torch.empty((B, H, H, co), device=d)
+    ops.layer_forward(geom, xd, wd, bd, yd, wsplit=ws_f)
+    assert rel_err(yd, y) < tol
+    dxd = torch.empty((B, H, H, ci), device=d)
+    ops.layer_dgrad(geom, dyd, wd, dxd, wsplit=ws_d)
+    assert rel_err(dxd, xr.grad) < tol
+    dwd, dbd = torch.zeros(geom.weight_shape, device=d), torch.zeros(co, device=d)
+    ops.layer_wgrad(geom, xd, dyd, dwd, dbd, bf16=bf16x3)
+    assert rel_err(dwd, wr.grad) < tol                    # masked taps: exactly zero on both sides
+    assert torch.equal(dwd.cpu()[vr:], torch.zeros_like(dwd.cpu()[vr:]))
+    assert torch.equal(dwd.cpu()[:, vc:], torch.zeros_like(dwd.cpu()[:, vc:]))
+    assert rel_err(dbd, br.grad) < 1e-5
