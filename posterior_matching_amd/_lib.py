@@ -100,6 +100,20 @@ SIGNATURES = {
     "pm_argmm_input_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _F],
     "pm_gmm_logprob_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "pm_gmm_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "pm_embed_fwd": [_P, _P, _P, _P, _LL, _I, _I],
+    "pm_embed_bwd": [_P, _P, _P, _P, _LL, _I, _I],
+    "pm_concat_elu_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_concat_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I],
+    "pm_gate_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_gate_bwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_rows_sum": [_P, _P, _P, _LL, _I, _I],
+    "pm_groups_sum": [_P, _P, _P, _LL, _I, _LL, _I],
+    "pm_elu_fwd": [_P, _P, _P, _LL],
+    "pm_elu_bwd": [_P, _P, _P, _P, _LL, _I],
+    "pm_categorical_ll_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_categorical_ll_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_neg_mean_loss": [_P, _P, _I, _F, _P, _P],
+    "pm_dropout_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
     "pm_pmvae_loss": [_P, _P, _P, _P, _I, C.POINTER(LossCfg), _P, _P, _P, _P, _P],
     "pm_adam_step": [_P, _P, _P, _P, _P, _LL, _LL, _P, C.POINTER(AdamCfg)],
     "pm_counter_increment": [_P, _P],

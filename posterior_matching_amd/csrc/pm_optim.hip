@@ -162,6 +162,28 @@ __global__ __launch_bounds__(256) void normal_fill_kernel(float* __restrict__ ou
     }
 }
 
+// hk.dropout keep mask, pre-scaled: out = (u >= rate) / (1 - rate), u ~ U[0,1) from the same Philox stream
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long long n, float rate,
+                                                             unsigned long long seed, const int* __restrict__ step_dev,
+                                                             int stream_id) {
+    const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+    const long long quads = (n + 3) / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    const float keep_scale = 1.f / (1.f - rate);
+    for (long long qd = (long long)blockIdx.x * 256 + threadIdx.x; qd < quads; qd += stride) {
+        unsigned c[4] = {(unsigned)qd, (unsigned)(qd >> 32), step, (unsigned)stream_id};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c[0], c[1], c[2], c[3], k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        for (int e = 0; e < 4; ++e)
+            if (qd * 4 + e < n) out[qd * 4 + e] = ((float)c[e] * 2.3283064365386963e-10f >= rate) ? keep_scale : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void axpy1_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += x[i];
@@ -226,6 +248,16 @@ int pm_zero_async(hipStream_t stream, void* ptr, size_t nbytes) {
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<unsigned*>(ptr),
                        nwords);
     return pm_check_launch("pm_zero_async");
+}
+
+extern "C" int pm_dropout_mask(pm_stream_t stream, float* out, long long n, float rate, unsigned long long seed,
+                               const int* step_dev, int stream_id) {
+    if (!out || n <= 0 || !(rate >= 0.f) || !(rate < 1.f)) return PM_EINVAL;
+    long long blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, rate, seed,
+                       step_dev, stream_id);
+    return pm_check_launch("pm_dropout_mask");
 }
 
 extern "C" int pm_fill_zero(pm_stream_t stream, void* ptr, long long nbytes) {

@@ -1,0 +1,312 @@
+// Row-wise (HBM-bound) pieces of the PixelCNN partial posterior, reference
+// posterior_matching/models/pixel_cnn.py:372-553.  The masked convolutions and hk.Linear layers run in
+// the gather-GEMM engine (pm_conv.hip); these kernels are what sits between them:
+//   embed        hk.Embed lookup of the code indices (:401) and its scatter-add gradient
+//   concat_elu   elu(concat[x, -x]) (:373-374), optionally times the dropout keep mask (:446, :508)
+//   gate         x += h_projection; sigmoid gating; residual (:455-460, :516-522, :565-574)
+//   rows_sum     gradient of the broadcast conditional projection: sum over the H*W positions
+//   elu          the final activation (:548)
+//   categorical  tfd.Categorical(logits).log_prob(value) summed per example (:53-63, :553)
+#include "pm_common.h"
+
+namespace {
+
+__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+__device__ __forceinline__ float elu_d(float v) { return v > 0.f ? 1.f : expf(v); }
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ idx, const float* __restrict__ table,
+                                                         float* __restrict__ out, long long total, int F, int K) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long r = i / F;
+    const int f = (int)(i - r * F);
+    int k = idx[r];
+    k = k < 0 ? 0 : (k >= K ? K - 1 : k);          // jnp indexing clamps out-of-range indices
+    out[i] = table[(size_t)k * F + f];
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ idx, const float* __restrict__ dout,
+                                                         float* __restrict__ dtable, long long total, int F, int K) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long r = i / F;
+    const int f = (int)(i - r * F);
+    int k = idx[r];
+    k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+    atomicAdd(dtable + (size_t)k * F + f, dout[i]);
+}
+
+// logical x = [a | b] (widths Ca, Cb; b may be absent) ; out[r] = [elu(x) | elu(-x)] * drop[r]
+__global__ __launch_bounds__(256) void concat_elu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ drop, float* __restrict__ out,
+                                                              long long R, int Ca, int Cb) {
+    const int C = Ca + Cb;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * C) return;
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const float v = c < Ca ? a[r * Ca + c] : b[r * Cb + (c - Ca)];
+    const size_t o = (size_t)r * 2 * C + c;
+    float p = elu_f(v), n = elu_f(-v);
+    if (drop) {
+        p *= drop[o];
+        n *= drop[o + C];
+    }
+    out[o] = p;
+    out[o + C] = n;
+}
+
+// da / db (+)= dout_pos * elu'(x) * drop_pos - dout_neg * elu'(-x) * drop_neg
+__global__ __launch_bounds__(256) void concat_elu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ drop,
+                                                              const float* __restrict__ dout, float* __restrict__ da,
+                                                              float* __restrict__ db, long long R, int Ca, int Cb,
+                                                              int accumulate) {
+    const int C = Ca + Cb;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * C) return;
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const bool first = c < Ca;
+    const size_t src = first ? (size_t)r * Ca + c : (size_t)r * Cb + (c - Ca);
+    const float v = first ? a[src] : b[src];
+    const size_t o = (size_t)r * 2 * C + c;
+    float gp = dout[o], gn = dout[o + C];
+    if (drop) {
+        gp *= drop[o];
+        gn *= drop[o + C];
+    }
+    const float g = gp * elu_d(v) - gn * elu_d(-v);
+    float* dst = first ? da : db;
+    if (!dst) return;
+    dst[src] = accumulate ? dst[src] + g : g;
+}
+
+// out = input + sigmoid(y_g + h_g) * (y_a + h_a);  y [R, 2F] = [activation | gate], h [B, 2F] broadcast over P rows
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ y, const float* __restrict__ h,
+                                                        const float* __restrict__ input, float* __restrict__ out,
+                                                        long long R, int F, int P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * F) return;
+    const long long r = i / F;
+    const int f = (int)(i - r * F);
+    float act = y[r * 2 * F + f], gate = y[r * 2 * F + F + f];
+    if (h) {
+        const long long bb = r / P;
+        act += h[bb * 2 * F + f];
+        gate += h[bb * 2 * F + F + f];
+    }
+    out[i] = input[i] + pm_sigmoid(gate) * act;
+}
+
+// dy [R, 2F]: d act = dout * s ; d gate = dout * act * s * (1 - s)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ y, const float* __restrict__ h,
+                                                        const float* __restrict__ dout, float* __restrict__ dy,
+                                                        long long R, int F, int P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * F) return;
+    const long long r = i / F;
+    const int f = (int)(i - r * F);
+    float act = y[r * 2 * F + f], gate = y[r * 2 * F + F + f];
+    if (h) {
+        const long long bb = r / P;
+        act += h[bb * 2 * F + f];
+        gate += h[bb * 2 * F + F + f];
+    }
+    const float s = pm_sigmoid(gate);
+    const float g = dout[i];
+    dy[r * 2 * F + f] = g * s;
+    dy[r * 2 * F + F + f] = g * act * s * (1.f - s);
+}
+
+// out[b, n] = sum_{p < P} x[(b*P + p), n]
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                        long long total, int N, int P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / N;
+    const int n = (int)(i - b * N);
+    const float* p = x + (size_t)b * P * N + n;
+    float s = 0.f;
+    for (int j = 0; j < P; ++j) s += p[(size_t)j * N];
+    out[i] = s;
+}
+
+// out[i] = sum_{g < G} x[g*stride + i]
+__global__ __launch_bounds__(256) void groups_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          long long n, int G, long long stride, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int g = 0; g < G; ++g) s += x[(size_t)g * stride + i];
+    out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void elu_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = elu_f(x[i]);
+}
+__global__ __launch_bounds__(256) void elu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                       float* __restrict__ dx, long long n, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = dout[i] * elu_d(x[i]);
+    dx[i] = accumulate ? dx[i] + g : g;
+}
+
+// One wave per row: log_softmax(logits[r])[idx[r]] ; ll[b] = sum over the P rows of example b (atomic).
+__global__ __launch_bounds__(256) void categorical_ll_fwd_kernel(const float* __restrict__ logits,
+                                                                  const int* __restrict__ idx, float* __restrict__ lse,
+                                                                  float* __restrict__ ll, long long R, int K, int P) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* lr = logits + (size_t)r * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, lr[k]);
+    mx = pm_wave_max(mx);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += expf(lr[k] - mx);
+    s = pm_wave_sum(s);
+    if (lane == 0) {
+        const float l = mx + logf(s);
+        lse[r] = l;
+        int k = idx[r];
+        k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+        atomicAdd(ll + r / P, lr[k] - l);
+    }
+}
+
+// dlogits[r, k] = g[b] * (onehot(idx[r])[k] - softmax(logits[r])[k])
+__global__ __launch_bounds__(256) void categorical_ll_bwd_kernel(const float* __restrict__ logits,
+                                                                  const int* __restrict__ idx,
+                                                                  const float* __restrict__ lse,
+                                                                  const float* __restrict__ g,
+                                                                  float* __restrict__ dlogits, long long R, int K, int P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * K) return;
+    const long long r = i / K;
+    const int k = (int)(i - r * K);
+    int t = idx[r];
+    t = t < 0 ? 0 : (t >= K ? K - 1 : t);
+    const float p = expf(logits[i] - lse[r]);
+    dlogits[i] = g[r / P] * ((k == t ? 1.f : 0.f) - p);
+}
+
+// loss = -mean_b ll[b] ; g_ll[b] = -grad_scale
+__global__ __launch_bounds__(256) void neg_mean_loss_kernel(const float* __restrict__ ll, int B, float grad_scale,
+                                                             float* __restrict__ out, float* __restrict__ g_ll) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        s += ll[i];
+        if (g_ll) g_ll[i] = -grad_scale;
+    }
+    s = pm_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = -(red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int pm_embed_fwd(pm_stream_t stream, const int* idx, const float* table, float* out, long long rows, int F,
+                            int K) {
+    if (!idx || !table || !out || rows <= 0 || F <= 0 || K <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, idx, table, out,
+                       rows * F, F, K);
+    return pm_check_launch("pm_embed_fwd");
+}
+
+extern "C" int pm_embed_bwd(pm_stream_t stream, const int* idx, const float* dout, float* dtable, long long rows, int F,
+                            int K) {
+    if (!idx || !dout || !dtable || rows <= 0 || F <= 0 || K <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, idx, dout, dtable,
+                       rows * F, F, K);
+    return pm_check_launch("pm_embed_bwd");
+}
+
+extern "C" int pm_concat_elu_fwd(pm_stream_t stream, const float* a, const float* b, const float* drop, float* out,
+                                 long long rows, int Ca, int Cb) {
+    if (!a || !out || rows <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && !b)) return PM_EINVAL;
+    hipLaunchKernelGGL(concat_elu_fwd_kernel, dim3(blocks_for(rows * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, b,
+                       drop, out, rows, Ca, Cb);
+    return pm_check_launch("pm_concat_elu_fwd");
+}
+
+extern "C" int pm_concat_elu_bwd(pm_stream_t stream, const float* a, const float* b, const float* drop,
+                                 const float* dout, float* da, float* db, long long rows, int Ca, int Cb,
+                                 int accumulate) {
+    if (!a || !dout || rows <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && !b)) return PM_EINVAL;
+    hipLaunchKernelGGL(concat_elu_bwd_kernel, dim3(blocks_for(rows * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, b,
+                       drop, dout, da, db, rows, Ca, Cb, accumulate);
+    return pm_check_launch("pm_concat_elu_bwd");
+}
+
+extern "C" int pm_gate_fwd(pm_stream_t stream, const float* y, const float* h, const float* input, float* out,
+                           long long rows, int F, int P) {
+    if (!y || !input || !out || rows <= 0 || F <= 0 || P <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, y, h, input, out,
+                       rows, F, P);
+    return pm_check_launch("pm_gate_fwd");
+}
+
+extern "C" int pm_gate_bwd(pm_stream_t stream, const float* y, const float* h, const float* dout, float* dy,
+                           long long rows, int F, int P) {
+    if (!y || !dout || !dy || rows <= 0 || F <= 0 || P <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, y, h, dout, dy,
+                       rows, F, P);
+    return pm_check_launch("pm_gate_bwd");
+}
+
+extern "C" int pm_rows_sum(pm_stream_t stream, const float* x, float* out, long long B, int N, int P) {
+    if (!x || !out || B <= 0 || N <= 0 || P <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(blocks_for(B * N)), dim3(256), 0, (hipStream_t)stream, x, out, B * N, N, P);
+    return pm_check_launch("pm_rows_sum");
+}
+
+extern "C" int pm_groups_sum(pm_stream_t stream, const float* x, float* out, long long n, int G, long long stride,
+                             int accumulate) {
+    if (!x || !out || n <= 0 || G <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(groups_sum_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, G, stride,
+                       accumulate);
+    return pm_check_launch("pm_groups_sum");
+}
+
+extern "C" int pm_elu_fwd(pm_stream_t stream, const float* x, float* out, long long n) {
+    if (!x || !out || n <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(elu_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    return pm_check_launch("pm_elu_fwd");
+}
+
+extern "C" int pm_elu_bwd(pm_stream_t stream, const float* x, const float* dout, float* dx, long long n, int accumulate) {
+    if (!x || !dout || !dx || n <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(elu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, dout, dx, n, accumulate);
+    return pm_check_launch("pm_elu_bwd");
+}
+
+extern "C" int pm_categorical_ll_fwd(pm_stream_t stream, const float* logits, const int* idx, float* lse, float* ll,
+                                     long long rows, int K, int P) {
+    if (!logits || !idx || !lse || !ll || rows <= 0 || K <= 0 || P <= 0 || rows % P != 0) return PM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (pm_zero_async(s, ll, (size_t)(rows / P) * sizeof(float))) return PM_ELAUNCH;
+    hipLaunchKernelGGL(categorical_ll_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, idx, lse, ll,
+                       rows, K, P);
+    return pm_check_launch("pm_categorical_ll_fwd");
+}
+
+extern "C" int pm_categorical_ll_bwd(pm_stream_t stream, const float* logits, const int* idx, const float* lse,
+                                     const float* g, float* dlogits, long long rows, int K, int P) {
+    if (!logits || !idx || !lse || !g || !dlogits || rows <= 0 || K <= 0 || P <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(categorical_ll_bwd_kernel, dim3(blocks_for(rows * K)), dim3(256), 0, (hipStream_t)stream, logits,
+                       idx, lse, g, dlogits, rows, K, P);
+    return pm_check_launch("pm_categorical_ll_bwd");
+}
+
+extern "C" int pm_neg_mean_loss(pm_stream_t stream, const float* ll, int B, float grad_scale, float* out, float* g_ll) {
+    if (!ll || !out || B <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(neg_mean_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ll, B, grad_scale, out, g_ll);
+    return pm_check_launch("pm_neg_mean_loss");
+}

@@ -229,3 +229,94 @@ class VQVAETrainStep:
         with torch.cuda.stream(self.stream):
             self.model(x, is_training=False)
         return self.read_metrics()
+
+
+class PMVQVAETrainStep:
+    """train_pm_vqvae.py:81-123 as one launch sequence: frozen VQ-VAE encode (is_training=False) ->
+    code indices; partial encoder on [x*b | b] -> conditional vector; loss = -mean PixelCNN.log_prob;
+    backward through the PixelCNN and the partial encoder only (trainable_predicate: every module
+    not under "vqvae/"), Adam with the exponential-decay schedule, step += 1."""
+
+    def __init__(self, vqvae, partial_encoder, pixel_cnn, optimizer: Chain, batch_size: int, x_shape, seed: int = 0,
+                 world_size: int = 1, rank: int = 0, external_dropout: bool = False):
+        from .models.core import ParamStore, Workspace
+
+        if vqvae.store is None:
+            vqvae.init(x_shape)
+        dev = vqvae.store.device
+        self.vqvae, self.penc, self.pcnn = vqvae, partial_encoder, pixel_cnn
+        self.B, self.world_size, self.rank, self.seed = batch_size, world_size, rank, seed
+        if getattr(pixel_cnn, "store", None) is None:
+            store, ws = ParamStore(), Workspace(dev)
+            partial_encoder.ws = pixel_cnn.ws = ws
+            xb_shape = tuple(x_shape[:-1]) + (2 * x_shape[-1],)
+            (cond_dim,) = partial_encoder.build(store, "partial_encoder", xb_shape)
+            pixel_cnn.build(store, "pixel_cnn", cond_dim)
+            store.allocate(dev, seed)
+        self.store, self.ws = pixel_cnn.store, pixel_cnn.ws
+        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        x_shape = tuple(x_shape)
+        self.x = torch.zeros((batch_size,) + x_shape, device=dev)
+        self.b = torch.zeros((batch_size,) + x_shape[:-1] + (1,), device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.metrics = torch.zeros(8, device=dev)
+        self.g_ll = torch.zeros(batch_size, device=dev)
+        self.dropout_masks = None          # parity tests set explicit masks (external_dropout)
+        self.external_dropout = external_dropout
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+
+    @property
+    def num_trainable_params(self) -> int:
+        return self.store.num_params
+
+    def forward(self, is_training: bool) -> torch.Tensor:
+        out = self.vqvae(self.x, is_training=False)                       # frozen: no EMA update, no gradient
+        idx = out["vq_output"]["encoding_indices"]
+        xob = self.ws.get("x_o_b", tuple(self.x.shape[:-1]) + (self.x.shape[-1] + self.b.shape[-1],))
+        ops.mask_concat(self.x, self.b, xob)
+        cond = self.penc(xob, is_training=is_training)
+        masks = self.dropout_masks if (self.external_dropout and is_training) else None
+        ll = self.pcnn.log_prob(idx, training=is_training, conditional_input=cond, dropout_masks=masks,
+                                seed=self.seed + self.rank, step_dev=self.step_dev)
+        ops.neg_mean_loss(ll, 1.0 / self.B, self.metrics, self.g_ll if is_training else None)
+        self._idx = idx
+        return ll
+
+    def _sequence(self) -> None:
+        s = self.store
+        self.forward(True)
+        ops.fill_zero(s.flat_g)
+        dcond = self.pcnn.backward(self.g_ll)
+        self.penc.backward(dcond)
+        self.ws.join_aux()
+        if self.world_size > 1:
+            from .parallel import allreduce_sum_
+
+            allreduce_sum_(s.flat_g)
+        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        s.split_all()
+        ops.counter_increment(self.step_dev)
+
+    def step(self) -> None:
+        with torch.cuda.stream(self.stream):
+            self._sequence()
+
+    def set_batch(self, x: torch.Tensor, b: torch.Tensor) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+            self.b.copy_(b.reshape(self.b.shape), non_blocking=True)
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def read_metrics(self) -> Dict[str, float]:
+        self.stream.synchronize()
+        return {"loss": self.metrics[0].item()}
+
+    def evaluate(self, x: torch.Tensor, b: torch.Tensor) -> Dict[str, float]:
+        self.set_batch(x, b)
+        with torch.cuda.stream(self.stream):
+            self.forward(False)
+        return self.read_metrics()

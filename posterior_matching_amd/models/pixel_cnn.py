@@ -1,0 +1,319 @@
+"""Host-side mirror of posterior_matching/models/pixel_cnn.py of the reference: the PixelCNN
+distribution used as partial posterior over VQ-VAE code indices (stage 2, train_pm_vqvae.py).
+
+Same constructor as the reference's `PixelCNN` (pixel_cnn.py:26-47) and the same `log_prob(value,
+training, conditional_input)` contract (:53-63); the arithmetic runs in libpmhip.so: the masked
+convolutions walk only the taps their mask keeps (sub-kernel form of the gather-GEMM engine), the
+per-block conditional projections (a new hk.Linear per gated block, :565-568) run as ONE grouped
+GEMM, and the row-wise glue (concat_elu, dropout, gating, categorical log-prob) are fused HBM-bound
+kernels (csrc/pm_pixelcnn.hip).  There is no autodiff: `backward(g_ll)` walks the stored buffers.
+
+Only num_hierarchies == 1 is implemented (every BASELINE config uses 1).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+from ..ops import ACT_NONE, LayerGeom
+from .core import Module, ParamStore
+
+
+def _kernel_plan(receptive_field_dims=(3, 3)):
+    """kernel sizes and valid (top-left) extents of pixel_cnn.py:389-422: name -> (kh, kw, valid_rows, valid_cols)"""
+    rows, cols = receptive_field_dims
+    return {
+        "vertical": (2 * rows - 3, cols, rows - 1, cols),
+        "horizontal": (3, cols, 2, cols // 2 + 1),
+        "vertical_init": (2 * rows - 1, cols, rows - 1, cols),
+        "horizontal_up": (3, cols, 1, cols),
+        "horizontal_left": (3, cols, 2, cols // 2),
+    }
+
+
+class _Layer:
+    def __init__(self, store: ParamStore, name: str, geom: LayerGeom, fan_in: int, split: bool = True):
+        self.g, self.w, self.b = geom, f"{name}/w", f"{name}/b"
+        store.add(self.w, geom.weight_shape, fan_in=fan_in)
+        store.add(self.b, (geom.CO,))
+        self.ws_f = store.request_split(self.w, geom, "fwd") if split else None
+        self.ws_d = store.request_split(self.w, geom, "dgrad") if split else None
+
+
+class _Block:
+    """one gated resnet block: names, layers, which tensors feed it"""
+
+    def __init__(self, name: str, stack: str, group: int):
+        self.name, self.stack, self.group = name, stack, group
+        self.conv1 = self.conv2 = self.linear = None
+
+
+class PixelCNN(Module):
+    """reference pixel_cnn.py:26-63 (+ the network :339-553)."""
+
+    def __init__(self, num_indices, image_shape, dropout=0.5, num_resnet=15, num_hierarchies=1, num_filters=128,
+                 receptive_field_dims=(3, 3), name: Optional[str] = None):
+        super().__init__(name)
+        if num_hierarchies != 1:
+            raise NotImplementedError("PixelCNN(num_hierarchies != 1) has no HIP path (no reference config uses it)")
+        self._event_shape = tuple(image_shape)
+        self._num_indices, self._dropout = num_indices, float(dropout)
+        self._num_resnet, self._num_filters = num_resnet, num_filters
+        self._receptive_field_dims = tuple(receptive_field_dims)
+
+    @property
+    def event_shape(self) -> Tuple[int, ...]:
+        return self._event_shape
+
+    # ------------------------------------------------------------------------------------------
+    def build(self, store: ParamStore, prefix: str, cond_dim: Optional[int]) -> None:
+        self.attach(store, prefix)
+        H, W = self._event_shape
+        F, K, R = self._num_filters, self._num_indices, self._num_resnet
+        plan = _kernel_plan(self._receptive_field_dims)
+        self._cond_dim = cond_dim
+        store.add(f"{prefix}/embed/embeddings", (K, F), fan_in=-1)             # hk.Embed: TruncatedNormal(stddev 1)
+
+        def mconv(name, kind, ci, co):
+            kh, kw, vr, vc = plan[kind]
+            return _Layer(store, f"{prefix}/{name}", LayerGeom.masked_conv(H, W, ci, co, kh, kw, vr, vc), kh * kw * ci)
+
+        self.v_init = mconv("vertical_init", "vertical_init", F, F)
+        self.h_up = mconv("horizontal_up", "horizontal_up", F, F)
+        self.h_left = mconv("horizontal_left", "horizontal_left", F, F)
+        self.blocks: List[_Block] = []
+        for phase in ("down", "up"):
+            for i in range(R):
+                for stack in ("vertical", "horizontal"):
+                    b = _Block(f"{phase}_{i}/{stack}", stack, len(self.blocks))
+                    b.conv1 = mconv(f"{b.name}/conv1", stack, 2 * F, F)
+                    lin_in = 0
+                    if phase == "down" and stack == "horizontal":
+                        lin_in = 2 * F
+                    elif phase == "up":
+                        lin_in = 2 * F if stack == "vertical" else 4 * F
+                    if lin_in:
+                        b.linear = _Layer(store, f"{prefix}/{b.name}/linear", LayerGeom.dense(lin_in, F), lin_in)
+                    b.conv2 = mconv(f"{b.name}/conv2", stack, 2 * F, 2 * F)
+                    self.blocks.append(b)
+        self.out_conv = _Layer(store, f"{prefix}/out_conv", LayerGeom.conv(H, W, F, K, 1, 1, "SAME"), F)
+        # the conditional projections: added back to back so that the G weight matrices [cond, 2F] (and
+        # the G biases) are adjacent in the flat parameter buffer = one grouped GEMM
+        if cond_dim is not None:
+            self.g_cond = LayerGeom.dense(cond_dim, 2 * F)
+            for b in self.blocks:
+                store.add(f"{prefix}/{b.name}/cond/w", (cond_dim, 2 * F), fan_in=-2)   # RandomNormal(stddev 1)
+            for b in self.blocks:
+                store.add(f"{prefix}/{b.name}/cond/b", (2 * F,))
+
+    # -- small helpers ------------------------------------------------------------------------
+    def _fwd(self, L: _Layer, x, out, res=None):
+        ops.layer_forward(L.g, x, self.store.p[L.w], self.store.p[L.b], out, res=res,
+                          wsplit=self.store.split_view(L.ws_f) if L.ws_f is not None else None)
+
+    def _wg(self, L: _Layer, x, dy):
+        self.wgrad(L.g, x, dy, self.store.g[L.w], self.store.g[L.b])
+
+    def _dg(self, L: _Layer, dy, dx, res=None):
+        ops.layer_dgrad(L.g, dy, self.store.p[L.w], dx, res=res,
+                        wsplit=self.store.split_view(L.ws_d) if L.ws_d is not None else None)
+
+    def _cond_kw(self, B):
+        F, cd, G = self._num_filters, self._cond_dim, len(self.blocks)
+        return dict(B=B, groups=G, in_gs=0, w_gs=cd * 2 * F, out_gs=B * 2 * F, bias_gs=2 * F)
+
+    def _cond_params(self, which):
+        first = self.blocks[0].name
+        src = self.store.p if which == "p" else self.store.g
+        return src[f"{self.prefix}/{first}/cond/w"], src[f"{self.prefix}/{first}/cond/b"]
+
+    # ------------------------------------------------------------------------------------------
+    def logits(self, value: torch.Tensor, training: bool = False, conditional_input: Optional[torch.Tensor] = None,
+               dropout_masks: Optional[Sequence[torch.Tensor]] = None, seed: int = 0, step_dev=None) -> torch.Tensor:
+        """_PixelCNNNetwork.__call__ (:372-553) -> logits [B,H,W,K].  value: int32 [B,H,W] code indices.
+        training=True applies hk.dropout with rate `dropout`: keep masks are drawn on the device (Philox,
+        keyed by seed / step / block) unless `dropout_masks` (one pre-scaled [B,H,W,2F] mask per gated
+        block in execution order) is given."""
+        H, W = self._event_shape
+        F, K = self._num_filters, self._num_indices
+        B = value.shape[0]
+        R, P = B * H * W, H * W
+        if (conditional_input is None) != (self._cond_dim is None):
+            raise ValueError("conditional_input must be given iff the network was built with a conditional_dim")
+        self._B, self._value = B, value
+        idx = value.reshape(-1)
+        sh = lambda c: (B, H, W, c)   # noqa: E731
+        emb = self.buf("embed", sh(F))
+        ops.embed_fwd(idx, self.P("embed/embeddings"), emb)
+        v = self.buf("v_init", sh(F))
+        self._fwd(self.v_init, emb, v)
+        h_up = self.buf("h_up", sh(F))
+        self._fwd(self.h_up, emb, h_up)
+        h = self.buf("h_init", sh(F))
+        self._fwd(self.h_left, emb, h, res=h_up)
+        hproj = None
+        if conditional_input is not None:
+            cond = conditional_input.reshape(B, -1)
+            self._cond = cond
+            hproj = self.buf("hproj", (len(self.blocks), B, 2 * F))
+            cw, cb = self._cond_params("p")
+            ops.layer_forward(self.g_cond, cond, cw, cb, hproj, **self._cond_kw(B))
+        self._hproj = hproj
+        rate = self._dropout if training else 0.0
+        self._drops: List[Optional[torch.Tensor]] = []
+        self._io: List[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]] = []
+
+        def run_block(blk: _Block, input_x, extra_a=None, extra_b=None):
+            n = blk.name
+            ce1 = self.buf(f"{n}/ce1", sh(2 * F))
+            ops.concat_elu_fwd(input_x, None, None, ce1)
+            x1 = self.buf(f"{n}/x1", sh(F))
+            if blk.linear is None:
+                self._fwd(blk.conv1, ce1, x1)
+            else:
+                x1a = self.buf(f"{n}/x1a", sh(F))
+                self._fwd(blk.conv1, ce1, x1a)
+                ce_e = self.buf(f"{n}/ce_e", (R, blk.linear.g.CI))
+                ops.concat_elu_fwd(extra_a, extra_b, None, ce_e)
+                self._fwd(blk.linear, ce_e, x1.view(R, F), res=x1a.view(R, F))
+            drop = None
+            if rate > 0.0:
+                if dropout_masks is not None:
+                    drop = dropout_masks[blk.group]
+                else:
+                    drop = self.buf(f"{n}/drop", sh(2 * F))
+                    ops.dropout_mask(drop, rate, seed, step_dev, stream_id=blk.group)
+            ce2 = self.buf(f"{n}/ce2", sh(2 * F))
+            ops.concat_elu_fwd(x1, None, drop, ce2)
+            y = self.buf(f"{n}/y", sh(2 * F))
+            self._fwd(blk.conv2, ce2, y)
+            out = self.buf(f"{n}/out", sh(F))
+            ops.gate_fwd(y, hproj[blk.group] if hproj is not None else None, input_x, out, P)
+            self._drops.append(drop)
+            self._io.append((input_x, extra_a, extra_b))
+            return out
+
+        nres = self._num_resnet
+        V, Hs = [v], [h]
+        for i in range(nres):                                   # down pass (:427-460)
+            v = run_block(self.blocks[2 * i], V[-1])
+            V.append(v)
+            h = run_block(self.blocks[2 * i + 1], Hs[-1], extra_a=v)
+            Hs.append(h)
+        up_v, up_h = V.pop(), Hs.pop()
+        for i in range(nres):                                   # up pass (:487-522)
+            up_v = run_block(self.blocks[2 * nres + 2 * i], up_v, extra_a=V.pop())
+            up_h = run_block(self.blocks[2 * nres + 2 * i + 1], up_h, extra_a=up_v, extra_b=Hs.pop())
+        self._up_h = up_h
+        x_out = self.buf("x_out", sh(F))
+        ops.elu_fwd(up_h, x_out)
+        logits = self.buf("logits", sh(K))
+        self._fwd(self.out_conv, x_out, logits)
+        self._emb, self._v0, self._h0 = emb, self.buf("v_init", sh(F)), self.buf("h_init", sh(F))
+        return logits
+
+    def log_prob(self, value: torch.Tensor, training: bool = False, conditional_input: Optional[torch.Tensor] = None,
+                 dropout_masks=None, seed: int = 0, step_dev=None) -> torch.Tensor:
+        """reference pixel_cnn.py:53-63: Categorical(logits).log_prob(value) summed per example -> [B]."""
+        H, W = self._event_shape
+        logits = self.logits(value, training, conditional_input, dropout_masks, seed, step_dev)
+        B = value.shape[0]
+        self._lse = self.buf("lse", (B * H * W,))
+        ll = self.buf("ll", (B,))
+        ops.categorical_ll_fwd(logits.view(B * H * W, -1), value.reshape(-1), self._lse, ll, H * W)
+        self._logits = logits
+        return ll
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self, g_ll: torch.Tensor) -> Optional[torch.Tensor]:
+        """g_ll [B] = d loss / d log_prob.  Accumulates parameter gradients; returns d loss / d
+        conditional_input [B, cond_dim] (None without conditioning)."""
+        H, W = self._event_shape
+        F, K = self._num_filters, self._num_indices
+        B = self._B
+        R, P = B * H * W, H * W
+        sh = lambda c: (B, H, W, c)   # noqa: E731
+        nres, G = self._num_resnet, len(self.blocks)
+        dlogits = self.buf("dlogits", sh(K))
+        ops.categorical_ll_bwd(self._logits.view(R, K), self._value.reshape(-1), self._lse, g_ll, dlogits.view(R, K), P)
+        self._wg(self.out_conv, self.buf("x_out", sh(F)), dlogits)
+        dx_out = self.buf("dx_out", sh(F))
+        self._dg(self.out_conv, dlogits, dx_out)
+
+        # gradient accumulators of every tensor that has several consumers: block outputs + the two inits
+        grads: Dict[int, torch.Tensor] = {}
+
+        def gbuf(t: torch.Tensor, name: str) -> torch.Tensor:
+            key = t.data_ptr()
+            if key not in grads:
+                gb = self.buf(f"grad/{name}", tuple(t.shape))
+                ops.fill_zero(gb)
+                grads[key] = gb
+            return grads[key]
+
+        names = {self._v0.data_ptr(): "v_init", self._h0.data_ptr(): "h_init"}
+        for blk in self.blocks:
+            names[self.buf(f"{blk.name}/out", sh(F)).data_ptr()] = blk.name
+        gname = lambda t: names[t.data_ptr()]   # noqa: E731
+
+        ops.elu_bwd(self._up_h, dx_out, gbuf(self._up_h, gname(self._up_h)), accumulate=True)
+        dh_all = self.buf("dhproj", (G, B, 2 * F)) if self._hproj is not None else None
+
+        for blk in reversed(self.blocks):
+            n = blk.name
+            input_x, extra_a, extra_b = self._io[blk.group]
+            out = self.buf(f"{n}/out", sh(F))
+            dout = gbuf(out, n)
+            d_in = gbuf(input_x, gname(input_x))
+            ops.axpy1(dout, d_in)                                              # residual branch
+            y = self.buf(f"{n}/y", sh(2 * F))
+            dy = self.buf(f"{n}/dy", sh(2 * F))
+            ops.gate_bwd(y, self._hproj[blk.group] if self._hproj is not None else None, dout, dy, P)
+            if dh_all is not None:
+                ops.rows_sum(dy.view(R, 2 * F), dh_all[blk.group], P)
+            ce2 = self.buf(f"{n}/ce2", sh(2 * F))
+            self._wg(blk.conv2, ce2, dy)
+            dce2 = self.buf(f"{n}/dce2", sh(2 * F))
+            self._dg(blk.conv2, dy, dce2)
+            x1 = self.buf(f"{n}/x1", sh(F))
+            dx1 = self.buf(f"{n}/dx1", sh(F))
+            ops.concat_elu_bwd(x1, None, self._drops[blk.group], dce2, dx1, None, accumulate=False)
+            if blk.linear is not None:
+                ce_e = self.buf(f"{n}/ce_e", (R, blk.linear.g.CI))
+                self._wg(blk.linear, ce_e, dx1.view(R, F))
+                dce_e = self.buf(f"{n}/dce_e", (R, blk.linear.g.CI))
+                self._dg(blk.linear, dx1.view(R, F), dce_e)
+                da = gbuf(extra_a, gname(extra_a))
+                db = gbuf(extra_b, gname(extra_b)) if extra_b is not None else None
+                ops.concat_elu_bwd(extra_a, extra_b, None, dce_e, da, db, accumulate=True)
+            ce1 = self.buf(f"{n}/ce1", sh(2 * F))
+            self._wg(blk.conv1, ce1, dx1)
+            dce1 = self.buf(f"{n}/dce1", sh(2 * F))
+            self._dg(blk.conv1, dx1, dce1)
+            ops.concat_elu_bwd(input_x, None, None, dce1, d_in, None, accumulate=True)
+
+        dv0, dh0 = gbuf(self._v0, "v_init"), gbuf(self._h0, "h_init")
+        emb = self._emb
+        self._wg(self.v_init, emb, dv0)
+        self._wg(self.h_up, emb, dh0)
+        self._wg(self.h_left, emb, dh0)
+        de1, de2 = self.buf("demb1", sh(F)), self.buf("demb2", sh(F))
+        self._dg(self.v_init, dv0, de1)
+        self._dg(self.h_up, dh0, de2, res=de1)
+        self._dg(self.h_left, dh0, de1, res=de2)
+        ops.embed_bwd(self._value.reshape(-1), de1, self.G("embed/embeddings"))
+        if dh_all is None:
+            return None
+        gw, gb_ = self._cond_params("g")
+        kw = self._cond_kw(B)
+        ops.layer_wgrad(self.g_cond, self._cond, dh_all, gw, gb_, bf16=False, **kw)
+        dcond_g = self.buf("dcond_groups", (G, B, self._cond_dim))
+        cw, _ = self._cond_params("p")
+        dkw = dict(kw)
+        dkw["in_gs"], dkw["out_gs"] = B * self._cond_dim, B * 2 * F      # layer_dgrad swaps them: dy groups -> dx groups
+        ops.layer_dgrad(self.g_cond, dh_all, cw, dcond_g, **dkw)
+        dcond = self.buf("dcond", (B, self._cond_dim))
+        ops.groups_sum(dcond_g, dcond, G)
+        return dcond

@@ -218,6 +218,47 @@ class ConvResidualDecoder(_ConvResidualNet):
         return dz
 
 
+class VQVAEPartialEncoder(Module):
+    """reference vqvae.py:99-130: ConvResidualEncoder on [x*b | b] -> Flatten -> Linear(conditional_dim)."""
+
+    def __init__(self, conditional_dim: int, vqvae_config: Dict[str, Any], name: Optional[str] = None):
+        super().__init__(name)
+        self._conditional_dim = conditional_dim
+        self.encoder = ConvResidualEncoder(vqvae_config["hidden_units"], vqvae_config["residual_blocks"],
+                                           vqvae_config["residual_hidden_units"])
+
+    def build(self, store: ParamStore, prefix: str, in_shape) -> Tuple[int, ...]:
+        self.attach(store, prefix)
+        self.encoder.ws = self.ws
+        h, w, c = self.encoder.build(store, f"{prefix}/encoder", in_shape)
+        self._flat = h * w * c
+        self.g_lin = LayerGeom.dense(self._flat, self._conditional_dim)
+        store.add(f"{prefix}/linear/w", (self._flat, self._conditional_dim), fan_in=self._flat)
+        store.add(f"{prefix}/linear/b", (self._conditional_dim,))
+        self._ws = (store.request_split(f"{prefix}/linear/w", self.g_lin, "fwd"),
+                    store.request_split(f"{prefix}/linear/w", self.g_lin, "dgrad"))
+        return (self._conditional_dim,)
+
+    def __call__(self, x_o_b: torch.Tensor, is_training: bool = False) -> torch.Tensor:
+        B = x_o_b.shape[0]
+        feat = self.encoder(Feat(x_o_b), is_training=is_training)
+        self._feat = feat
+        out = self.buf("cond", (B, self._conditional_dim))
+        ops.layer_forward(self.g_lin, feat.t.view(B, self._flat), self.P("linear/w"), self.P("linear/b"), out,
+                          in_act=feat.in_act, wsplit=self.store.split_view(self._ws[0]))
+        return out
+
+    def backward(self, dcond: torch.Tensor) -> None:
+        B = dcond.shape[0]
+        feat = self._feat
+        flat = feat.t.view(B, self._flat)
+        self.wgrad(self.g_lin, flat, dcond, self.G("linear/w"), self.G("linear/b"), in_act=feat.in_act)
+        dfeat = self.buf("dfeat", (B, self._flat))
+        ops.layer_dgrad(self.g_lin, dcond, self.P("linear/w"), dfeat, aux=flat, aux_act=feat.grad_act,
+                        wsplit=self.store.split_view(self._ws[1]))
+        self.encoder.backward(dfeat.view(feat.t.shape), need_input_grad=False)
+
+
 class VectorQuantizerEMA(Module):
     """hk.nets.VectorQuantizerEMA (third party) as constructed at reference
     vqvae.py:66-72.  State tensors (haiku names): embeddings [D,K], ema_cluster_size/{hidden,average},

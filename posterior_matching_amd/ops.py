@@ -294,7 +294,8 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False) 
 
 
 def _thin_ok(d: GatherDesc) -> bool:
-    return d.groups == 1 and d.d == 1 and d.KH * d.KW * d.C <= 64 and d.N <= 32 and d.N % 8 == 0
+    return (d.groups == 1 and d.d == 1 and d.KH * d.KW * d.C <= 64 and d.N <= 32 and d.N % 8 == 0
+            and d.off_x == d.off and d.kws == d.KW)
 
 
 def thin_conv(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
@@ -460,6 +461,74 @@ def gmm_logprob_fwd(head, z, mll, nc) -> None:
 def gmm_logprob_bwd(head, z, g, dhead, dz, nc, accumulate_dz) -> None:
     B, k = z.shape
     _call("pm_gmm_logprob_bwd", _ptr(head), _ptr(z), _ptr(g), _ptr(dhead), _ptr(dz), B, k, nc, int(accumulate_dz))
+
+
+# ---- PixelCNN row-wise pieces (reference pixel_cnn.py:372-553) ----------------------------------------
+def embed_fwd(idx, table, out) -> None:
+    K, F = table.shape
+    _call("pm_embed_fwd", _iptr(idx), _ptr(table), _ptr(out), idx.numel(), F, K)
+
+
+def embed_bwd(idx, dout, dtable) -> None:
+    K, F = dtable.shape
+    _call("pm_embed_bwd", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K)
+
+
+def concat_elu_fwd(a, b, drop, out) -> None:
+    Ca, Cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
+    _call("pm_concat_elu_fwd", _ptr(a), _ptr(b), _ptr(drop), _ptr(out), a.numel() // Ca, Ca, Cb,
+          work={"bytes": _nbytes(a, b, drop, out)})
+
+
+def concat_elu_bwd(a, b, drop, dout, da, db, accumulate: bool) -> None:
+    Ca, Cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
+    _call("pm_concat_elu_bwd", _ptr(a), _ptr(b), _ptr(drop), _ptr(dout), _ptr(da), _ptr(db), a.numel() // Ca, Ca, Cb,
+          int(accumulate), work={"bytes": _nbytes(a, b, drop, dout, da, db)})
+
+
+def gate_fwd(y, h, inp, out, P: int) -> None:
+    F = inp.shape[-1]
+    _call("pm_gate_fwd", _ptr(y), _ptr(h), _ptr(inp), _ptr(out), inp.numel() // F, F, P, work={"bytes": _nbytes(y, inp, out)})
+
+
+def gate_bwd(y, h, dout, dy, P: int) -> None:
+    F = dout.shape[-1]
+    _call("pm_gate_bwd", _ptr(y), _ptr(h), _ptr(dout), _ptr(dy), dout.numel() // F, F, P, work={"bytes": _nbytes(y, dout, dy)})
+
+
+def rows_sum(x, out, P: int) -> None:
+    N = x.shape[-1]
+    _call("pm_rows_sum", _ptr(x), _ptr(out), x.numel() // (N * P), N, P, work={"bytes": _nbytes(x, out)})
+
+
+def groups_sum(x, out, G: int, accumulate: bool = False) -> None:
+    _call("pm_groups_sum", _ptr(x), _ptr(out), out.numel(), G, x.numel() // G, int(accumulate))
+
+
+def elu_fwd(x, out) -> None:
+    _call("pm_elu_fwd", _ptr(x), _ptr(out), x.numel())
+
+
+def elu_bwd(x, dout, dx, accumulate: bool = False) -> None:
+    _call("pm_elu_bwd", _ptr(x), _ptr(dout), _ptr(dx), x.numel(), int(accumulate))
+
+
+def categorical_ll_fwd(logits, idx, lse, ll, P: int) -> None:
+    K = logits.shape[-1]
+    _call("pm_categorical_ll_fwd", _ptr(logits), _iptr(idx), _ptr(lse), _ptr(ll), logits.numel() // K, K, P)
+
+
+def categorical_ll_bwd(logits, idx, lse, g, dlogits, P: int) -> None:
+    K = logits.shape[-1]
+    _call("pm_categorical_ll_bwd", _ptr(logits), _iptr(idx), _ptr(lse), _ptr(g), _ptr(dlogits), logits.numel() // K, K, P)
+
+
+def neg_mean_loss(ll, grad_scale: float, out, g_ll) -> None:
+    _call("pm_neg_mean_loss", _ptr(ll), ll.numel(), grad_scale, _ptr(out), _ptr(g_ll))
+
+
+def dropout_mask(out, rate: float, seed: int, step_dev, stream_id: int = 0) -> None:
+    _call("pm_dropout_mask", _ptr(out), out.numel(), rate, seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
 
 
 def pmvae_loss(rec, kl, mll, cfg: _lib.LossCfg, step_dev, out, g_rec, g_kl, g_mll) -> None:

@@ -53,3 +53,16 @@ def vqvae_mnist():
                   "output_channels": 1},
         "steps": 60000, "validation_freq": 1000, "learning_rate": 3e-4,
     }
+
+
+def pm_vqvae_mnist():
+    """configs/pm_vqvae_mnist.py:4-40 of the reference (stage 2: PixelCNN partial posterior over the 7x7 codes)."""
+    return {
+        "data": {"dataset": "mnist", "train_split": "train", "validation_split": "test",
+                 "train_batch_size": 32, "val_batch_size": 32, "mask_generator": "MNISTMaskGenerator"},
+        "vqvae_dir": "runs/vqvae-mnist-20220227-111235",
+        "pixel_cnn": {"image_shape": (7, 7), "num_resnet": 8, "num_hierarchies": 1, "num_filters": 128, "dropout": 0.5},
+        "conditional_dim": 512,
+        "steps": 120000, "validation_freq": 1000,
+        "lr_schedule": {"init_value": 3e-4, "decay_rate": 0.999995, "transition_steps": 1},
+    }

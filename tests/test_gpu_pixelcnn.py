@@ -1,0 +1,365 @@
+"""GPU parity of the PixelCNN partial posterior and the PM-VQVAE (stage 2) step: HIP path through
+the C ABI vs oracle/pixel_cnn_oracle.py (float64).  Tolerances stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pixel_cnn_oracle as PO
+from oracle import vqvae_oracle as VO
+from tests.ref_configs import pm_vqvae_mnist, vqvae_mnist
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def f32d(t):
+    return t.float().to(dev()).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# row-wise kernels in isolation
+# ----------------------------------------------------------------------------------------------
+def test_concat_elu_gate_rows_sum_elu():
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(0)
+    R, Ca, Cb, P = 3 * 49, 24, 40, 49
+    a, b = torch.randn((R, Ca), generator=gen, dtype=F64), torch.randn((R, Cb), generator=gen, dtype=F64)
+    drop = (torch.rand((R, 2 * (Ca + Cb)), generator=gen) > 0.5).double() * 2.0
+    dout = torch.randn((R, 2 * (Ca + Cb)), generator=gen, dtype=F64)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    want = PO.concat_elu(torch.cat([ar, br], -1)) * drop
+    want.backward(dout)
+    out = torch.empty((R, 2 * (Ca + Cb)), device=dev())
+    ops.concat_elu_fwd(f32d(a), f32d(b), f32d(drop), out)
+    assert rel_err(out, want) < 1e-6
+    da, db = torch.ones((R, Ca), device=dev()), torch.ones((R, Cb), device=dev())
+    ops.concat_elu_bwd(f32d(a), f32d(b), f32d(drop), f32d(dout), da, db, accumulate=True)
+    assert rel_err(da, ar.grad + 1.0) < 1e-6 and rel_err(db, br.grad + 1.0) < 1e-6
+    ops.concat_elu_bwd(f32d(a), None, None, f32d(dout[:, :2 * Ca]), da, None, accumulate=False)
+    a2 = a.clone().requires_grad_(True)
+    PO.concat_elu(a2).backward(dout[:, :2 * Ca])
+    assert rel_err(da, a2.grad) < 1e-6
+
+    F, B = 32, 3
+    y, h = torch.randn((R, 2 * F), generator=gen, dtype=F64), torch.randn((B, 2 * F), generator=gen, dtype=F64)
+    inp, g = torch.randn((R, F), generator=gen, dtype=F64), torch.randn((R, F), generator=gen, dtype=F64)
+    yr, hr = y.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    x = yr.reshape(B, P, 2 * F) + hr[:, None, :]
+    wantg = inp.reshape(B, P, F) + torch.sigmoid(x[..., F:]) * x[..., :F]
+    wantg.backward(g.reshape(B, P, F))
+    og = torch.empty((R, F), device=dev())
+    ops.gate_fwd(f32d(y), f32d(h), f32d(inp), og, P)
+    assert rel_err(og, wantg.reshape(R, F)) < 1e-6
+    dy = torch.empty((R, 2 * F), device=dev())
+    ops.gate_bwd(f32d(y), f32d(h), f32d(g), dy, P)
+    assert rel_err(dy, yr.grad) < 2e-6
+    dh = torch.empty((B, 2 * F), device=dev())
+    ops.rows_sum(dy, dh, P)
+    assert rel_err(dh, hr.grad) < 2e-6
+    gs = torch.ones((B, 2 * F), device=dev())
+    ops.groups_sum(dy.view(P, B * 2 * F)[:0 + P].contiguous(), gs.view(-1), P, accumulate=True)
+    assert rel_err(gs.view(-1), dy.view(P, -1).double().sum(0) + 1.0) < 1e-6
+
+    e = torch.empty((R, Ca), device=dev())
+    ops.elu_fwd(f32d(a), e)
+    assert rel_err(e, PO.elu(a)) < 1e-6
+    de = torch.empty((R, Ca), device=dev())
+    ops.elu_bwd(f32d(a), f32d(dout[:, :Ca]), de)
+    a3 = a.clone().requires_grad_(True)
+    PO.elu(a3).backward(dout[:, :Ca])
+    assert rel_err(de, a3.grad) < 1e-6
+
+
+def test_embed_categorical_and_dropout_mask():
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(1)
+    B, P, K, F = 5, 49, 256, 128
+    R = B * P
+    idx = torch.randint(0, K, (R,), generator=gen)
+    table = torch.randn((K, F), generator=gen, dtype=F64)
+    out = torch.empty((R, F), device=dev())
+    idd = idx.to(torch.int32).to(dev())
+    ops.embed_fwd(idd, f32d(table), out)
+    assert torch.equal(out.cpu(), table.float()[idx])
+    dout = torch.randn((R, F), generator=gen, dtype=F64)
+    dt = torch.zeros((K, F), device=dev())
+    ops.embed_bwd(idd, f32d(dout), dt)
+    want = torch.zeros((K, F), dtype=F64).index_add_(0, idx, dout)
+    assert rel_err(dt, want) < 1e-6
+
+    logits = torch.randn((R, K), generator=gen, dtype=F64) * 3
+    g = torch.randn((B,), generator=gen, dtype=F64)
+    lr = logits.clone().requires_grad_(True)
+    ll = torch.log_softmax(lr, -1).gather(-1, idx[:, None]).reshape(B, P).sum(1)
+    (ll * g).sum().backward()
+    lse, lld = torch.empty(R, device=dev()), torch.empty(B, device=dev())
+    ops.categorical_ll_fwd(f32d(logits), idd, lse, lld, P)
+    assert rel_err(lld, ll) < 1e-6
+    dl = torch.empty((R, K), device=dev())
+    ops.categorical_ll_bwd(f32d(logits), idd, lse, f32d(g), dl, P)
+    assert rel_err(dl, lr.grad) < 2e-6
+    met, gl = torch.zeros(8, device=dev()), torch.empty(B, device=dev())
+    ops.neg_mean_loss(lld, 1.0 / B, met, gl)
+    assert abs(met[0].item() + ll.mean().item()) < 1e-5 * abs(ll.mean().item()) and torch.allclose(gl.cpu(), torch.full((B,), -1.0 / B))
+
+    m = torch.empty(1 << 20, device=dev())
+    step = torch.tensor([3], dtype=torch.int32, device=dev())
+    ops.dropout_mask(m, 0.5, 1234, step, stream_id=2)
+    vals = set(torch.unique(m).cpu().tolist())
+    assert vals == {0.0, 2.0} and abs(m.mean().item() - 1.0) < 0.01      # E[mask] = 1
+    m2 = torch.empty_like(m)
+    ops.dropout_mask(m2, 0.5, 1234, step, stream_id=2)
+    assert torch.equal(m, m2)                                              # counter-based: reproducible
+    ops.dropout_mask(m2, 0.5, 1234, step, stream_id=3)
+    assert not torch.equal(m, m2)
+
+
+# ----------------------------------------------------------------------------------------------
+# the network
+# ----------------------------------------------------------------------------------------------
+SMALL = {"num_indices": 24, "image_shape": (5, 5), "num_resnet": 2, "num_hierarchies": 1, "num_filters": 32, "dropout": 0.5}
+
+
+def _build_pixelcnn(cfg, cond_dim, seed=3, bf16x3=False):
+    from posterior_matching_amd import _lib
+    from posterior_matching_amd.models.core import ParamStore, Workspace
+    from posterior_matching_amd.models.pixel_cnn import PixelCNN
+
+    _lib.load()
+    store, ws = ParamStore(), Workspace(dev())
+    pc = PixelCNN(**cfg)
+    pc.ws = ws
+    pc.build(store, "pc", cond_dim)
+    store.allocate(dev(), seed)
+    store.use_bf16 = bf16x3
+    gen = torch.Generator().manual_seed(seed)
+    vals = {}
+    for n, t in store.to_dict("p").items():           # biases are zero at init: move them; tame the N(0,1) projections
+        v = t.cpu()
+        if n.endswith("/b"):
+            v = 0.05 * torch.randn(v.shape, generator=gen)
+        if n.endswith("/cond/w") or n.endswith("/embeddings"):
+            v = v * 0.3
+        vals[n] = v
+    store.load_dict(vals)
+    return pc, store
+
+
+@pytest.mark.parametrize("training,bf16x3", [(False, False), (True, False), (True, True)])
+def test_pixelcnn_log_prob_and_grads(training, bf16x3):
+    cfg, cd, B = SMALL, 16, 3
+    pc, store = _build_pixelcnn(cfg, cd, bf16x3=bf16x3)
+    p64 = {n: t.cpu().double() for n, t in store.to_dict("p").items()}
+    assert {n: tuple(t.shape) for n, t in p64.items()} == PO.pixel_cnn_param_shapes("pc", cfg, cd)
+    gen = torch.Generator().manual_seed(5)
+    H, W = cfg["image_shape"]
+    idx = torch.randint(0, cfg["num_indices"], (B, H, W), generator=gen)
+    cond = torch.randn((B, cd), generator=gen, dtype=F64)
+    g = torch.randn((B,), generator=gen, dtype=F64)
+    F = cfg["num_filters"]
+    masks = [((torch.rand((B, H, W, 2 * F), generator=gen) > 0.5).double() * 2.0) for _ in range(4 * cfg["num_resnet"])] \
+        if training else None
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    cr = cond.clone().requires_grad_(True)
+    lp = PO.pixel_cnn_log_prob(leaves, "pc", idx, cfg, cr, masks)
+    grads = torch.autograd.grad((lp * g).sum(), list(leaves.values()) + [cr])
+    gd_want = dict(zip(leaves, grads[:-1]))
+
+    got = pc.log_prob(idx.to(torch.int32).to(dev()), training=training, conditional_input=f32d(cond),
+                      dropout_masks=[f32d(m) for m in masks] if masks else None)
+    tol = 1e-5 if not bf16x3 else 1e-4
+    assert rel_err(got, lp) < tol
+    from posterior_matching_amd import ops
+    ops.fill_zero(store.flat_g)
+    dcond = pc.backward(f32d(g))
+    torch.cuda.synchronize()
+    assert rel_err(dcond, grads[-1]) < (5e-5 if not bf16x3 else 5e-3)
+    for n, gt in store.to_dict("g").items():
+        e = rel_err(gt, gd_want[n])
+        assert e < (5e-5 if not bf16x3 else 5e-3), (n, e)
+    # masked taps never receive gradient
+    gw = store.to_dict("g")["pc/down_0/horizontal/conv2/w"].cpu()
+    assert torch.equal(gw[2], torch.zeros_like(gw[2])) and torch.equal(gw[:, 2], torch.zeros_like(gw[:, 2]))
+
+
+def test_pixelcnn_is_autoregressive_on_device():
+    """bit-exact: logits at raster positions <= (r, c) do not depend on the index at (r, c)."""
+    cfg, cd, B = dict(SMALL, image_shape=(7, 7)), 16, 2
+    pc, store = _build_pixelcnn(cfg, cd)
+    gen = torch.Generator().manual_seed(9)
+    idx = torch.randint(0, 24, (B, 7, 7), generator=gen).to(torch.int32).to(dev())
+    cond = torch.randn((B, cd), generator=gen).to(dev())
+    base = pc.logits(idx, False, cond).clone()
+    for (r, c) in [(0, 0), (3, 3), (6, 6), (2, 5)]:
+        idx2 = idx.clone()
+        idx2[:, r, c] = (idx2[:, r, c] + 1) % 24
+        l2 = pc.logits(idx2, False, cond)
+        torch.cuda.synchronize()
+        same = (l2 == base).all(-1)[0].cpu()
+        for rr in range(7):
+            for cc in range(7):
+                if (rr, cc) <= (r, c):
+                    assert same[rr, cc], ((r, c), (rr, cc))
+        if (r, c) != (6, 6):
+            assert not same.all()
+
+
+# ----------------------------------------------------------------------------------------------
+# stage 2 of PM-VQVAE: frozen VQ-VAE + partial encoder + PixelCNN
+# ----------------------------------------------------------------------------------------------
+TINY_VQ = {"embedding_dim": 32, "num_embeddings": 24, "hidden_units": 32, "residual_hidden_units": 32,
+           "residual_blocks": 1, "decay": 0.99, "use_ema": True, "commitment_cost": 0.25, "output_channels": 1}
+TINY_CFG = {"pixel_cnn": {"image_shape": (3, 3), "num_resnet": 2, "num_hierarchies": 1, "num_filters": 32, "dropout": 0.5},
+            "conditional_dim": 64, "lr_schedule": {"init_value": 3e-4, "decay_rate": 0.999995, "transition_steps": 1}}
+
+
+def _stage2(cfg, vq_cfg, xs, B, seed=4, bf16x3=False):
+    from posterior_matching_amd import optim
+    from posterior_matching_amd.engine import PMVQVAETrainStep
+    from posterior_matching_amd.models.pixel_cnn import PixelCNN
+    from posterior_matching_amd.models.vqvae import VQVAE, VQVAEPartialEncoder
+
+    vq = VQVAE(**vq_cfg, device="cuda:0", seed=seed)
+    vq.init(xs)
+    vq.store.use_bf16 = False           # frozen encoder: indices must match the oracle's
+    pc_cfg = dict(cfg["pixel_cnn"], num_indices=vq_cfg["num_embeddings"])
+    penc, pcnn = VQVAEPartialEncoder(cfg["conditional_dim"], vq_cfg), PixelCNN(**pc_cfg)
+    opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(0.0),
+                      optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
+    ts = PMVQVAETrainStep(vq, penc, pcnn, opt, B, xs, seed=seed, external_dropout=True)
+    ts.store.use_bf16 = bf16x3
+    gen = torch.Generator().manual_seed(seed)
+    vals = {}
+    for n, t in ts.store.to_dict("p").items():
+        v = t.cpu()
+        if n.endswith("/b"):
+            v = 0.05 * torch.randn(v.shape, generator=gen)
+        if n.endswith("/cond/w") or n.endswith("/embeddings"):
+            v = v * 0.3
+        vals[n] = v
+    ts.store.load_dict(vals)
+    p64 = {n: t.cpu().double() for n, t in ts.store.to_dict("p").items()}
+    vq64 = {n: t.cpu().double() for n, t in vq.params_dict().items()}
+    sd = vq.state_dict()
+    st64 = {"vq/embeddings": sd["embeddings"].cpu().double()}
+    for name in ("ema_cluster_size", "ema_dw"):
+        st64[f"vq/{name}/hidden"] = sd[f"{name}/hidden"].cpu().double()
+        st64[f"vq/{name}/average"] = sd[f"{name}/average"].cpu().double()
+        st64[f"vq/{name}/counter"] = torch.tensor(0)
+    return ts, p64, vq64, st64
+
+
+def _batch(rng, B, xs):
+    x = rng.uniform(size=(B,) + xs) * (rng.uniform(size=(B,) + xs) < 0.3)
+    b = (rng.uniform(size=(B,) + xs[:-1] + (1,)) < 0.5).astype(np.float64)
+    return torch.tensor(x), torch.tensor(b)
+
+
+def _masks(rng, cfg, B):
+    H, W = cfg["pixel_cnn"]["image_shape"]
+    F, R = cfg["pixel_cnn"]["num_filters"], cfg["pixel_cnn"]["num_resnet"]
+    return [torch.tensor((rng.uniform(size=(B, H, W, 2 * F)) > 0.5) * 2.0) for _ in range(4 * R)]
+
+
+def test_stage2_param_names_match_oracle():
+    ts, p64, vq64, st64 = _stage2(TINY_CFG, TINY_VQ, (12, 12, 1), 2)
+    want = PO.init_params(TINY_CFG, TINY_VQ, 2)
+    assert {n: tuple(t.shape) for n, t in p64.items()} == {n: tuple(t.shape) for n, t in want.items()}
+
+
+@pytest.mark.parametrize("bf16x3", [False, True])
+def test_stage2_loss_and_grads(bf16x3):
+    B, xs = 4, (12, 12, 1)
+    ts, p64, vq64, st64 = _stage2(TINY_CFG, TINY_VQ, xs, B, bf16x3=bf16x3)
+    rng = np.random.default_rng(0)
+    x, b = _batch(rng, B, xs)
+    masks = _masks(rng, TINY_CFG, B)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, idx, lp = PO.pm_vqvae_loss(leaves, vq64, st64, TINY_CFG, TINY_VQ, x, b, True, masks)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    ts.dropout_masks = [f32d(m) for m in masks]
+    ts.set_batch(f32d(x), f32d(b))
+    with torch.cuda.stream(ts.stream):
+        ll = ts.forward(True)
+        from posterior_matching_amd import ops
+        ops.fill_zero(ts.store.flat_g)
+        ts.penc.backward(ts.pcnn.backward(ts.g_ll))
+    ts.synchronize()
+    assert torch.equal(ts._idx.cpu().long(), idx)
+    tol = 1e-5 if not bf16x3 else 1e-4
+    assert rel_err(ll, lp) < tol and abs(ts.read_metrics()["loss"] - loss.item()) < tol * abs(loss.item())
+    for n, gt in ts.store.to_dict("g").items():
+        e = rel_err(gt, grads[n])
+        assert e < (1e-4 if not bf16x3 else 1e-2), (n, e)
+
+
+def test_stage2_train_steps_match_oracle():
+    B, xs = 4, (12, 12, 1)
+    ts, p64, vq64, st64 = _stage2(TINY_CFG, TINY_VQ, xs, B)
+    m = {k: torch.zeros_like(v) for k, v in p64.items()}
+    v = {k: torch.zeros_like(t) for k, t in p64.items()}
+    p32 = {k: t.float().clone() for k, t in p64.items()}
+    m32, v32 = {k: torch.zeros_like(t) for k, t in p32.items()}, {k: torch.zeros_like(t) for k, t in p32.items()}
+    vq32 = {k: t.float() for k, t in vq64.items()}
+    st32 = {k: (t.float() if t.is_floating_point() else t) for k, t in st64.items()}
+    rng = np.random.default_rng(1)
+    frozen_before = {n: t.clone() for n, t in ts.vqvae.params_dict().items()}
+    for step in range(3):
+        x, b = _batch(rng, B, xs)
+        masks = _masks(rng, TINY_CFG, B)
+        loss, _ = PO.train_step(p64, vq64, st64, m, v, TINY_CFG, TINY_VQ, x, b, step, masks)
+        PO.train_step(p32, vq32, st32, m32, v32, TINY_CFG, TINY_VQ, x.float(), b.float(), step, [t.float() for t in masks])
+        ts.dropout_masks = [f32d(t) for t in masks]
+        ts.set_batch(f32d(x), f32d(b))
+        ts.step()
+        assert abs(ts.read_metrics()["loss"] - loss.item()) < 1e-4 * abs(loss.item()), step
+        pd = ts.store.to_dict("p")
+        for n in p64:
+            e, e32 = rel_err(pd[n], p64[n]), rel_err(p32[n], p64[n])
+            assert e < max(3e-4, 20 * e32) and e < 5e-3, (step, n, e, e32)
+    assert ts.step_dev.item() == 3
+    for n, t in ts.vqvae.params_dict().items():                     # trainable_predicate: "vqvae/" stays frozen
+        assert torch.equal(t, frozen_before[n]), n
+    assert int(ts.vqvae.state["counter"]) == 0
+
+
+def test_stage2_reference_config_small_batch():
+    """configs/pm_vqvae_mnist.py network sizes (34.2 M PixelCNN params) at batch 2: loss and a sample of gradients."""
+    cfg, vq_cfg = pm_vqvae_mnist(), vqvae_mnist()["model"]
+    B, xs = 2, (28, 28, 1)
+    ts, p64, vq64, st64 = _stage2(cfg, vq_cfg, xs, B, seed=6)
+    assert ts.num_trainable_params == 35026768                       # 841 936 + 34 184 832
+    rng = np.random.default_rng(2)
+    x, b = _batch(rng, B, xs)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, idx, lp = PO.pm_vqvae_loss(leaves, vq64, st64, cfg, vq_cfg, x, b, False)
+    names = ["pixel_cnn/embed/embeddings", "pixel_cnn/down_3/horizontal/conv2/w", "pixel_cnn/up_7/horizontal/linear/w",
+             "pixel_cnn/up_0/vertical/cond/w", "partial_encoder/linear/w", "partial_encoder/encoder/enc_1/w",
+             "pixel_cnn/out_conv/b"]
+    grads = dict(zip(names, torch.autograd.grad(loss, [leaves[n] for n in names])))
+    ts.set_batch(f32d(x), f32d(b))
+    with torch.cuda.stream(ts.stream):
+        ll = ts.forward(False)
+        from posterior_matching_amd import ops
+        ops.neg_mean_loss(ll, 1.0 / B, ts.metrics, ts.g_ll)
+        ops.fill_zero(ts.store.flat_g)
+        ts.penc.backward(ts.pcnn.backward(ts.g_ll))
+    ts.synchronize()
+    assert torch.equal(ts._idx.cpu().long(), idx)
+    assert rel_err(ll, lp) < 2e-5
+    gd = ts.store.to_dict("g")
+    for n in names:
+        assert rel_err(gd[n], grads[n]) < 2e-4, (n, rel_err(gd[n], grads[n]))
