@@ -227,3 +227,51 @@ def init_params(cfg: dict, vqvae_cfg: dict, in_channels: int = 2, seed: int = 3,
             arr = np.zeros(shp)
         out[name] = torch.tensor(arr, dtype=dtype)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# ancestral sampling, imputation and PSNR (pixel_cnn.py:76-146, vqvae.py:269-312, eval_pm_vqvae.py:120-138)
+# ----------------------------------------------------------------------------------------------
+def pixel_cnn_sample(p: Params, prefix: str, cfg: dict, conditional_input: Tensor, num_samples: int,
+                     gumbel: Tensor) -> Tensor:
+    """PixelCNN._sample_n with conditioning (pixel_cnn.py:102-124): for every conditioning vector, draw
+    `num_samples` index grids position by position in raster order.  Returns [num_samples, B, H, W].
+    jax.random.categorical is the Gumbel-max trick; the noise is explicit here: gumbel [H*W, B*num_samples, K]
+    (row b*num_samples + s belongs to sample s of example b)."""
+    H, W = cfg["image_shape"]
+    B = conditional_input.shape[0]
+    cond = conditional_input.reshape(B, -1).repeat_interleave(num_samples, dim=0)       # jnp.tile per vmap lane
+    x = torch.zeros((B * num_samples, H, W), dtype=torch.long)
+    for i in range(H * W):
+        logits = pixel_cnn_logits(p, prefix, x, cfg, cond)
+        r, c = divmod(i, W)
+        x[:, r, c] = torch.argmax(logits[:, r, c, :] + gumbel[i], dim=-1)
+    return x.reshape(B, num_samples, H, W).permute(1, 0, 2, 3)
+
+
+def vqvae_impute(p: Params, vq_params: Params, vq_state, cfg: dict, vqvae_cfg: dict, x: Tensor, b: Tensor,
+                 num_samples: int, gumbel: Tensor) -> Tensor:
+    """vqvae_impute (vqvae.py:269-312) -> [B, num_samples, H, W, C] with observed pixels kept, clipped to [0,1]."""
+    from .vqvae_oracle import conv_residual_decoder
+
+    x_o_b = torch.cat([x * b, b], dim=-1)
+    cond = vqvae_partial_encoder(p, "partial_encoder", x_o_b, vqvae_cfg)
+    pc = dict(cfg["pixel_cnn"])
+    pc["num_indices"] = vqvae_cfg["num_embeddings"]
+    samples = pixel_cnn_sample(p, "pixel_cnn", pc, cond, num_samples, gumbel)           # [S, B, H, W]
+    E = vq_state["vq/embeddings"]
+    out = []
+    for s in range(num_samples):
+        q = E.t()[samples[s]]                                                        # vq.quantize(indices)
+        loc, _ = conv_residual_decoder(vq_params, "decoder", q, vqvae_cfg.get("residual_blocks", 2))
+        out.append(loc)
+    imp = torch.stack(out, dim=1)                                                     # [B, S, H, W, C]
+    imp = torch.where(b[:, None].bool(), x[:, None].expand_as(imp), imp)
+    return imp.clamp(0.0, 1.0)
+
+
+def imputation_psnr(imputations: Tensor, x: Tensor) -> Tensor:
+    """eval_pm_vqvae.py:133-136: PSNR of the mean imputation, per example."""
+    mean_imp = imputations.mean(1)
+    mse = ((mean_imp - x) ** 2).reshape(x.shape[0], -1).mean(1)
+    return -10.0 * torch.log10(mse)

@@ -113,6 +113,10 @@ SIGNATURES = {
     "pm_categorical_ll_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_categorical_ll_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_neg_mean_loss": [_P, _P, _I, _F, _P, _P],
+    "pm_categorical_sample": [_P, _P, _P, _P, _LL, _I, _I, _I],
+    "pm_impute_blend": [_P, _P, _P, _P, _LL, _I, _LL, _I, _I],
+    "pm_imputation_psnr": [_P, _P, _P, _P, _LL, _I, _LL],
+    "pm_gumbel_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
     "pm_dropout_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
     "pm_pmvae_loss": [_P, _P, _P, _P, _I, C.POINTER(LossCfg), _P, _P, _P, _P, _P],
     "pm_adam_step": [_P, _P, _P, _P, _P, _LL, _LL, _P, C.POINTER(AdamCfg)],

@@ -184,6 +184,28 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ o
     }
 }
 
+__global__ __launch_bounds__(256) void gumbel_fill_kernel(float* __restrict__ out, long long n, unsigned long long seed,
+                                                            const int* __restrict__ step_dev, int stream_id) {
+    const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+    const long long quads = (n + 3) / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long qd = (long long)blockIdx.x * 256 + threadIdx.x; qd < quads; qd += stride) {
+        unsigned c[4] = {(unsigned)qd, (unsigned)(qd >> 32), step, (unsigned)stream_id};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c[0], c[1], c[2], c[3], k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        for (int e = 0; e < 4; ++e)
+            if (qd * 4 + e < n) {
+                const float u = ((float)c[e] + 0.5f) * 2.3283064365386963e-10f;   // (0, 1)
+                out[qd * 4 + e] = -logf(-logf(fminf(fmaxf(u, 1e-20f), 0.99999994f)));
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void axpy1_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += x[i];
@@ -248,6 +270,16 @@ int pm_zero_async(hipStream_t stream, void* ptr, size_t nbytes) {
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<unsigned*>(ptr),
                        nwords);
     return pm_check_launch("pm_zero_async");
+}
+
+extern "C" int pm_gumbel_fill(pm_stream_t stream, float* out, long long n, unsigned long long seed, const int* step_dev,
+                              int stream_id) {
+    if (!out || n <= 0) return PM_EINVAL;
+    long long blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gumbel_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, seed,
+                       step_dev, stream_id);
+    return pm_check_launch("pm_gumbel_fill");
 }
 
 extern "C" int pm_dropout_mask(pm_stream_t stream, float* out, long long n, float rate, unsigned long long seed,

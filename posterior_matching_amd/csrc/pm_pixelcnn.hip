@@ -208,6 +208,63 @@ __global__ __launch_bounds__(256) void neg_mean_loss_kernel(const float* __restr
     if (threadIdx.x == 0) out[0] = -(red[0] + red[1] + red[2] + red[3]) / (float)B;
 }
 
+// One wave per example: idx[b*P + pos] = argmax_k(logits[b*P + pos, k] + gumbel[b, k]) (Gumbel-max =
+// jax.random.categorical); ties -> lowest k.
+__global__ __launch_bounds__(256) void categorical_sample_kernel(const float* __restrict__ logits,
+                                                                  const float* __restrict__ gumbel, int* __restrict__ idx,
+                                                                  long long B, int K, int P, int pos) {
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* lr = logits + ((size_t)b * P + pos) * K;
+    const float* gr = gumbel + (size_t)b * K;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+        const float v = lr[k] + gr[k];
+        if (v > best) { best = v; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) idx[(size_t)b * P + pos] = bi >= K ? 0 : bi;
+}
+
+// imp[b, s, :] = clip(where(mask[b, :], x[b, :], imp[b, s, :]), 0, 1) in place (vqvae.py:304-312); mask has Cm
+// channels per pixel (1 = broadcast over the C image channels)
+__global__ __launch_bounds__(256) void impute_blend_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                            float* __restrict__ imp, long long total, long long D, int S,
+                                                            int C, int Cm) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long j = i % D;
+    const long long b = i / (D * S);
+    const float m = mask[b * (D / C * Cm) + (Cm == C ? j : j / C)];
+    const float v = m != 0.f ? x[b * D + j] : imp[i];
+    imp[i] = fminf(fmaxf(v, 0.f), 1.f);
+}
+
+// psnr[b] = -10 log10( mean_j (mean_s imp[b,s,j] - x[b,j])^2 )   (eval_pm_vqvae.py:133-136)
+__global__ __launch_bounds__(256) void imputation_psnr_kernel(const float* __restrict__ imp, const float* __restrict__ x,
+                                                               float* __restrict__ psnr, long long D, int S) {
+    __shared__ float red[4];
+    const long long b = blockIdx.x;
+    float acc = 0.f;
+    for (long long j = threadIdx.x; j < D; j += 256) {
+        float m = 0.f;
+        for (int s = 0; s < S; ++s) m += imp[(b * S + s) * D + j];
+        const float d = m / (float)S - x[b * D + j];
+        acc = fmaf(d, d, acc);
+    }
+    acc = pm_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) psnr[b] = -10.f * log10f((red[0] + red[1] + red[2] + red[3]) / (float)D);
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -309,4 +366,29 @@ extern "C" int pm_neg_mean_loss(pm_stream_t stream, const float* ll, int B, floa
     if (!ll || !out || B <= 0) return PM_EINVAL;
     hipLaunchKernelGGL(neg_mean_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ll, B, grad_scale, out, g_ll);
     return pm_check_launch("pm_neg_mean_loss");
+}
+
+extern "C" int pm_categorical_sample(pm_stream_t stream, const float* logits, const float* gumbel, int* idx, long long B,
+                                     int K, int P, int pos) {
+    if (!logits || !gumbel || !idx || B <= 0 || K <= 0 || P <= 0 || pos < 0 || pos >= P) return PM_EINVAL;
+    hipLaunchKernelGGL(categorical_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits,
+                       gumbel, idx, B, K, P, pos);
+    return pm_check_launch("pm_categorical_sample");
+}
+
+extern "C" int pm_impute_blend(pm_stream_t stream, const float* x, const float* mask, float* imp, long long B, int S,
+                               long long D, int C, int Cm) {
+    if (!x || !mask || !imp || B <= 0 || S <= 0 || D <= 0 || C <= 0 || (Cm != C && Cm != 1) || D % C != 0)
+        return PM_EINVAL;
+    const long long total = B * S * D;
+    hipLaunchKernelGGL(impute_blend_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, mask, imp, total,
+                       D, S, C, Cm);
+    return pm_check_launch("pm_impute_blend");
+}
+
+extern "C" int pm_imputation_psnr(pm_stream_t stream, const float* imp, const float* x, float* psnr, long long B, int S,
+                                  long long D) {
+    if (!imp || !x || !psnr || B <= 0 || S <= 0 || D <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(imputation_psnr_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, imp, x, psnr, D, S);
+    return pm_check_launch("pm_imputation_psnr");
 }

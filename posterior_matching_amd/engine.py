@@ -246,7 +246,7 @@ class PMVQVAETrainStep:
         dev = vqvae.store.device
         self.vqvae, self.penc, self.pcnn = vqvae, partial_encoder, pixel_cnn
         self.B, self.world_size, self.rank, self.seed = batch_size, world_size, rank, seed
-        if getattr(pixel_cnn, "store", None) is None:
+        if getattr(pixel_cnn, "store", None) is None:          # not built yet (models.vqvae.build_partial_posterior)
             store, ws = ParamStore(), Workspace(dev)
             partial_encoder.ws = pixel_cnn.ws = ws
             xb_shape = tuple(x_shape[:-1]) + (2 * x_shape[-1],)

@@ -226,6 +226,32 @@ class PixelCNN(Module):
         self._logits = logits
         return ll
 
+    def sample(self, *, seed: int = 0, sample_shape=(), conditional_input: Optional[torch.Tensor] = None,
+               gumbel: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """reference pixel_cnn.py:76-146 with conditioning: ancestral sampling in raster order, one full
+        network evaluation per position.  Returns int32 [*sample_shape, B, H, W].  The categorical draw is
+        the Gumbel-max trick (what jax.random.categorical does) with device Philox noise, or the explicit
+        `gumbel` [H*W, B*n, K] (row b*n + s = sample s of conditioning vector b) in parity mode."""
+        if conditional_input is None:
+            raise NotImplementedError("unconditional PixelCNN sampling is not used by the reference's scripts")
+        H, W = self._event_shape
+        K, P = self._num_indices, H * W
+        shape = (sample_shape,) if isinstance(sample_shape, int) else tuple(sample_shape)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        B = conditional_input.shape[0]
+        cond = conditional_input.reshape(B, -1).repeat_interleave(n, dim=0).contiguous()   # jnp.tile per vmap lane
+        x = torch.zeros((B * n, H, W), dtype=torch.int32, device=cond.device)
+        noise = self.buf("gumbel", (B * n, K)) if gumbel is None else None
+        for i in range(P):
+            logits = self.logits(x, False, cond)
+            if gumbel is None:
+                ops.gumbel_fill(noise, seed, None, stream_id=i)
+            ops.categorical_sample(logits.view(B * n * P, K), noise if gumbel is None else gumbel[i], x.view(-1), P, i)
+        out = x.view(B, n, H, W).permute(1, 0, 2, 3).contiguous()
+        return out.view(*shape, B, H, W) if shape else out[0]
+
     # ------------------------------------------------------------------------------------------
     def backward(self, g_ll: torch.Tensor) -> Optional[torch.Tensor]:
         """g_ll [B] = d loss / d log_prob.  Accumulates parameter gradients; returns d loss / d

@@ -468,3 +468,49 @@ class VQVAE(Module):
         for k, v in values.items():
             t = torch.as_tensor(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v))
             self.vq.state[k].copy_(t.reshape(self.vq.state[k].shape).to(self.vq.state[k].dtype))
+
+
+def build_partial_posterior(vqvae: VQVAE, conditional_dim: int, pixel_cnn_config: Dict[str, Any], x_shape, seed: int = 0):
+    """Builds the two trainable modules of stage 2 (train_pm_vqvae.py:82-84) on their own parameter
+    store: VQVAEPartialEncoder on [x*b | b] and the conditional PixelCNN over the code grid."""
+    from .pixel_cnn import PixelCNN
+
+    if vqvae.store is None:
+        vqvae.init(x_shape)
+    dev = vqvae.store.device
+    store, ws = ParamStore(), Workspace(dev)
+    penc = VQVAEPartialEncoder(conditional_dim, vqvae.config)
+    pc_cfg = dict(pixel_cnn_config)
+    pc_cfg["num_indices"] = vqvae.config["num_embeddings"]            # train_pm_vqvae.py:78
+    pcnn = PixelCNN(**pc_cfg)
+    penc.ws = pcnn.ws = ws
+    xb_shape = tuple(x_shape[:-1]) + (2 * x_shape[-1],)
+    (cond_dim,) = penc.build(store, "partial_encoder", xb_shape)
+    pcnn.build(store, "pixel_cnn", cond_dim)
+    store.allocate(dev, seed)
+    return penc, pcnn, store
+
+
+def vqvae_impute(vqvae: VQVAE, partial_encoder: VQVAEPartialEncoder, partial_posterior, x: torch.Tensor,
+                 b: torch.Tensor, num_samples: int = 5, seed: int = 0, gumbel: Optional[torch.Tensor] = None):
+    """reference vqvae.py:269-312: imputations [B, num_samples, H, W, C] - codes sampled from the partially
+    observed posterior, decoded by the VQ-VAE, observed pixels kept, clipped to [0, 1]."""
+    B = x.shape[0]
+    ws = partial_encoder.ws
+    xob = ws.get("impute/x_o_b", tuple(x.shape[:-1]) + (x.shape[-1] + b.shape[-1],))
+    ops.mask_concat(x, b, xob)
+    cond = partial_encoder(xob)
+    samples = partial_posterior.sample(seed=seed, sample_shape=num_samples, conditional_input=cond, gumbel=gumbel)
+    idx = samples.permute(1, 0, 2, 3).contiguous()                            # [B, S, H, W]
+    q = vqvae.vq.quantize(idx.view((B * num_samples,) + tuple(idx.shape[2:])))
+    loc = vqvae.decoder(Feat(q))
+    imp = loc.view((B, num_samples) + tuple(loc.shape[1:])).clone()
+    ops.impute_blend(x, b, imp)
+    return imp
+
+
+def imputation_psnr(imputations: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """eval_pm_vqvae.py:133-136: PSNR [B] of the mean imputation against the full image."""
+    psnr = torch.empty(x.shape[0], device=x.device)
+    ops.imputation_psnr(imputations, x, psnr)
+    return psnr

@@ -527,6 +527,28 @@ def neg_mean_loss(ll, grad_scale: float, out, g_ll) -> None:
     _call("pm_neg_mean_loss", _ptr(ll), ll.numel(), grad_scale, _ptr(out), _ptr(g_ll))
 
 
+def categorical_sample(logits, gumbel, idx, P: int, pos: int) -> None:
+    """logits [B*P, K], gumbel [B, K], idx int32 [B*P] updated at position `pos` of every example"""
+    K = logits.shape[-1]
+    _call("pm_categorical_sample", _ptr(logits), _ptr(gumbel), _iptr(idx), gumbel.shape[0], K, P, pos)
+
+
+def impute_blend(x, mask, imp) -> None:
+    """imp [B,S,...image] <- clip(where(mask, x, imp), 0, 1) in place"""
+    B, S = imp.shape[0], imp.shape[1]
+    D, C, Cm = x.numel() // B, x.shape[-1], mask.shape[-1]
+    _call("pm_impute_blend", _ptr(x), _ptr(mask), _ptr(imp), B, S, D, C, Cm)
+
+
+def imputation_psnr(imp, x, psnr) -> None:
+    B, S = imp.shape[0], imp.shape[1]
+    _call("pm_imputation_psnr", _ptr(imp), _ptr(x), _ptr(psnr), B, S, x.numel() // B)
+
+
+def gumbel_fill(out, seed: int, step_dev=None, stream_id: int = 0) -> None:
+    _call("pm_gumbel_fill", _ptr(out), out.numel(), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
+
+
 def dropout_mask(out, rate: float, seed: int, step_dev, stream_id: int = 0) -> None:
     _call("pm_dropout_mask", _ptr(out), out.numel(), rate, seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
 

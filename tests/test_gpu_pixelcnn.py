@@ -363,3 +363,40 @@ def test_stage2_reference_config_small_batch():
     gd = ts.store.to_dict("g")
     for n in names:
         assert rel_err(gd[n], grads[n]) < 2e-4, (n, rel_err(gd[n], grads[n]))
+
+
+def test_sampling_imputation_and_psnr_match_oracle():
+    """PixelCNN ancestral sampling with explicit Gumbel noise, vqvae_impute and the held-out PSNR
+    (reference pixel_cnn.py:102-124, vqvae.py:269-312, eval_pm_vqvae.py:133-136)."""
+    from posterior_matching_amd.models.vqvae import imputation_psnr, vqvae_impute
+
+    B, S, xs = 3, 2, (12, 12, 1)
+    ts, p64, vq64, st64 = _stage2(TINY_CFG, TINY_VQ, xs, B)
+    rng = np.random.default_rng(5)
+    x, b = _batch(rng, B, xs)
+    K, P = TINY_VQ["num_embeddings"], 9
+    u = rng.uniform(1e-6, 1 - 1e-6, size=(P, B * S, K))
+    gumbel = torch.tensor(-np.log(-np.log(u)))
+    want = PO.vqvae_impute(p64, vq64, st64, TINY_CFG, TINY_VQ, x, b, S, gumbel)
+    want_psnr = PO.imputation_psnr(want, x)
+    got = vqvae_impute(ts.vqvae, ts.penc, ts.pcnn, f32d(x), f32d(b), num_samples=S, gumbel=f32d(gumbel))
+    psnr = imputation_psnr(got, f32d(x))
+    torch.cuda.synchronize()
+    assert got.shape == (B, S) + xs
+    assert rel_err(got, want) < 1e-5                 # identical code draws (no Gumbel near-tie at this seed)
+    assert rel_err(psnr, want_psnr) < 1e-5
+    obs = b.bool().expand(B, *xs)
+    assert torch.equal(got.cpu()[:, 0][obs], x.float()[obs]) and got.min() >= 0 and got.max() <= 1
+    # device noise path: reproducible for a seed, different across seeds, indices in range
+    cond = torch.randn((B, TINY_CFG["conditional_dim"]), device=dev())
+    s1 = ts.pcnn.sample(seed=7, sample_shape=S, conditional_input=cond)
+    s2 = ts.pcnn.sample(seed=7, sample_shape=S, conditional_input=cond)
+    s3 = ts.pcnn.sample(seed=8, sample_shape=S, conditional_input=cond)
+    assert s1.shape == (S, B, 3, 3) and torch.equal(s1, s2) and not torch.equal(s1, s3)
+    assert int(s1.min()) >= 0 and int(s1.max()) < K
+    assert ts.pcnn.sample(seed=1, conditional_input=cond).shape == (B, 3, 3)
+    # PSNR known answers (SURVEY.md 8c xii): uniform error e -> -20 log10 e ; identical images -> +inf
+    xi = torch.rand((2, 12, 12, 1), device=dev())
+    imp = (xi + 0.1).view(2, 1, 12, 12, 1).repeat(1, 3, 1, 1, 1).contiguous()
+    assert torch.allclose(imputation_psnr(imp, xi).cpu(), torch.full((2,), 20.0), atol=1e-3)
+    assert torch.isinf(imputation_psnr(xi.view(2, 1, 12, 12, 1).contiguous(), xi)).all()
