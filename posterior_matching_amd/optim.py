@@ -89,7 +89,10 @@ class Chain:
 
 
 def chain(*transforms) -> Chain:
-    """optax.chain(scale_by_adam, add_decayed_weights, scale_by_schedule(exponential_decay), scale(-1))."""
+    """optax.chain(scale_by_adam, [add_decayed_weights,] scale_by_schedule(exponential_decay), scale(-1)):
+    the 4-transform form of train_pm_vae.py:74-83 or the 3-transform form of train_pm_vqvae.py:115-120."""
+    if len(transforms) == 3 and isinstance(transforms[0], ScaleByAdam) and isinstance(transforms[1], ScaleBySchedule):
+        transforms = (transforms[0], AddDecayedWeights(0.0), transforms[1], transforms[2])
     if (len(transforms) != 4 or not isinstance(transforms[0], ScaleByAdam)
             or not isinstance(transforms[1], AddDecayedWeights) or not isinstance(transforms[2], ScaleBySchedule)
             or not isinstance(transforms[2].schedule, ExponentialDecay) or not isinstance(transforms[3], Scale)

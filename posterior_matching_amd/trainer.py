@@ -16,7 +16,7 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional
 import torch
 
 from . import ops
-from .engine import PMVAETrainStep, VQVAETrainStep
+from .engine import PMVAETrainStep, PMVQVAETrainStep, VQVAETrainStep
 from .models.vae import PosteriorMatchingVAE
 from .models.vqvae import VQVAE
 from .optim import Chain
@@ -38,6 +38,16 @@ class VQVAELoss:
 
     def __init__(self, config: Mapping[str, Any], model: VQVAE, data_key: str = "image"):
         self.config, self.model, self.data_key = config, model, data_key
+
+
+class PMVQVAELoss:
+    """loss_fn of train_pm_vqvae.py:81-99 as an object: frozen VQ-VAE -> code indices, partial encoder ->
+    conditional vector, loss = -mean PixelCNN.log_prob.  `vqvae` must carry the stage-1 parameters and
+    state; `partial_encoder` / `pixel_cnn` come from models.vqvae.build_partial_posterior."""
+
+    def __init__(self, config: Mapping[str, Any], vqvae: VQVAE, partial_encoder, pixel_cnn, data_key: str = "image"):
+        self.config, self.model, self.data_key = config, vqvae, data_key
+        self.partial_encoder, self.pixel_cnn = partial_encoder, pixel_cnn
 
 
 @dataclass
@@ -73,7 +83,14 @@ class Trainer:
     def __init__(self, loss_fn: PMVAELoss, optimizer: Chain, num_devices: int = 1, seed: int = 0,
                  trainable_predicate=None, skip_nonfinite_updates: bool = False, ema_rate: Optional[float] = None,
                  use_ema_for_eval: bool = False, use_graph: bool = True):
-        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss)):
+        if isinstance(loss_fn, PMVQVAELoss):
+            # train_pm_vqvae.py:122-123: the only predicate the reference uses freezes every module under "vqvae/";
+            # that is exactly what PMVQVAETrainStep does (the VQ-VAE lives on its own, never-updated store)
+            if trainable_predicate is not None and (trainable_predicate("vqvae/encoder", "w", None)
+                                                    or not trainable_predicate("pixel_cnn", "w", None)):
+                raise NotImplementedError("only the reference's predicate (freeze 'vqvae/...') is lowered")
+            trainable_predicate = None
+        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss, PMVQVAELoss)):
             raise NotImplementedError("Trainer lowers PMVAELoss / VQVAELoss (the loss_fn of train_pm_vae.py / "
                                       "train_vqvae.py) to the fused HIP step; arbitrary Python loss functions have "
                                       "no HIP path")
@@ -87,6 +104,13 @@ class Trainer:
                              "process per GPU, start it with torch.distributed.run --nproc-per-node num_devices")
 
     def _state(self, ts) -> TrainState:
+        if isinstance(ts, PMVQVAETrainStep):
+            # the reference's TrainState holds frozen and trainable parameters in one tree (vqvae/ prefix, :123)
+            params = {f"vqvae/{k}": v.cpu() for k, v in ts.vqvae.params_dict().items()}
+            params.update({k: v.cpu() for k, v in ts.store.to_dict("p").items()})
+            state = {f"vqvae/{k}": v.cpu() for k, v in ts.vqvae.state_dict().items()}
+            return TrainState(step=int(ts.step_dev.item()), params=params, state=state,
+                              opt_state={"mu": ts.store.flat_m.cpu(), "nu": ts.store.flat_v.cpu()})
         store = ts.model.store
         state = {k: v.cpu() for k, v in ts.model.state_dict().items()} if isinstance(ts.model, VQVAE) else {}
         return TrainState(step=int(ts.step_dev.item()), params={k: v.cpu() for k, v in store.to_dict("p").items()},
@@ -103,13 +127,20 @@ class Trainer:
         B, x_shape = x0.shape[0], tuple(x0.shape[1:])
         if model.store is None:
             model.init(x_shape, device=torch.device("cuda", self.local_rank), seed=self.seed)   # same init on all ranks
+        def strip(d):     # stage-1 checkpoints may carry the reference's "vqvae/" module prefix (train_pm_vqvae.py:123)
+            return {(k[len("vqvae/"):] if k.startswith("vqvae/") else k): v for k, v in d.items()}
+
         if initial_params is not None:
-            model.load_params(initial_params)
+            model.load_params(strip(initial_params))
         if initial_state is not None and isinstance(model, VQVAE):
-            model.load_state(initial_state)
+            model.load_state(strip(initial_state))
         dev = model.store.device
         is_vq = isinstance(lf, VQVAELoss)
-        if is_vq:
+        is_pmvq = isinstance(lf, PMVQVAELoss)
+        if is_pmvq:
+            ts = PMVQVAETrainStep(model, lf.partial_encoder, lf.pixel_cnn, self.optimizer, B, x_shape, seed=self.seed,
+                                  world_size=self.world, rank=self.rank)
+        elif is_vq:
             if self.world > 1:
                 model.vq.cross_replica_axis = "i"          # psum of the EMA statistics across ranks
             ts = VQVAETrainStep(model, self.optimizer, B, x_shape, world_size=self.world, rank=self.rank,
@@ -149,6 +180,8 @@ class Trainer:
         for i, vb in enumerate(batches):
             if isinstance(ts, VQVAETrainStep):
                 out = ts.evaluate(vb[key].to(dev))
+            elif isinstance(ts, PMVQVAETrainStep):
+                out = ts.evaluate(vb[key].to(dev), vb["mask"].to(dev))
             else:
                 x, b = vb[key].to(dev), vb["mask"].to(dev)
                 eps = torch.empty((x.shape[0], ts.model.latent_dim), device=dev)

@@ -400,3 +400,44 @@ def test_sampling_imputation_and_psnr_match_oracle():
     imp = (xi + 0.1).view(2, 1, 12, 12, 1).repeat(1, 3, 1, 1, 1).contiguous()
     assert torch.allclose(imputation_psnr(imp, xi).cpu(), torch.full((2,), 20.0), atol=1e-3)
     assert torch.isinf(imputation_psnr(xi.view(2, 1, 12, 12, 1).contiguous(), xi)).all()
+
+
+def test_two_stage_scripts_end_to_end(tmp_path):
+    """train_vqvae.py -> train_pm_vqvae.py -> eval_pm_vqvae.py on small network sizes: the stage-1 run
+    directory feeds stage 2, stage 2 checkpoints both trees, the PSNR script reads them back."""
+    import json
+    import os
+    import pickle
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(script, *argv):
+        out = subprocess.run([sys.executable, os.path.join(root, script), *argv], cwd=tmp_path, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        return out.stdout
+
+    run("train_vqvae.py", "--config", os.path.join(root, "configs", "vqvae_mnist.py"), "--config.steps=20",
+        "--config.validation_freq=20", "--config.seed=1")
+    stage1 = os.path.join(tmp_path, "runs", [d for d in os.listdir(os.path.join(tmp_path, "runs")) if d.startswith("vqvae-")][0])
+    run("train_pm_vqvae.py", "--config", os.path.join(root, "configs", "pm_vqvae_mnist.py"), f"--config.vqvae_dir={stage1}",
+        "--config.steps=6", "--config.validation_freq=3", "--config.seed=2", "--config.pixel_cnn.num_resnet=1",
+        "--config.pixel_cnn.num_filters=32", "--config.conditional_dim=64", "--config.data.train_batch_size=8",
+        "--config.data.val_batch_size=8")
+    stage2 = os.path.join(tmp_path, "runs", [d for d in os.listdir(os.path.join(tmp_path, "runs")) if d.startswith("pm-vqvae-")][0])
+    lines = [json.loads(l) for l in open(os.path.join(stage2, "tb", "scalars.jsonl"))]
+    assert [l["step"] for l in lines] == [3, 6] and all(np.isfinite(l["train_loss"]) and np.isfinite(l["val_loss"]) for l in lines)
+    imp = np.load(os.path.join(stage2, "tb", "imputations_6.npy"))
+    assert imp.shape == (3, 28, 28 * 7, 1) and imp.min() >= 0.0 and imp.max() <= 1.0
+    sys.path.insert(0, root)
+    s1 = pickle.load(open(os.path.join(stage1, "train_state.pkl"), "rb"))
+    s2 = pickle.load(open(os.path.join(stage2, "train_state.pkl"), "rb"))
+    assert s2.step == 6 and int(s2.state["vqvae/counter"]) == 20
+    for k, v in s1.params.items():                                  # stage 2 never touches the VQ-VAE
+        assert torch.equal(s2.params["vqvae/" + k], v), k
+    assert any(k.startswith("pixel_cnn/") for k in s2.params) and any(k.startswith("partial_encoder/") for k in s2.params)
+    out = run("eval_pm_vqvae.py", "--run_dir", stage2, "--num_instances", "16", "--batch_size", "8", "--num_samples", "2")
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["num_instances"] == 16 and np.isfinite(res["mean_psnr"]) and 0.0 < res["mean_psnr"] < 60.0

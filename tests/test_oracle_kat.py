@@ -310,3 +310,77 @@ def test_vqvae_gradcheck_small():
         lm = VO.vqvae_loss({**p, name: p[name] - h * d}, st, CFG, x, True)[0]
         fd = (lp - lm).item() / (2 * h)
         assert fd == pytest.approx((grads[name] * d).sum().item(), rel=1e-5), name
+
+
+# ----------------------------------------------------------------------------------------------
+# PixelCNN oracle (oracle/pixel_cnn_oracle.py)
+# ----------------------------------------------------------------------------------------------
+def _small_pixelcnn(seed=0, cond_dim=6):
+    from oracle import pixel_cnn_oracle as PO
+
+    cfg = {"num_indices": 11, "num_resnet": 2, "num_filters": 8, "num_hierarchies": 1}
+    gen = torch.Generator().manual_seed(seed)
+    p = {k: torch.randn(s, generator=gen) * 0.3 for k, s in PO.pixel_cnn_param_shapes("pc", cfg, cond_dim).items()}
+    return PO, cfg, p, gen
+
+
+def test_pixelcnn_kernel_masks():
+    from oracle import pixel_cnn_oracle as PO
+
+    plan = PO.kernel_plan((3, 3))
+    assert plan["vertical"][0] == (3, 3) and plan["vertical"][1][:, :, 0, 0].tolist() == [[1, 1, 1], [1, 1, 1], [0, 0, 0]]
+    assert plan["horizontal"][1][:, :, 0, 0].tolist() == [[1, 1, 0], [1, 1, 0], [0, 0, 0]]
+    assert plan["vertical_init"][0] == (5, 3) and plan["vertical_init"][1][:, :, 0, 0].sum() == 6
+    assert plan["horizontal_up"][1][:, :, 0, 0].tolist() == [[1, 1, 1], [0, 0, 0], [0, 0, 0]]
+    assert plan["horizontal_left"][1][:, :, 0, 0].tolist() == [[1, 0, 0], [1, 0, 0], [0, 0, 0]]
+
+
+def test_pixelcnn_is_autoregressive_and_normalised():
+    PO, cfg, p, gen = _small_pixelcnn()
+    idx = torch.randint(0, 11, (2, 5, 5), generator=gen)
+    cond = torch.randn(2, 6, generator=gen)
+    base = PO.pixel_cnn_logits(p, "pc", idx, cfg, cond)
+    for (r, c) in [(0, 0), (2, 2), (4, 4), (1, 3)]:
+        idx2 = idx.clone()
+        idx2[:, r, c] = (idx2[:, r, c] + 1) % 11
+        changed = ((PO.pixel_cnn_logits(p, "pc", idx2, cfg, cond) - base).abs().amax(-1) > 1e-12)[0]
+        for rr in range(5):
+            for cc in range(5):
+                if (rr, cc) <= (r, c):
+                    assert not changed[rr, cc], ((r, c), (rr, cc))        # no look-ahead, not even at the pixel itself
+        assert int(changed.sum()) == 25 - (r * 5 + c) - 1               # and every later pixel does see it
+    # the chain rule over a 2x2 grid of 3 symbols sums to one
+    cfg3 = dict(cfg, num_indices=3)
+    p3 = {k: torch.randn(s, generator=gen) * 0.3 for k, s in PO.pixel_cnn_param_shapes("pc", cfg3, 6).items()}
+    import itertools
+    grids = torch.tensor(list(itertools.product(range(3), repeat=4))).reshape(-1, 2, 2)
+    lp = PO.pixel_cnn_log_prob(p3, "pc", grids, cfg3, cond[:1].expand(81, 6))
+    assert torch.exp(lp).sum().item() == pytest.approx(1.0, abs=1e-10)
+
+
+def test_pixelcnn_reference_config_param_count():
+    from oracle import pixel_cnn_oracle as PO
+    from tests.ref_configs import pm_vqvae_mnist, vqvae_mnist
+
+    cfg = dict(pm_vqvae_mnist()["pixel_cnn"], num_indices=256)
+    n_pc = sum(int(np.prod(s)) for s in PO.pixel_cnn_param_shapes("pixel_cnn", cfg, 512).values())
+    n_pe = sum(int(np.prod(s)) for s in PO.partial_encoder_param_shapes("pe", vqvae_mnist()["model"], 2, (7, 7), 512).values())
+    assert n_pc == 34184832 and n_pe == 841936        # 34.2 M and 841 936
+
+
+def test_pixelcnn_dropout_and_sampling_helpers():
+    PO, cfg, p, gen = _small_pixelcnn(1)
+    cfg = dict(cfg, image_shape=(3, 3))
+    idx = torch.randint(0, 11, (2, 3, 3), generator=gen)
+    cond = torch.randn(2, 6, generator=gen)
+    ones = [torch.ones(2, 3, 3, 16) for _ in range(8)]
+    assert torch.allclose(PO.pixel_cnn_logits(p, "pc", idx, cfg, cond, ones), PO.pixel_cnn_logits(p, "pc", idx, cfg, cond))
+    g = -torch.log(-torch.log(torch.rand(9, 2 * 3, 11, generator=gen).clamp(1e-9, 1 - 1e-9)))
+    s = PO.pixel_cnn_sample(p, "pc", cfg, cond, 3, g)
+    assert s.shape == (3, 2, 3, 3) and int(s.min()) >= 0 and int(s.max()) < 11
+    # a very peaked noise row forces the draw
+    g2 = g.clone()
+    g2[:, :, 4] += 1e6
+    assert (PO.pixel_cnn_sample(p, "pc", cfg, cond, 3, g2) == 4).all()
+    x = torch.rand(2, 4, 4, 1)
+    assert torch.allclose(PO.imputation_psnr((x + 0.1)[:, None].repeat(1, 3, 1, 1, 1), x), torch.full((2,), 20.0))
