@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpmhip.so")
 
-ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 AUX_AFTER_RES = 16  # PM_AUX_AFTER_RES (include/pmhip.h)
 LEAKY_SLOPE = 0.01  # jax.nn.leaky_relu default negative_slope
 
@@ -118,6 +118,28 @@ SIGNATURES = {
     "pm_imputation_psnr": [_P, _P, _P, _P, _LL, _I, _LL],
     "pm_gumbel_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
     "pm_dropout_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
+    "pm_gelu_fwd": [_P, _P, _P, _P, _LL, _I, _I],
+    "pm_gelu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I],
+    "pm_avgpool_fwd": [_P, _P, _P, _I, _I, _I, _I, _I],
+    "pm_avgpool_bwd": [_P, _P, _P, _I, _I, _I, _I, _I],
+    "pm_resize_nearest_add": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "pm_resize_nearest_add_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "pm_broadcast_rows": [_P, _P, _P, _LL, _LL],
+    "pm_add_cols": [_P, _P, _P, _I, _I, _P, _LL, _I],
+    "pm_copy_cols": [_P, _P, _P, _I, _I, _LL, _I],
+    "pm_scale_shift": [_P, _P, _F, _F, _P, _LL],
+    "pm_diag_sample_kl_fwd": [_P, _P, _P, _I, _P, _P, _P, _LL, _I, _I],
+    "pm_diag_sample_kl_bwd": [_P, _P, _P, _I, _P, _P, _F, _P, _P, _LL, _I],
+    "pm_diag_tril_kl_fwd": [_P, _P, _P, _P, _LL, _I, _I],
+    "pm_diag_tril_kl_bwd": [_P, _P, _P, _F, _P, _LL, _I, _I],
+    "pm_affine_fwd": [_P, _P, _P, _P, _P, _LL, _I],
+    "pm_affine_bwd": [_P, _P, _P, _P, _P, _P, _P, _LL, _I],
+    "pm_dmol_ll_fwd": [_P, _P, _P, _P, _LL, _I, _I, _F, _F],
+    "pm_dmol_ll_bwd": [_P, _P, _P, _F, _P, _LL, _I, _I, _F, _F],
+    "pm_dmol_mean": [_P, _P, _P, _LL, _I, _F, _F],
+    "pm_vdvae_loss": [_P, _P, _P, _P, _I, _F, _P],
+    "pm_sumsq": [_P, _P, _LL, _P],
+    "pm_adam_step_clip_ema": [_P, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, C.POINTER(AdamCfg), _F, _F, _I],
     "pm_pmvae_loss": [_P, _P, _P, _P, _I, C.POINTER(LossCfg), _P, _P, _P, _P, _P],
     "pm_adam_step": [_P, _P, _P, _P, _P, _LL, _LL, _P, C.POINTER(AdamCfg)],
     "pm_counter_increment": [_P, _P],

@@ -15,9 +15,17 @@ int pm_check_launch(const char* what);
 // of the range non-zero on replay (tests/test_gpu_vqvae.py::test_vqvae_train_steps_match_oracle).
 int pm_zero_async(hipStream_t stream, void* ptr, size_t nbytes);
 
+__device__ __forceinline__ float pm_gelu_tanh(float x) {      // jax.nn.gelu(approximate=True)
+    return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float pm_gelu_tanh_d(float x) {
+    const float t = tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x));
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 0.134145f * x * x);
+}
 __device__ __forceinline__ float pm_act(float v, int act, float slope) {
     if (act == PM_ACT_LEAKY) return v >= 0.f ? v : slope * v;  // jax.nn.leaky_relu: where(x >= 0, x, a*x)
     if (act == PM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == PM_ACT_GELU) return pm_gelu_tanh(v);
     return v;
 }
 // derivative expressed on the activation's OUTPUT (sign is preserved by both activations) or on
@@ -25,6 +33,7 @@ __device__ __forceinline__ float pm_act(float v, int act, float slope) {
 __device__ __forceinline__ float pm_dact(float v, int act, float slope) {
     if (act == PM_ACT_LEAKY) return v >= 0.f ? 1.f : slope;
     if (act == PM_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if (act == PM_ACT_GELU) return pm_gelu_tanh_d(v);   // on the activation's INPUT only (gelu is not monotone)
     return 1.f;
 }
 

@@ -94,6 +94,55 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ void counter_increment_kernel(int* c) { c[0] += 1; }
 
+// sum of squares with a non-finite guard: out[0] += sum x^2 (NaN / inf propagate into the sum)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) s = fmaf(x[i], x[i], s);
+    s = pm_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// train_pm_vdvae.py:131-154: clip_by_global_norm -> scale_by_adam -> add_decayed_weights -> schedule -> scale(-1),
+// Trainer(skip_nonfinite_updates=True, ema_rate).  gnorm_sq holds sum g^2 of the (already reduced) gradient;
+// `count` is the optimizer's own update counter (it does not advance on a skipped step).
+__global__ __launch_bounds__(256) void adam_clip_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              float* __restrict__ ema, long long n, long long n_decay,
+                                                              const int* __restrict__ count_dev,
+                                                              const float* __restrict__ gnorm_sq, pm_adam_cfg c,
+                                                              float clip, float ema_rate, int skip_nonfinite) {
+    const float gn = sqrtf(gnorm_sq[0]) * c.grad_scale;
+    if (skip_nonfinite && !isfinite(gn)) return;                 // every thread sees the same value
+    const float cs = (clip > 0.f && !(gn < clip)) ? clip / gn : 1.f;   // optax: where(g_norm < max_norm, g, g/g_norm*max_norm)
+    const int count = count_dev[0];
+    const float t = (float)(count + 1);
+    const float bc1 = 1.f - powf(c.b1, t);
+    const float bc2 = 1.f - powf(c.b2, t);
+    const float lr = c.lr_init * powf(c.lr_decay_rate, (float)count / c.lr_transition_steps);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gi = g[i] * c.grad_scale * cs;
+        float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
+        float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float u = (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
+        float pi = p[i];
+        if (i < n_decay) u += c.weight_decay * pi;
+        pi -= lr * u;
+        p[i] = pi;
+        if (ema) ema[i] = ema_rate * ema[i] + (1.f - ema_rate) * pi;
+    }
+}
+
+__global__ void counter_increment_if_finite_kernel(int* c, const float* gnorm_sq) {
+    if (isfinite(gnorm_sq[0])) c[0] += 1;
+}
+
 // out[n] += sum_m x[m][n]: bias gradient of a transposed-conv layer (its weight gradient runs with
 // the roles of x and dy swapped, so the column sums of dy are taken here).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long M,
@@ -231,6 +280,30 @@ extern "C" int pm_adam_step(pm_stream_t stream, float* p, const float* g, float*
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, n_decay,
                        count_dev, *cfg);
     return pm_check_launch("pm_adam_step");
+}
+
+extern "C" int pm_sumsq(pm_stream_t stream, const float* x, long long n, float* out) {
+    if (!x || !out || n <= 0) return PM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (pm_zero_async(s, out, sizeof(float))) return PM_ELAUNCH;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, out);
+    return pm_check_launch("pm_sumsq");
+}
+
+extern "C" int pm_adam_step_clip_ema(pm_stream_t stream, float* p, const float* g, float* m, float* v, float* ema,
+                                     long long n, long long n_decay, int* count_dev, const float* gnorm_sq,
+                                     const pm_adam_cfg* cfg, float clip, float ema_rate, int skip_nonfinite) {
+    if (!p || !g || !m || !v || !count_dev || !gnorm_sq || !cfg || n <= 0) return PM_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_clip_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, n_decay,
+                       count_dev, gnorm_sq, *cfg, clip, ema_rate, skip_nonfinite);
+    if (skip_nonfinite) hipLaunchKernelGGL(counter_increment_if_finite_kernel, dim3(1), dim3(1), 0, s, count_dev, gnorm_sq);
+    else hipLaunchKernelGGL(counter_increment_kernel, dim3(1), dim3(1), 0, s, count_dev);
+    return pm_check_launch("pm_adam_step_clip_ema");
 }
 
 extern "C" int pm_counter_increment(pm_stream_t stream, int* count_dev) {

@@ -320,3 +320,87 @@ class PMVQVAETrainStep:
         with torch.cuda.stream(self.stream):
             self.forward(False)
         return self.read_metrics()
+
+
+class VDVAETrainStep:
+    """train_pm_vdvae.py:109-154 as one launch sequence: eps -> PosteriorMatchingVDVAE forward ->
+    loss = -mean(rec_ll - kl) + mean(pm_kl) -> backward -> [gradient all-reduce] -> global-norm clip +
+    Adam (+ parameter EMA, non-finite steps skipped) -> step += 1."""
+
+    def __init__(self, model, lr: float, batch_size: int, gradient_clip: float = 200.0, ema_rate: Optional[float] = 0.999,
+                 weight_decay: float = 0.0, adam: Optional[Mapping[str, float]] = None, seed: int = 0, world_size: int = 1,
+                 rank: int = 0, external_eps: bool = False, skip_nonfinite_updates: bool = True):
+        from ._lib import AdamCfg
+
+        if model.store is None:
+            model.init()
+        s = model.store
+        dev = s.device
+        self.model, self.B, self.world_size, self.rank, self.seed = model, batch_size, world_size, rank, seed
+        adam = dict(adam or {})
+        c = AdamCfg()
+        c.b1, c.b2, c.eps = adam.get("b1", 0.9), adam.get("b2", 0.999), adam.get("eps", 1e-8)
+        c.weight_decay, c.lr_init, c.lr_decay_rate, c.lr_transition_steps = weight_decay, lr, 1.0, 1.0
+        c.grad_scale = 1.0 / world_size
+        self.adam_cfg, self.clip, self.skip = c, float(gradient_clip or 0.0), skip_nonfinite_updates
+        self.ema_rate = ema_rate
+        self.ema = s.flat_p.clone() if ema_rate is not None else None       # bax: ema_params start at the parameters
+        H, W_, C = model.config["image_shape"]
+        self.x = torch.zeros((batch_size, H, W_, C), device=dev)
+        self.b = torch.zeros((batch_size, H, W_, 1), device=dev)
+        shapes = model.eps_shapes(batch_size)
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+        self.eps_flat = torch.zeros(sum(sizes), device=dev)
+        self.eps, off = [], 0
+        for sh, n in zip(shapes, sizes):
+            self.eps.append(self.eps_flat[off:off + n].view(sh))
+            off += n
+        self.external_eps = external_eps
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # training step (RNG counter)
+        self.opt_count = torch.zeros(1, dtype=torch.int32, device=dev)     # optax count: not advanced by skipped steps
+        self.gnorm_sq = torch.zeros(1, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+
+    def _sequence(self) -> None:
+        m, s = self.model, self.model.store
+        if not self.external_eps:
+            ops.normal_fill(self.eps_flat, self.seed, self.step_dev, stream_id=self.rank)
+        m(self.x, self.b, self.eps)
+        m.zero_grad()
+        m.backward()
+        if self.world_size > 1:
+            from .parallel import allreduce_sum_
+
+            allreduce_sum_(s.flat_g)
+        ops.sumsq(s.flat_g, self.gnorm_sq)
+        ops.adam_step_clip_ema(s.flat_p, s.flat_g, s.flat_m, s.flat_v, self.ema, s.n_decay, self.opt_count, self.gnorm_sq,
+                               self.adam_cfg, self.clip, self.ema_rate if self.ema_rate is not None else 0.0, self.skip)
+        s.split_all()
+        ops.counter_increment(self.step_dev)
+
+    def step(self) -> None:
+        with torch.cuda.stream(self.stream):
+            self._sequence()
+
+    def set_batch(self, x: torch.Tensor, b: torch.Tensor, eps: Optional[Sequence[torch.Tensor]] = None) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+            self.b.copy_(b.reshape(self.b.shape), non_blocking=True)
+            if eps is not None:
+                for dst, src in zip(self.eps, eps):
+                    dst.copy_(src, non_blocking=True)
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def read_metrics(self) -> Dict[str, float]:
+        self.stream.synchronize()
+        v = self.model.metrics.cpu().tolist()
+        return {"loss": v[0], "reconstruction_ll": v[1], "kl": v[2], "pm_kl": v[3], "bpd": v[4],
+                "grad_norm": float(self.gnorm_sq.sqrt().item()) / self.world_size}
+
+    def ema_params(self) -> Dict[str, torch.Tensor]:
+        s = self.model.store
+        return {n: self.ema[o:o + c].view(s.specs[n][0]).detach().clone() for n, (o, c) in s.offsets.items()}

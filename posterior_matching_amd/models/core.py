@@ -51,7 +51,8 @@ class ParamStore:
 
     def add(self, name: str, shape, fan_in: int = 0) -> None:
         """fan_in > 0: haiku TruncatedNormal(stddev = 1/sqrt(fan_in)); 0: zeros; -1: TruncatedNormal(stddev 1)
-        (hk.Embed); -2: RandomNormal(stddev 1) (PixelCNN conditional projections, pixel_cnn.py:567)."""
+        (hk.Embed); -2: RandomNormal(stddev 1) (PixelCNN conditional projections, pixel_cnn.py:567); -3: ones
+        (VDVAE gain, vdvae.py:807-809)."""
         assert name not in self.specs, name
         assert self.flat_p is None, "parameters are frozen once allocated"
         self.specs[name] = (tuple(int(s) for s in shape), int(fan_in))
@@ -75,6 +76,8 @@ class ParamStore:
                 host[name] = truncnorm.rvs(-2.0, 2.0, size=shape, random_state=rng).astype(np.float32)
             elif fan_in == -2:
                 host[name] = rng.normal(size=shape).astype(np.float32)
+            elif fan_in == -3:
+                host[name] = np.ones(shape, np.float32)
             else:
                 host[name] = np.zeros(shape, np.float32)
         decayed = [n for n, (s, _) in self.specs.items() if len(s) != 1]

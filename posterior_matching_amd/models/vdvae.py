@@ -1,0 +1,434 @@
+"""Host-side mirror of posterior_matching/models/vdvae.py of the reference: PosteriorMatchingVDVAE.
+
+Same constructor arguments and `__call__(x, b)` outputs (reference vdvae.py:41-94); the arithmetic
+runs in libpmhip.so: every 1x1 / 3x3 convolution in the gather-GEMM engine (gelu' of a Block's
+hidden activations fused into the data-gradient epilogue), the rest in the row-wise kernels of
+csrc/pm_vdvae.hip.  There is no autodiff: `backward()` walks the buffers the forward left in HBM,
+in reverse block order, accumulating the gradients of tensors with several consumers (the shared
+encoder activations of a resolution, the per-resolution decoder state, the mix-in sources).
+
+Not implemented here (no reference config needs them): custom_width_string (per-resolution widths
+with channel padding), multi-channel logistic mixtures (coefficients), is_log_probs / impute / sample.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_NONE, LayerGeom
+from .core import Module, ParamStore, Workspace
+
+
+def parse_layer_string(s: str) -> List[Tuple[int, Optional[int]]]:
+    """reference vdvae.py:213-229"""
+    layers: List[Tuple[int, Optional[int]]] = []
+    for ss in s.split(","):
+        if "x" in ss:
+            res, num = ss.split("x")
+            layers += [(int(res), None) for _ in range(int(num))]
+        elif "m" in ss:
+            res, mixin = [int(a) for a in ss.split("m")]
+            layers.append((res, mixin))
+        elif "d" in ss:
+            res, down = [int(a) for a in ss.split("d")]
+            layers.append((res, down))
+        else:
+            layers.append((int(ss), None))
+    return layers
+
+
+class _Conv:
+    def __init__(self, store: ParamStore, name: str, geom: LayerGeom, fan_in: int):
+        self.g, self.w, self.b = geom, f"{name}/w", f"{name}/b"
+        store.add(self.w, geom.weight_shape, fan_in=fan_in)
+        store.add(self.b, (geom.CO,))
+        self.ws_f = store.request_split(self.w, geom, "fwd")
+        self.ws_d = store.request_split(self.w, geom, "dgrad")
+
+
+class Block(Module):
+    """reference vdvae.py:263-299 without the pooling (the caller pools): four convolutions with gelu
+    in front of each.  `forward` takes the ALREADY activated input gelu(x) (the callers build it, possibly
+    from two concatenated sources) and an optional residual tensor added to the last conv's output."""
+
+    def __init__(self, store: ParamStore, ws: Workspace, name: str, H: int, W: int, cin: int, mid: int, cout: int,
+                 use_3x3: bool, zero_last: bool = False, out_init_div: int = 1):
+        super().__init__(name)
+        self.attach(store, name)
+        self.ws = ws
+        k = 3 if use_3x3 else 1
+        pad = "SAME"
+        self.c1 = _Conv(store, f"{name}/c1", LayerGeom.conv(H, W, cin, mid, 1, 1, pad), cin)
+        self.c2 = _Conv(store, f"{name}/c2", LayerGeom.conv(H, W, mid, mid, k, 1, pad), k * k * mid)
+        self.c3 = _Conv(store, f"{name}/c3", LayerGeom.conv(H, W, mid, mid, k, 1, pad), k * k * mid)
+        # get_1x1(zero_last / init_multiple = sqrt(1/N)) (:193-205): stddev * sqrt(1/N) <=> fan_in * N
+        self.c4 = _Conv(store, f"{name}/c4", LayerGeom.conv(H, W, mid, cout, 1, 1, pad), 0 if zero_last else mid * out_init_div)
+        self.H, self.W, self.cin, self.mid, self.cout = H, W, cin, mid, cout
+
+    def _f(self, L: _Conv, x, out, res=None):
+        ops.layer_forward(L.g, x, self.store.p[L.w], self.store.p[L.b], out, res=res, wsplit=self.store.split_view(L.ws_f))
+
+    def forward(self, xg: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, H, W = xg.shape[0], self.H, self.W
+        self._xg = xg
+        sh = lambda c: (B, H, W, c)   # noqa: E731
+        self._h, self._g = [], []
+        x = xg
+        for i, L in enumerate((self.c1, self.c2, self.c3)):
+            h = self.buf(f"h{i + 1}", sh(self.mid))
+            self._f(L, x, h)
+            g = self.buf(f"g{i + 1}", sh(self.mid))
+            ops.gelu_fwd(h, None, g)
+            self._h.append(h)
+            self._g.append(g)
+            x = g
+        out = self.buf("out", sh(self.cout))
+        self._f(self.c4, x, out, res=res)
+        return out
+
+    def backward(self, dout: torch.Tensor, dx: torch.Tensor, x_pre: Optional[torch.Tensor] = None,
+                 res: Optional[torch.Tensor] = None) -> None:
+        """dout: gradient w.r.t. the last conv's output.  Writes into dx the gradient w.r.t. the activated
+        input gelu(x) - or, when x_pre (the single-source pre-activation x) is given, w.r.t. x itself:
+        dx = dgrad * gelu'(x_pre) + res (one fused epilogue)."""
+        B = dout.shape[0]
+        sh = lambda c: (B, self.H, self.W, c)   # noqa: E731
+        d = dout
+        layers = (self.c1, self.c2, self.c3, self.c4)
+        for i in (3, 2, 1):
+            L = layers[i]
+            self.wgrad(L.g, self._g[i - 1], d, self.store.g[L.w], self.store.g[L.b])
+            dh = self.buf(f"dh{i}", sh(self.mid))
+            ops.layer_dgrad(L.g, d, self.store.p[L.w], dh, aux=self._h[i - 1], aux_act=ACT_GELU,
+                            wsplit=self.store.split_view(L.ws_d))
+            d = dh
+        self.wgrad(self.c1.g, self._xg, d, self.store.g[self.c1.w], self.store.g[self.c1.b])
+        if x_pre is not None:
+            ops.layer_dgrad(self.c1.g, d, self.store.p[self.c1.w], dx, aux=x_pre, aux_act=ACT_GELU, res=res,
+                            wsplit=self.store.split_view(self.c1.ws_d))
+        else:
+            ops.layer_dgrad(self.c1.g, d, self.store.p[self.c1.w], dx, wsplit=self.store.split_view(self.c1.ws_d))
+
+
+class Encoder(Module):
+    """reference vdvae.py:302-348: 3x3 stem + residual bottleneck blocks, AvgPool at the `d` blocks;
+    returns the last activation of every resolution."""
+
+    def __init__(self, width: int, blocks: str, bottleneck_multiple: float, custom_width_string: Optional[str] = None,
+                 name: Optional[str] = None):
+        super().__init__(name)
+        if custom_width_string:
+            raise NotImplementedError("custom_width_string has no HIP path (the reference configs leave it None)")
+        self.width, self.blocks_spec, self.mid = width, parse_layer_string(blocks), int(width * bottleneck_multiple)
+
+    def build(self, store: ParamStore, prefix: str, in_shape) -> None:
+        self.attach(store, prefix)
+        H, W, C = in_shape
+        assert H == W
+        self.stem = _Conv(store, f"{prefix}/stem", LayerGeom.conv(H, W, C, self.width, 3, 1, "SAME"), 9 * C)
+        self.blocks: List[Tuple[Block, Optional[int], int]] = []
+        n = len(self.blocks_spec)
+        res = H
+        for i, (r, down) in enumerate(self.blocks_spec):
+            assert r == res, f"encoder block {i} declared at resolution {r} but the running resolution is {res}"
+            blk = Block(store, self.ws, f"{prefix}/block_{i}", res, res, self.width, self.mid, self.width, res > 2,
+                        out_init_div=n)
+            self.blocks.append((blk, down, res))
+            if down is not None:
+                res = res // down
+
+    def __call__(self, x: torch.Tensor) -> Dict[int, torch.Tensor]:
+        B = x.shape[0]
+        self._x = x
+        g = self.stem.g
+        h = self.buf("stem_out", (B, g.OH, g.OW, g.CO))
+        ops.layer_forward(g, x, self.store.p[self.stem.w], self.store.p[self.stem.b], h,
+                          wsplit=self.store.split_view(self.stem.ws_f))
+        acts = {h.shape[1]: h}
+        self._ins, self._outs = [], []
+        for i, (blk, down, res) in enumerate(self.blocks):
+            xg = self.buf(f"block_{i}/xg", tuple(h.shape))
+            ops.gelu_fwd(h, None, xg)
+            out = blk.forward(xg, res=h)
+            self._ins.append(h)
+            if down is not None:
+                pooled = self.buf(f"block_{i}/pooled", (B, res // down, res // down, self.width))
+                ops.avgpool_fwd(out, pooled, down)
+                out = pooled
+            self._outs.append(out)
+            h = out
+            acts[h.shape[1]] = h
+        self._acts = acts
+        return acts
+
+    def backward(self, dacts: Dict[int, torch.Tensor]) -> None:
+        """dacts[res]: gradient w.r.t. the exported activation of each resolution (from the decoder)."""
+        exported = {t.data_ptr(): r for r, t in self._acts.items()}
+        dh = None
+        for i in reversed(range(len(self.blocks))):
+            blk, down, res = self.blocks[i]
+            out = self._outs[i]
+            r_out = exported.get(out.data_ptr())
+            if r_out is not None:
+                if dh is None:
+                    dh = dacts[r_out]
+                else:
+                    ops.axpy1(dacts[r_out], dh)
+            if down is not None:
+                dfull = self.buf(f"block_{i}/dfull", tuple(blk._xg.shape[:3]) + (self.width,))
+                ops.avgpool_bwd(dh, dfull, down)
+                dh = dfull
+            dprev = self.buf(f"block_{i}/dx", tuple(self._ins[i].shape))
+            blk.backward(dh, dprev, x_pre=self._ins[i], res=dh)
+            dh = dprev
+        stem_out = self._ins[0]
+        r0 = exported.get(stem_out.data_ptr())
+        if r0 is not None:
+            ops.axpy1(dacts[r0], dh)
+        self.wgrad(self.stem.g, self._x, dh, self.store.g[self.stem.w], self.store.g[self.stem.b])
+
+
+class PosteriorMatchingDecoderBlock(Module):
+    """reference vdvae.py:479-687 (forward_posterior path)."""
+
+    def __init__(self, store: ParamStore, ws: Workspace, name: str, latent_dim: int, res: int, mixin: Optional[int],
+                 num_blocks: int, width: int, mid: int):
+        super().__init__(name)
+        self.attach(store, name)
+        self.ws = ws
+        self.base, self.mixin, self.Z, self.width = res, mixin, latent_dim, width
+        Z, u3 = latent_dim, res > 2
+        self.posterior = Block(store, ws, f"{name}/posterior", res, res, 2 * width, mid, 2 * Z, u3)
+        self.masked_posterior = Block(store, ws, f"{name}/masked_posterior", res, res, 2 * width, mid,
+                                      Z + Z * (Z + 1) // 2, u3)
+        self.prior = Block(store, ws, f"{name}/prior", res, res, width, mid, 2 * Z + width, u3, zero_last=True)
+        self.z_proj = _Conv(store, f"{name}/z_proj", LayerGeom.conv(res, res, Z, width, 1, 1, "SAME"), Z * num_blocks)
+        self.resnet = Block(store, ws, f"{name}/resnet", res, res, width, mid, width, u3, out_init_div=num_blocks)
+
+    def forward(self, x_in: torch.Tensor, acts: torch.Tensor, macts: torch.Tensor, eps: torch.Tensor,
+                kl: torch.Tensor, pm_kl: torch.Tensor) -> torch.Tensor:
+        B, r, W, Z = x_in.shape[0], self.base, self.width, self.Z
+        P = r * r
+        sh = lambda c: (B, r, r, c)   # noqa: E731
+        self._x_in, self._acts, self._macts, self._eps = x_in, acts, macts, eps
+        a = self.buf("a", sh(2 * W))
+        ops.gelu_fwd(x_in, acts, a)
+        self._pp = self.posterior.forward(a)
+        am = self.buf("am", sh(2 * W))
+        ops.gelu_fwd(x_in, macts, am)                      # stop_gradient(x): handled in backward (:536-538)
+        self._mp = self.masked_posterior.forward(am)
+        ap = self.buf("ap", sh(W))
+        ops.gelu_fwd(x_in, None, ap)
+        self._pr = self.prior.forward(ap)
+        x1 = self.buf("x1", sh(W))
+        ops.add_cols(x_in, self._pr, 2 * Z, x1)              # x += h (:558)
+        self._z = self.buf("z", sh(Z))
+        ops.diag_sample_kl_fwd(self._pp, self._pr, eps, self._z, kl, P)
+        ops.diag_tril_kl_fwd(self._pp, self._mp, pm_kl, Z, P)
+        x2 = self.buf("x2", sh(W))
+        ops.layer_forward(self.z_proj.g, self._z, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
+                          wsplit=self.store.split_view(self.z_proj.ws_f))
+        self._x2 = x2
+        x2g = self.buf("x2g", sh(W))
+        ops.gelu_fwd(x2, None, x2g)
+        return self.resnet.forward(x2g, res=x2)
+
+    def backward(self, dx3: torch.Tensor, dacts: torch.Tensor, dmacts: torch.Tensor, g_kl: float, g_pm: float) -> torch.Tensor:
+        """dx3: gradient w.r.t. this block's output.  Accumulates into dacts / dmacts (the encoder
+        activations of this resolution) and returns the gradient w.r.t. x_in."""
+        B, r, W, Z = dx3.shape[0], self.base, self.width, self.Z
+        P = r * r
+        sh = lambda c: (B, r, r, c)   # noqa: E731
+        dx2 = self.buf("dx2", sh(W))
+        self.resnet.backward(dx3, dx2, x_pre=self._x2, res=dx3)                 # dx2 = dx1
+        self.wgrad(self.z_proj.g, self._z, dx2, self.store.g[self.z_proj.w], self.store.g[self.z_proj.b])
+        dz = self.buf("dz", sh(Z))
+        ops.layer_dgrad(self.z_proj.g, dx2, self.store.p[self.z_proj.w], dz, wsplit=self.store.split_view(self.z_proj.ws_d))
+        dpp, dpr = self.buf("dpp", sh(2 * Z)), self.buf("dpr", sh(2 * Z + W))
+        ops.diag_sample_kl_bwd(self._pp, self._pr, self._eps, dz, g_kl, dpp, dpr)
+        ops.copy_cols(dx2, dpr, 2 * Z)                                            # d h = d x1
+        dmp = self.buf("dmp", tuple(self._mp.shape))
+        ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, P)
+        dxin = self.buf("dxin", sh(W))
+        self.prior.backward(dpr, dxin, x_pre=self._x_in, res=dx2)               # + the direct x1 = x_in + h path
+        da = self.buf("da", sh(2 * W))
+        self.posterior.backward(dpp, da)
+        ops.gelu_bwd(self._x_in, self._acts, da, dxin, dacts, accumulate=True)
+        self.masked_posterior.backward(dmp, da)
+        ops.gelu_bwd(self._x_in, self._macts, da, None, dmacts, accumulate=True)   # no gradient into stop_gradient(x)
+        return dxin
+
+
+class PosteriorMatchingVDVAE(Module):
+    """A "Very Deep VAE" modified for Posterior Matching (reference vdvae.py:15-94)."""
+
+    def __init__(self, image_shape: Tuple[int, int, int], encoder_blocks: str, decoder_blocks: str, latent_dim: int = 16,
+                 width: int = 128, bottleneck_multiple: float = 0.25, no_bias_above: int = 64, num_mixtures: int = 10,
+                 custom_width_string: Optional[str] = None, name: Optional[str] = None, device: Optional[str] = None,
+                 seed: int = 1):
+        super().__init__(name)
+        image_shape = tuple(image_shape)
+        if image_shape[-1] != 1:
+            raise NotImplementedError("LogisticMixture with num_channels > 1 (channel coefficients) has no HIP path")
+        if custom_width_string:
+            raise NotImplementedError("custom_width_string has no HIP path")
+        self.config = dict(image_shape=image_shape, encoder_blocks=encoder_blocks, decoder_blocks=decoder_blocks,
+                           latent_dim=latent_dim, width=width, bottleneck_multiple=bottleneck_multiple,
+                           no_bias_above=no_bias_above, num_mixtures=num_mixtures, custom_width_string=custom_width_string)
+        self.encoder = Encoder(width, encoder_blocks, bottleneck_multiple)
+        self.masked_encoder = Encoder(width, encoder_blocks, bottleneck_multiple)
+        self._device, self._seed = device, seed
+        self.store: Optional[ParamStore] = None
+
+    def init(self, device=None, seed: Optional[int] = None) -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("posterior_matching_amd needs an MI355X: there is no CPU fallback path")
+        from .. import _lib
+
+        _lib.load()
+        c = self.config
+        device = torch.device(device or self._device or "cuda:0")
+        store, ws = ParamStore(), Workspace(device)
+        self.ws = ws
+        H, W_, C = c["image_shape"]
+        width, Z = c["width"], c["latent_dim"]
+        mid = int(width * c["bottleneck_multiple"])
+        self.encoder.ws = self.masked_encoder.ws = ws
+        self.encoder.build(store, "encoder", (H, W_, C))
+        self.masked_encoder.build(store, "masked_encoder", (H, W_, 2 * C))
+        spec = parse_layer_string(c["decoder_blocks"])
+        self.dec_blocks = [PosteriorMatchingDecoderBlock(store, ws, f"decoder/block_{i}", Z, r, m, len(spec), width, mid)
+                           for i, (r, m) in enumerate(spec)]
+        self.resolutions = sorted({r for r, _ in spec})
+        self.bias_res = [r for r in self.resolutions if r <= c["no_bias_above"]]
+        for r in self.bias_res:
+            store.add(f"decoder/x_bias_{r}", (1, r, r, width))      # reference name: "x_bias_{res}]" (stray bracket, :797)
+        nm = c["num_mixtures"]
+        self.out_net = _Conv(store, "decoder/out_net", LayerGeom.conv(H, W_, width, nm * 3, 1, 1, "SAME"), width)
+        store.add("decoder/gain", (1, 1, 1, width), fan_in=-3)      # Constant(1.0)
+        store.add("decoder/bias", (1, 1, 1, width))
+        store.allocate(device, self._seed if seed is None else seed)
+        self.store = store
+        self.attach(store, "decoder")
+        self.metrics = torch.zeros(8, device=device)
+
+    @property
+    def num_params(self) -> int:
+        return self.store.num_params
+
+    def eps_shapes(self, B: int) -> List[Tuple[int, ...]]:
+        Z = self.config["latent_dim"]
+        return [(B, blk.base, blk.base, Z) for blk in self.dec_blocks]
+
+    def __call__(self, x: torch.Tensor, b: torch.Tensor, eps: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """reference vdvae.py:76-94.  x: raw pixel values 0..255 [B,H,W,1]; b: mask (1 = observed);
+        eps: one N(0,1) draw [B,res,res,Z] per decoder block (the caller owns the RNG).  Returns per-example
+        reconstruction_ll, kl, pm_kl (device tensors owned by the model)."""
+        if self.store is None:
+            self.init(x.device)
+        c = self.config
+        B, H, W_, _ = x.shape
+        width, nm = c["width"], c["num_mixtures"]
+        self._B, self._x = B, x
+        xn = self.ws.get("vdvae/xn", tuple(x.shape))
+        ops.scale_shift(x, 1.0 / 127.5, -1.0, xn)
+        xob = self.ws.get("vdvae/x_o_b", (B, H, W_, 2))
+        ops.mask_concat(xn, b, xob)
+        acts = self.encoder(xn)
+        macts = self.masked_encoder(xob)
+        self._acts, self._macts = acts, macts
+        kl, pm_kl = self.ws.get("vdvae/kl", (B,)), self.ws.get("vdvae/pm_kl", (B,))
+        ops.fill_zero(kl)
+        ops.fill_zero(pm_kl)
+        xs: Dict[int, torch.Tensor] = {}
+        self._first_use: Dict[int, int] = {}
+        self._x_ins: List[torch.Tensor] = []
+        for i, blk in enumerate(self.dec_blocks):
+            r = blk.base
+            if r in xs:
+                x_in = xs[r]
+            else:
+                x_in = self.ws.get(f"decoder/x_start_{r}", (B, r, r, width))
+                if r in self.bias_res:
+                    ops.broadcast_rows(self.store.p[f"decoder/x_bias_{r}"], x_in)     # jnp.repeat(x, B, axis=0) (:669-670)
+                else:
+                    ops.fill_zero(x_in)                                                   # zeros_like(acts) (:667-668)
+                self._first_use[r] = i
+            if blk.mixin is not None:
+                ops.resize_nearest_add(xs[blk.mixin], x_in)
+            xs[r] = blk.forward(x_in, acts[r], macts[r], eps[i], kl, pm_kl)
+        top = xs[H]
+        self._top = top
+        px_z = self.ws.get("decoder/px_z", tuple(top.shape))
+        ops.affine_fwd(top, self.store.p["decoder/gain"], self.store.p["decoder/bias"], px_z)
+        self._px_z = px_z
+        params = self.ws.get("decoder/dmol_params", (B, H, W_, 3 * nm))
+        ops.layer_forward(self.out_net.g, px_z, self.store.p[self.out_net.w], self.store.p[self.out_net.b], params,
+                          wsplit=self.store.split_view(self.out_net.ws_f))
+        self._params = params
+        rec = self.ws.get("vdvae/rec_ll", (B,))
+        ops.dmol_ll_fwd(params, x, rec, nm, H * W_)
+        ops.vdvae_loss(rec, kl, pm_kl, float(H * W_ * c["image_shape"][-1]), self.metrics)
+        return {"reconstruction_ll": rec, "kl": kl, "pm_kl": pm_kl}
+
+    def reconstruction(self) -> torch.Tensor:
+        """decoder_dist.mean() of the last call (reference :93)"""
+        B, H, W_, _ = self._x.shape
+        out = torch.empty((B, H, W_, 1), device=self._x.device)
+        ops.dmol_mean(self._params, out, self.config["num_mixtures"])
+        return out
+
+    def backward(self, grad_scale: float = 1.0) -> None:
+        """Gradient of loss = -mean(rec_ll - kl) + mean(pm_kl) (train_pm_vdvae.py:112-118) times grad_scale,
+        accumulated into the flat gradient buffer (zero it first)."""
+        c = self.config
+        B, H, W_, _ = self._x.shape
+        width, nm = c["width"], c["num_mixtures"]
+        g = grad_scale / B
+        dparams = self.ws.get("decoder/d_dmol_params", tuple(self._params.shape))
+        ops.dmol_ll_bwd(self._params, self._x, -g, dparams, nm, H * W_)
+        self.wgrad(self.out_net.g, self._px_z, dparams, self.store.g[self.out_net.w], self.store.g[self.out_net.b])
+        dpx = self.ws.get("decoder/d_px_z", tuple(self._px_z.shape))
+        ops.layer_dgrad(self.out_net.g, dparams, self.store.p[self.out_net.w], dpx, wsplit=self.store.split_view(self.out_net.ws_d))
+        dxs: Dict[int, torch.Tensor] = {}
+        for r in self.resolutions:
+            t = self.ws.get(f"decoder/dxs_{r}", (B, r, r, width))
+            ops.fill_zero(t)
+            dxs[r] = t
+        ops.affine_bwd(self._top, self.store.p["decoder/gain"], dpx, dxs[H], self.store.g["decoder/gain"],
+                       self.store.g["decoder/bias"])
+        dacts = {r: self.ws.get(f"vdvae/dacts_{r}", tuple(t.shape)) for r, t in self._acts.items()}
+        dmacts = {r: self.ws.get(f"vdvae/dmacts_{r}", tuple(t.shape)) for r, t in self._macts.items()}
+        for t in list(dacts.values()) + list(dmacts.values()):
+            ops.fill_zero(t)
+        for i in reversed(range(len(self.dec_blocks))):
+            blk = self.dec_blocks[i]
+            r = blk.base
+            dxin = blk.backward(dxs[r], dacts[r], dmacts[r], g, g)
+            if blk.mixin is not None:
+                ops.resize_nearest_add_bwd(dxin, dxs[blk.mixin])
+            if self._first_use[r] == i:
+                if r in self.bias_res:
+                    ops.groups_sum(dxin, self.store.g[f"decoder/x_bias_{r}"], B, accumulate=True)
+            else:
+                # x_in was the previous block of this resolution's output, and this block its only consumer (mix-in
+                # sources are always the LAST state of a coarser resolution): hand dxin over as that block's dx3
+                dxs[r] = dxin
+        self.encoder.backward(dacts)
+        self.masked_encoder.backward(dmacts)
+        self.ws.join_aux()
+
+    def zero_grad(self) -> None:
+        ops.fill_zero(self.store.flat_g)
+
+    def params_dict(self):
+        return self.store.to_dict("p")
+
+    def grads_dict(self):
+        return self.store.to_dict("g")
+
+    def load_params(self, values) -> None:
+        self.store.load_dict(values)

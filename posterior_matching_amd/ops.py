@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, AUX_AFTER_RES, LEAKY_SLOPE, GatherDesc  # noqa: F401
+from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, AUX_AFTER_RES, LEAKY_SLOPE, GatherDesc  # noqa: F401
 
 
 def _stream() -> int:
@@ -551,6 +551,114 @@ def gumbel_fill(out, seed: int, step_dev=None, stream_id: int = 0) -> None:
 
 def dropout_mask(out, rate: float, seed: int, step_dev, stream_id: int = 0) -> None:
     _call("pm_dropout_mask", _ptr(out), out.numel(), rate, seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
+
+
+# ---- VDVAE row-wise pieces (reference vdvae.py) ---------------------------------------------------------
+def gelu_fwd(a, b, out) -> None:
+    Ca, Cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
+    _call("pm_gelu_fwd", _ptr(a), _ptr(b), _ptr(out), a.numel() // Ca, Ca, Cb, work={"bytes": _nbytes(a, b, out)})
+
+
+def gelu_bwd(a, b, dout, da, db, accumulate: bool) -> None:
+    Ca, Cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
+    _call("pm_gelu_bwd", _ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), a.numel() // Ca, Ca, Cb, int(accumulate),
+          work={"bytes": _nbytes(a, b, dout, da, db)})
+
+
+def avgpool_fwd(x, out, k: int) -> None:
+    B, H, W, C_ = x.shape
+    _call("pm_avgpool_fwd", _ptr(x), _ptr(out), B, H, W, C_, k)
+
+
+def avgpool_bwd(dout, dx, k: int) -> None:
+    B, H, W, C_ = dx.shape
+    _call("pm_avgpool_bwd", _ptr(dout), _ptr(dx), B, H, W, C_, k)
+
+
+def resize_nearest_add(src, dst) -> None:
+    """dst [B,H,W,C] += nearest-resized src [B,h,w,Cs][..., :C]"""
+    B, h, w, Cs = src.shape
+    _, H, W, C_ = dst.shape
+    _call("pm_resize_nearest_add", _ptr(src), _ptr(dst), B, h, w, Cs, H, W, C_)
+
+
+def resize_nearest_add_bwd(ddst, dsrc) -> None:
+    B, h, w, Cs = dsrc.shape
+    _, H, W, C_ = ddst.shape
+    _call("pm_resize_nearest_add_bwd", _ptr(ddst), _ptr(dsrc), B, h, w, Cs, H, W, C_)
+
+
+def broadcast_rows(src, dst) -> None:
+    _call("pm_broadcast_rows", _ptr(src), _ptr(dst), dst.numel() // src.numel(), src.numel())
+
+
+def add_cols(a, b, bcol: int, out) -> None:
+    C_ = a.shape[-1]
+    _call("pm_add_cols", _ptr(a), _ptr(b), b.shape[-1], bcol, _ptr(out), a.numel() // C_, C_)
+
+
+def copy_cols(src, dst, dcol: int) -> None:
+    C_ = src.shape[-1]
+    _call("pm_copy_cols", _ptr(src), _ptr(dst), dst.shape[-1], dcol, src.numel() // C_, C_)
+
+
+def scale_shift(x, a: float, c: float, out) -> None:
+    _call("pm_scale_shift", _ptr(x), a, c, _ptr(out), x.numel())
+
+
+def diag_sample_kl_fwd(post, prior, eps, z, kl, P: int) -> None:
+    Z = eps.shape[-1]
+    _call("pm_diag_sample_kl_fwd", _ptr(post), _ptr(prior), prior.shape[-1], _ptr(eps), _ptr(z), _ptr(kl), eps.numel() // Z, Z, P)
+
+
+def diag_sample_kl_bwd(post, prior, eps, dz, g_kl: float, dpost, dprior) -> None:
+    Z = eps.shape[-1]
+    _call("pm_diag_sample_kl_bwd", _ptr(post), _ptr(prior), prior.shape[-1], _ptr(eps), _ptr(dz), g_kl, _ptr(dpost),
+          _ptr(dprior), eps.numel() // Z, Z)
+
+
+def diag_tril_kl_fwd(post, mp, kl, Z: int, P: int) -> None:
+    _call("pm_diag_tril_kl_fwd", _ptr(post), _ptr(mp), _ptr(kl), post.numel() // (2 * Z), Z, P)
+
+
+def diag_tril_kl_bwd(post, mp, g: float, dmp, Z: int, P: int) -> None:
+    _call("pm_diag_tril_kl_bwd", _ptr(post), _ptr(mp), g, _ptr(dmp), post.numel() // (2 * Z), Z, P)
+
+
+def affine_fwd(x, gain, bias, out) -> None:
+    C_ = x.shape[-1]
+    _call("pm_affine_fwd", _ptr(x), _ptr(gain), _ptr(bias), _ptr(out), x.numel() // C_, C_)
+
+
+def affine_bwd(x, gain, dout, dx, dgain, dbias) -> None:
+    C_ = x.shape[-1]
+    _call("pm_affine_bwd", _ptr(x), _ptr(gain), _ptr(dout), _ptr(dx), _ptr(dgain), _ptr(dbias), x.numel() // C_, C_)
+
+
+def dmol_ll_fwd(params, value, ll, nm: int, P: int, low: float = 0.0, high: float = 255.0) -> None:
+    _call("pm_dmol_ll_fwd", _ptr(params), _ptr(value), _ptr(ll), value.numel(), nm, P, low, high)
+
+
+def dmol_ll_bwd(params, value, g: float, dparams, nm: int, P: int, low: float = 0.0, high: float = 255.0) -> None:
+    _call("pm_dmol_ll_bwd", _ptr(params), _ptr(value), g, _ptr(dparams), value.numel(), nm, P, low, high)
+
+
+def dmol_mean(params, out, nm: int, low: float = 0.0, high: float = 255.0) -> None:
+    _call("pm_dmol_mean", _ptr(params), _ptr(out), out.numel(), nm, low, high)
+
+
+def vdvae_loss(rec, kl, pm_kl, num_dims: float, out) -> None:
+    _call("pm_vdvae_loss", _ptr(rec), _ptr(kl), _ptr(pm_kl), rec.numel(), num_dims, _ptr(out))
+
+
+def sumsq(x, out) -> None:
+    _call("pm_sumsq", _ptr(x), x.numel(), _ptr(out))
+
+
+def adam_step_clip_ema(p, g, m, v, ema, n_decay, count_dev, gnorm_sq, cfg: _lib.AdamCfg, clip: float, ema_rate: float,
+                       skip_nonfinite: bool) -> None:
+    _call("pm_adam_step_clip_ema", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), n_decay, _iptr(count_dev),
+          _ptr(gnorm_sq), C.byref(cfg), clip, ema_rate, int(skip_nonfinite))
 
 
 def pmvae_loss(rec, kl, mll, cfg: _lib.LossCfg, step_dev, out, g_rec, g_kl, g_mll) -> None:

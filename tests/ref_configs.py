@@ -66,3 +66,16 @@ def pm_vqvae_mnist():
         "steps": 120000, "validation_freq": 1000,
         "lr_schedule": {"init_value": 3e-4, "decay_rate": 0.999995, "transition_steps": 1},
     }
+
+
+def pm_vdvae_mnist():
+    """configs/pm_vdvae_mnist.py:4-35 of the reference (per-device batch 16; BASELINE quotes global 64 on 8 GPUs)."""
+    return {
+        "data": {"dataset": "mnist", "train_split": "train", "validation_split": "test",
+                 "train_batch_size": 16, "val_batch_size": 16, "mask_generator": "MNISTMaskGenerator"},
+        "model": {"image_shape": (28, 28, 1), "encoder_blocks": "28x6,28d2,14x4,14d2,7x2,7d2,3x2,3d2,1x2",
+                  "decoder_blocks": "1x2,3m1,3x2,7m3,7x2,14m7,14x4,28m14,28x6", "latent_dim": 16, "width": 192,
+                  "bottleneck_multiple": 0.25, "no_bias_above": 64, "num_mixtures": 10, "custom_width_string": None},
+        "ema_rate": 0.999, "gradient_clip": 200.0, "lr": 0.00015,
+        "steps": 500000, "validation_freq": 5000,
+    }

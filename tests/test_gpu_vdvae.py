@@ -1,0 +1,314 @@
+"""GPU parity of the Posterior-Matching VDVAE path: HIP kernels through the C ABI vs oracle/vdvae_oracle.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pm_vae_oracle as O
+from oracle import vdvae_oracle as DO
+from tests.ref_configs import pm_vdvae_mnist
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def f32d(t):
+    return t.float().to(dev()).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# row-wise kernels in isolation
+# ----------------------------------------------------------------------------------------------
+def test_gelu_pool_resize_affine():
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(0)
+    B, H, C = 3, 7, 12
+    a, b = torch.randn((B, H, H, C), generator=gen, dtype=F64) * 2, torch.randn((B, H, H, 5), generator=gen, dtype=F64) * 2
+    dout = torch.randn((B, H, H, C + 5), generator=gen, dtype=F64)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    want = DO.gelu(torch.cat([ar, br], -1))
+    want.backward(dout)
+    out = torch.empty((B, H, H, C + 5), device=dev())
+    ops.gelu_fwd(f32d(a), f32d(b), out)
+    assert rel_err(out, want) < 1e-6
+    da, db = torch.ones(a.shape, device=dev()), torch.ones(b.shape, device=dev())
+    ops.gelu_bwd(f32d(a), f32d(b), f32d(dout), da, db, accumulate=True)
+    assert rel_err(da, ar.grad + 1) < 2e-6 and rel_err(db, br.grad + 1) < 2e-6
+
+    for k, size in ((2, 7), (2, 3), (2, 28)):
+        x = torch.randn((B, size, size, C), generator=gen, dtype=F64)
+        xr = x.clone().requires_grad_(True)
+        y = DO.avg_pool(xr, k)
+        g = torch.randn(y.shape, generator=gen, dtype=F64)
+        y.backward(g)
+        yd = torch.empty(tuple(y.shape), device=dev())
+        ops.avgpool_fwd(f32d(x), yd, k)
+        assert rel_err(yd, y) < 1e-6
+        dx = torch.empty(tuple(x.shape), device=dev())
+        ops.avgpool_bwd(f32d(g), dx, k)
+        assert rel_err(dx, xr.grad) < 1e-6
+
+    for (h, Hh) in ((3, 7), (1, 3), (7, 14), (14, 28)):
+        src = torch.randn((B, h, h, C + 3), generator=gen, dtype=F64)
+        dst = torch.randn((B, Hh, Hh, C), generator=gen, dtype=F64)
+        sr = src.clone().requires_grad_(True)
+        y = dst + DO.resize_nearest(sr[..., :C], (Hh, Hh))
+        g = torch.randn(y.shape, generator=gen, dtype=F64)
+        y.backward(g)
+        dd = f32d(dst)
+        ops.resize_nearest_add(f32d(src), dd)
+        assert rel_err(dd, y) < 1e-6
+        ds = torch.ones(tuple(src.shape), device=dev())
+        ops.resize_nearest_add_bwd(f32d(g), ds)
+        assert rel_err(ds, sr.grad + 1) < 1e-6
+    assert DO.nearest_index(7, 3) == [0, 0, 1, 1, 1, 2, 2]
+
+    x = torch.randn((B * 49, C), generator=gen, dtype=F64)
+    gain, bias = torch.randn(C, generator=gen, dtype=F64), torch.randn(C, generator=gen, dtype=F64)
+    g = torch.randn(x.shape, generator=gen, dtype=F64)
+    xr, gr, br_ = x.clone().requires_grad_(True), gain.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    (xr * gr + br_).backward(g)
+    o = torch.empty(tuple(x.shape), device=dev())
+    ops.affine_fwd(f32d(x), f32d(gain), f32d(bias), o)
+    assert rel_err(o, x * gain + bias) < 1e-6
+    dx, dg, dbb = torch.empty(tuple(x.shape), device=dev()), torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    ops.affine_bwd(f32d(x), f32d(gain), f32d(g), dx, dg, dbb)
+    assert rel_err(dx, xr.grad) < 1e-6 and rel_err(dg, gr.grad) < 1e-5 and rel_err(dbb, br_.grad) < 1e-5
+
+
+@pytest.mark.parametrize("Z", [16, 4])
+def test_diag_sample_kl_and_diag_tril_kl(Z):
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(Z)
+    B, P, W = 3, 9, 8
+    R = B * P
+    post = torch.randn((R, 2 * Z), generator=gen, dtype=F64)
+    prior = torch.randn((R, 2 * Z + W), generator=gen, dtype=F64)
+    eps, dz = torch.randn((R, Z), generator=gen, dtype=F64), torch.randn((R, Z), generator=gen, dtype=F64)
+    NP = Z + Z * (Z + 1) // 2
+    mp = torch.randn((R, NP), generator=gen, dtype=F64) * 0.5
+    pr_, qr = prior.clone().requires_grad_(True), post.clone().requires_grad_(True)
+    sq, sp = O.softplus(qr[:, Z:]) + 1e-5, O.softplus(pr_[:, Z:2 * Z]) + 1e-5
+    z = qr[:, :Z] + sq * eps
+    kl = DO.mvn_diag_kl(qr[:, :Z], sq, pr_[:, :Z], sp).reshape(B, P).sum(1)
+    g_kl = 0.37
+    ((z * dz).sum() + g_kl * kl.sum()).backward()
+    zd, kld = torch.empty((R, Z), device=dev()), torch.zeros(B, device=dev())
+    ops.diag_sample_kl_fwd(f32d(post), f32d(prior), f32d(eps), zd, kld, P)
+    assert rel_err(zd, z) < 1e-6 and rel_err(kld, kl) < 2e-6
+    dpost, dprior = torch.empty((R, 2 * Z), device=dev()), torch.zeros((R, 2 * Z + W), device=dev())
+    ops.diag_sample_kl_bwd(f32d(post), f32d(prior), f32d(eps), f32d(dz), g_kl, dpost, dprior)
+    assert rel_err(dpost, qr.grad) < 2e-6 and rel_err(dprior, pr_.grad) < 2e-6
+
+    mr = mp.clone().requires_grad_(True)
+    sq0 = O.softplus(post[:, Z:]) + 1e-5
+    pm = DO.mvn_diag_tril_kl(post[:, :Z], sq0, mr[:, :Z], O.fill_scale_tril(mr[:, Z:])).reshape(B, P).sum(1)
+    # closed form against torch.distributions (SURVEY.md 8c iv)
+    td = torch.distributions
+    ref = td.kl_divergence(td.MultivariateNormal(post[:, :Z], scale_tril=torch.diag_embed(sq0)),
+                           td.MultivariateNormal(mp[:, :Z], scale_tril=O.fill_scale_tril(mp[:, Z:]))).reshape(B, P).sum(1)
+    assert torch.allclose(pm.detach(), ref, rtol=1e-9)
+    (0.21 * pm.sum()).backward()
+    pmd = torch.zeros(B, device=dev())
+    ops.diag_tril_kl_fwd(f32d(post), f32d(mp), pmd, Z, P)
+    assert rel_err(pmd, pm) < 1e-5
+    dmp = torch.empty((R, NP), device=dev())
+    ops.diag_tril_kl_bwd(f32d(post), f32d(mp), 0.21, dmp, Z, P)
+    assert rel_err(dmp, mr.grad) < 2e-5
+
+
+def test_dmol_log_prob_mean_and_grads():
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(2)
+    B, P, nm = 4, 36, 10
+    R = B * P
+    params = torch.randn((B, 6, 6, 3 * nm), generator=gen, dtype=F64)
+    params.view(B, 6, 6, nm, 3)[..., 2] -= 2.0                             # some sharp components
+    x = torch.randint(0, 256, (B, 6, 6, 1), generator=gen).double()
+    x[0, 0, :3] = 0.0
+    x[1, 1, :3] = 255.0                                                    # the open edge bins
+    prr = params.clone().requires_grad_(True)
+    ll = DO.logistic_mixture_log_prob(prr, x, nm)
+    (0.3 * ll.sum()).backward()
+    lld = torch.empty(B, device=dev())
+    ops.dmol_ll_fwd(f32d(params), f32d(x), lld, nm, P)
+    assert rel_err(lld, ll) < 1e-5
+    dp = torch.empty((B, 6, 6, 3 * nm), device=dev())
+    ops.dmol_ll_bwd(f32d(params), f32d(x), 0.3, dp, nm, P)
+    assert rel_err(dp, prr.grad) < 2e-5
+    mean = torch.empty((B, 6, 6, 1), device=dev())
+    ops.dmol_mean(f32d(params), mean, nm)
+    assert torch.equal(mean.cpu().double(), DO.logistic_mixture_mean(params, nm))
+    # normalisation over 0..255 on the device (SURVEY.md 8c viii)
+    one = torch.randn((1, 1, 1, 3 * nm), generator=gen).repeat(256, 1, 1, 1).to(dev()).contiguous()
+    vals = torch.arange(256, dtype=torch.float32, device=dev()).view(256, 1, 1, 1).contiguous()
+    l1 = torch.empty(256, device=dev())
+    ops.dmol_ll_fwd(one, vals, l1, nm, 1)
+    assert abs(torch.exp(l1.double()).sum().item() - 1.0) < 1e-5
+
+
+def test_clipped_adam_with_ema_and_nonfinite_skip():
+    from posterior_matching_amd import ops
+    from posterior_matching_amd._lib import AdamCfg
+
+    gen = torch.Generator().manual_seed(3)
+    n, n_decay = 5000, 3000
+    p = {"w": torch.randn(n_decay, 1, generator=gen, dtype=F64) * 0.05, "b": torch.randn(n - n_decay, generator=gen, dtype=F64) * 0.05}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    ema = {k: t.clone() for k, t in p.items()}
+    cfg = {"lr": 1.5e-4, "gradient_clip": 2.0, "ema_rate": 0.999, "weight_decay": 0.01}
+    d = dev()
+    flat = lambda dd: torch.cat([dd["w"].reshape(-1), dd["b"]]).float().to(d)   # noqa: E731
+    pd, md, vd, ed = flat(p), flat(m), flat(v), flat(ema)
+    c = AdamCfg()
+    c.b1, c.b2, c.eps, c.weight_decay, c.lr_init, c.lr_decay_rate, c.lr_transition_steps, c.grad_scale = 0.9, 0.999, 1e-8, 0.01, 1.5e-4, 1.0, 1.0, 1.0
+    count, gn = torch.zeros(1, dtype=torch.int32, device=d), torch.zeros(1, device=d)
+    for step, scale in enumerate([1.0, 0.01, float("nan"), 1.0]):
+        g = {"w": torch.randn(n_decay, 1, generator=gen, dtype=F64) * scale, "b": torch.randn(n - n_decay, generator=gen, dtype=F64) * scale}
+        applied = DO.optimizer_update(p, g, m, v, ema, int(count.item()), cfg)
+        gd = flat(g)
+        ops.sumsq(gd, gn)
+        ops.adam_step_clip_ema(pd, gd, md, vd, ed, n_decay, count, gn, c, 2.0, 0.999, True)
+        torch.cuda.synchronize()
+        assert applied == (step != 2)
+        assert count.item() == (step + 1 if step < 2 else step)          # the skipped step does not advance optax's count
+        assert rel_err(pd, flat(p)) < 2e-6 and rel_err(ed, flat(ema)) < 2e-6 and rel_err(md, flat(m)) < 1e-5
+        assert torch.isfinite(pd).all()
+
+
+# ----------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------
+TINY = {"model": {"image_shape": (7, 7, 1), "encoder_blocks": "7x2,7d2,3x1,3d2,1x1", "decoder_blocks": "1x1,3m1,3x2,7m3,7x2",
+                  "latent_dim": 4, "width": 32, "bottleneck_multiple": 0.25, "no_bias_above": 64, "num_mixtures": 10,
+                  "custom_width_string": None},
+        "ema_rate": 0.999, "gradient_clip": 200.0, "lr": 0.00015}
+
+
+def _setup(cfg, B, seed=5, bf16x3=False, perturb=True):
+    from posterior_matching_amd.models.vdvae import PosteriorMatchingVDVAE
+
+    m = PosteriorMatchingVDVAE(**cfg["model"], device="cuda:0", seed=seed)
+    m.init()
+    m.store.use_bf16 = bf16x3
+    if perturb:      # zero-initialised pieces (prior c4, biases, x_bias) and the unit gain: move them so every path matters
+        gen = torch.Generator().manual_seed(seed)
+        m.load_params({n: t.cpu() + 0.05 * torch.randn(t.shape, generator=gen) for n, t in m.params_dict().items()})
+    p64 = {n: t.cpu().double() for n, t in m.params_dict().items()}
+    rng = np.random.default_rng(seed)
+    H = cfg["model"]["image_shape"][0]
+    x = torch.tensor(np.round(rng.uniform(size=(B, H, H, 1)) * 255.0 * (rng.uniform(size=(B, H, H, 1)) < 0.4)))
+    b = torch.tensor((rng.uniform(size=(B, H, H, 1)) < 0.5).astype(np.float64))
+    eps = [torch.tensor(rng.normal(size=s)) for s in m.eps_shapes(B)]
+    return m, p64, x, b, eps
+
+
+def test_vdvae_param_names_and_init_match_oracle():
+    cfg = pm_vdvae_mnist()
+    m, p64, x, b, eps = _setup(cfg, 1, perturb=False)
+    shapes = DO.param_shapes(cfg["model"])
+    assert {n: tuple(t.shape) for n, t in p64.items()} == shapes
+    assert m.num_params == 7266942
+    assert p64["decoder/gain"].eq(1).all() and p64["decoder/block_3/prior/c4/w"].eq(0).all()
+    # init scale of the sqrt(1/N)-damped layers (vdvae.py:193-205): stddev = 0.88 * (1/sqrt(fan_in)) / sqrt(N)
+    w = p64["decoder/block_5/resnet/c4/w"]
+    assert abs(w.std().item() / (0.8796 / math.sqrt(48) / math.sqrt(20)) - 1) < 0.05
+    # at init the prior's last conv is zero: prior loc = 0, scale = softplus(0) + 1e-5, h = 0 (SURVEY.md 8c ix)
+    out = m(f32d(x), f32d(b), [f32d(e) for e in eps])
+    pr = m.dec_blocks[0]._pr
+    torch.cuda.synchronize()
+    assert pr.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("bf16x3", [False, True])
+def test_vdvae_forward_and_grads(bf16x3):
+    B = 3
+    m, p64, x, b, eps = _setup(TINY, B, bf16x3=bf16x3)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, aux, out = DO.vdvae_loss(leaves, TINY, x, b, eps)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    got = m(f32d(x), f32d(b), [f32d(e) for e in eps])
+    m.zero_grad()
+    m.backward()
+    torch.cuda.synchronize()
+    tol = 2e-5 if not bf16x3 else 2e-4
+    for k in ("reconstruction_ll", "kl", "pm_kl"):
+        assert rel_err(got[k], out[k]) < tol, k
+    met = m.metrics.cpu().double()
+    assert abs(met[0].item() - loss.item()) < tol * abs(loss.item())
+    assert abs(met[4].item() - aux["bpd"].item()) < tol * abs(aux["bpd"].item())
+    assert torch.equal(m.reconstruction().cpu().double(), out["reconstruction"]) or bf16x3
+    gd = m.grads_dict()
+    worst = max((rel_err(gd[n], grads[n]), n) for n in grads)
+    assert worst[0] < (1e-4 if not bf16x3 else 1e-2), worst
+
+
+def test_vdvae_train_steps_match_oracle():
+    from posterior_matching_amd.engine import VDVAETrainStep
+
+    B = 4
+    cfg = dict(TINY, gradient_clip=30.0)                                    # small enough to clip at this size
+    m, p64, x, b, eps = _setup(cfg, B)
+    ts = VDVAETrainStep(m, cfg["lr"], B, gradient_clip=cfg["gradient_clip"], ema_rate=cfg["ema_rate"], external_eps=True)
+    mo = {k: torch.zeros_like(v) for k, v in p64.items()}
+    vo = {k: torch.zeros_like(v) for k, v in p64.items()}
+    ema = {k: v.clone() for k, v in p64.items()}
+    p32 = {k: v.float().clone() for k, v in p64.items()}
+    m32, v32 = {k: torch.zeros_like(v) for k, v in p32.items()}, {k: torch.zeros_like(v) for k, v in p32.items()}
+    rng = np.random.default_rng(11)
+    clipped = 0
+    for step in range(3):
+        xb = torch.tensor(np.round(rng.uniform(size=(B, 7, 7, 1)) * 255.0))
+        bb = torch.tensor((rng.uniform(size=(B, 7, 7, 1)) < 0.5).astype(np.float64))
+        ee = [torch.tensor(rng.normal(size=s)) for s in m.eps_shapes(B)]
+        loss, aux, g = DO.train_step(p64, mo, vo, ema, cfg, xb, bb, ee, step)
+        DO.train_step(p32, m32, v32, None, cfg, xb.float(), bb.float(), [e.float() for e in ee], step)
+        gn = math.sqrt(sum(float((t ** 2).sum()) for t in g.values()))
+        clipped += gn >= cfg["gradient_clip"]
+        ts.set_batch(f32d(xb), f32d(bb), [f32d(e) for e in ee])
+        ts.step()
+        met = ts.read_metrics()
+        assert abs(met["loss"] - loss.item()) < 1e-4 * abs(loss.item()), (step, met)
+        assert abs(met["grad_norm"] - gn) < 1e-3 * gn
+        pd, ed = m.params_dict(), ts.ema_params()
+        for n in p64:
+            e, e32 = rel_err(pd[n], p64[n]), rel_err(p32[n], p64[n])
+            assert e < max(3e-4, 20 * e32) and e < 5e-3, (step, n, e, e32)
+            assert rel_err(ed[n], ema[n]) < max(3e-4, 20 * e32), (step, n)
+    assert clipped >= 1 and ts.opt_count.item() == 3 and ts.step_dev.item() == 3
+
+
+def test_vdvae_reference_config_small_batch():
+    """configs/pm_vdvae_mnist.py (7.27 M parameters, 20 + 20 + 20 blocks) at batch 2: outputs and sampled gradients."""
+    cfg = pm_vdvae_mnist()
+    B = 2
+    m, p64, x, b, eps = _setup(cfg, B, seed=8)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, aux, out = DO.vdvae_loss(leaves, cfg, x, b, eps)
+    names = ["encoder/stem/w", "encoder/block_3/c2/w", "masked_encoder/block_19/c4/w", "decoder/block_0/posterior/c1/w",
+             "decoder/block_7/masked_posterior/c4/w", "decoder/block_12/prior/c3/w", "decoder/block_19/resnet/c4/w",
+             "decoder/block_2/z_proj/w", "decoder/x_bias_3", "decoder/x_bias_28", "decoder/gain", "decoder/out_net/b"]
+    grads = dict(zip(names, torch.autograd.grad(loss, [leaves[n] for n in names])))
+    got = m(f32d(x), f32d(b), [f32d(e) for e in eps])
+    m.zero_grad()
+    m.backward()
+    torch.cuda.synchronize()
+    for k in ("reconstruction_ll", "kl", "pm_kl"):
+        assert rel_err(got[k], out[k]) < 5e-5, k
+    gd = m.grads_dict()
+    for n in names:
+        assert rel_err(gd[n], grads[n]) < 5e-4, (n, rel_err(gd[n], grads[n]))
