@@ -322,3 +322,43 @@ def init_params(cfg: dict, seed: int = 1, dtype=torch.float64) -> Params:
             arr = np.zeros(shp)
         out[name] = torch.tensor(arr, dtype=dtype)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# imputation from the partially observed posterior and its PSNR (vdvae.py:161-186, 573-590, 689-703;
+# eval_pm_vdvae_imputation.py:116-130)
+# ----------------------------------------------------------------------------------------------
+def vdvae_impute(p: Params, cfg: dict, x: Tensor, b: Tensor, eps: Sequence[Sequence[Tensor]]) -> Tensor:
+    """PosteriorMatchingVDVAE.impute -> [B, S, H, W, C]; eps[s][i]: noise of sample s, decoder block i."""
+    Z, size = cfg.get("latent_dim", 16), cfg["image_shape"][0]
+    xn = x / 127.5 - 1.0
+    macts = encoder(p, "masked_encoder", torch.cat([xn * b, b], -1), cfg)
+    blocks = parse_layer_string(cfg["decoder_blocks"])
+    resolutions = sorted({r for r, _ in blocks})
+    outs = []
+    for es in eps:
+        xs = {r: p[f"decoder/x_bias_{r}"] for r in resolutions if r <= cfg.get("no_bias_above", 64)}
+        for i, (res, mixin) in enumerate(blocks):
+            ma = macts[res]
+            W = ma.shape[-1]
+            xx = xs[res] if res in xs else torch.zeros_like(ma)
+            if xx.shape[0] != ma.shape[0]:
+                xx = xx.expand(ma.shape[0], -1, -1, -1)
+            if mixin is not None:
+                xx = xx + resize_nearest(xs[mixin][..., :W], (res, res))
+            n = f"decoder/block_{i}"
+            mp = block(p, f"{n}/masked_posterior", torch.cat([xx, ma], -1), res > 2, False)
+            pr = block(p, f"{n}/prior", xx, res > 2, False)
+            xx = xx + pr[..., 2 * Z:]
+            z = mp[..., :Z] + (fill_scale_tril(mp[..., Z:]) @ es[i].unsqueeze(-1)).squeeze(-1)
+            xx = xx + conv1x1(p, f"{n}/z_proj", z)
+            xs[res] = block(p, f"{n}/resnet", xx, res > 2, True)
+        params = conv1x1(p, "decoder/out_net", xs[size] * p["decoder/gain"] + p["decoder/bias"])
+        mean = logistic_mixture_mean(params, cfg.get("num_mixtures", 10))
+        outs.append(torch.where(b == 1, x, mean))
+    return torch.stack(outs, dim=1)
+
+
+def imputation_psnr(imputations: Tensor, x: Tensor) -> Tensor:
+    err = ((imputations.mean(1) / 255.0 - x / 255.0) ** 2).reshape(x.shape[0], -1).mean(1)
+    return -10.0 * torch.log10(err)

@@ -114,8 +114,8 @@ SIGNATURES = {
     "pm_categorical_ll_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_neg_mean_loss": [_P, _P, _I, _F, _P, _P],
     "pm_categorical_sample": [_P, _P, _P, _P, _LL, _I, _I, _I],
-    "pm_impute_blend": [_P, _P, _P, _P, _LL, _I, _LL, _I, _I],
-    "pm_imputation_psnr": [_P, _P, _P, _P, _LL, _I, _LL],
+    "pm_impute_blend": [_P, _P, _P, _P, _LL, _I, _LL, _I, _I, _F, _F],
+    "pm_imputation_psnr": [_P, _P, _P, _P, _LL, _I, _LL, _F],
     "pm_gumbel_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
     "pm_dropout_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
     "pm_gelu_fwd": [_P, _P, _P, _P, _LL, _I, _I],

@@ -237,26 +237,26 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(const float* __
 // channels per pixel (1 = broadcast over the C image channels)
 __global__ __launch_bounds__(256) void impute_blend_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                                             float* __restrict__ imp, long long total, long long D, int S,
-                                                            int C, int Cm) {
+                                                            int C, int Cm, float lo, float hi) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long long j = i % D;
     const long long b = i / (D * S);
     const float m = mask[b * (D / C * Cm) + (Cm == C ? j : j / C)];
     const float v = m != 0.f ? x[b * D + j] : imp[i];
-    imp[i] = fminf(fmaxf(v, 0.f), 1.f);
+    imp[i] = lo <= hi ? fminf(fmaxf(v, lo), hi) : v;
 }
 
 // psnr[b] = -10 log10( mean_j (mean_s imp[b,s,j] - x[b,j])^2 )   (eval_pm_vqvae.py:133-136)
 __global__ __launch_bounds__(256) void imputation_psnr_kernel(const float* __restrict__ imp, const float* __restrict__ x,
-                                                               float* __restrict__ psnr, long long D, int S) {
+                                                               float* __restrict__ psnr, long long D, int S, float scale) {
     __shared__ float red[4];
     const long long b = blockIdx.x;
     float acc = 0.f;
     for (long long j = threadIdx.x; j < D; j += 256) {
         float m = 0.f;
         for (int s = 0; s < S; ++s) m += imp[(b * S + s) * D + j];
-        const float d = m / (float)S - x[b * D + j];
+        const float d = (m / (float)S - x[b * D + j]) * scale;
         acc = fmaf(d, d, acc);
     }
     acc = pm_wave_sum(acc);
@@ -377,18 +377,18 @@ extern "C" int pm_categorical_sample(pm_stream_t stream, const float* logits, co
 }
 
 extern "C" int pm_impute_blend(pm_stream_t stream, const float* x, const float* mask, float* imp, long long B, int S,
-                               long long D, int C, int Cm) {
+                               long long D, int C, int Cm, float lo, float hi) {
     if (!x || !mask || !imp || B <= 0 || S <= 0 || D <= 0 || C <= 0 || (Cm != C && Cm != 1) || D % C != 0)
         return PM_EINVAL;
     const long long total = B * S * D;
     hipLaunchKernelGGL(impute_blend_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, mask, imp, total,
-                       D, S, C, Cm);
+                       D, S, C, Cm, lo, hi);
     return pm_check_launch("pm_impute_blend");
 }
 
 extern "C" int pm_imputation_psnr(pm_stream_t stream, const float* imp, const float* x, float* psnr, long long B, int S,
-                                  long long D) {
+                                  long long D, float scale) {
     if (!imp || !x || !psnr || B <= 0 || S <= 0 || D <= 0) return PM_EINVAL;
-    hipLaunchKernelGGL(imputation_psnr_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, imp, x, psnr, D, S);
+    hipLaunchKernelGGL(imputation_psnr_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, imp, x, psnr, D, S, scale);
     return pm_check_launch("pm_imputation_psnr");
 }

@@ -22,7 +22,7 @@ class SyntheticDataset:
     ({"image"|"features": f32[B,...], "mask": f32[B,...]}), already resident on `device`."""
 
     def __init__(self, config: Mapping, batch_size: int, num_batches: int = 64, seed: int = 0, device="cpu",
-                 training: bool = True, arrays: Optional[np.ndarray] = None):
+                 training: bool = True, arrays: Optional[np.ndarray] = None, normalize_images: bool = True):
         rng = np.random.default_rng(seed)
         name = config["dataset"]
         shape = data_shape(name)
@@ -38,6 +38,8 @@ class SyntheticDataset:
             elif self.key == "image":
                 # MNIST-like: ~19 % of the pixels carry ink, values in [0, 1] (utils.py:50-54: x / 255)
                 x = (rng.uniform(size=(batch_size,) + shape) * (rng.uniform(size=(batch_size,) + shape) < 0.19)).astype(np.float32)
+                if not normalize_images:                 # load_datasets(normalize_images=False): raw 0..255 pixel values
+                    x = np.round(x * 255.0).astype(np.float32)
             else:
                 x = rng.normal(size=(batch_size,) + shape).astype(np.float32)
                 if training and "training_noise" in config:          # utils.py:108-116

@@ -404,3 +404,26 @@ class VDVAETrainStep:
     def ema_params(self) -> Dict[str, torch.Tensor]:
         s = self.model.store
         return {n: self.ema[o:o + c].view(s.specs[n][0]).detach().clone() for n, (o, c) in s.offsets.items()}
+
+    def swap_in_ema(self) -> None:
+        """exchanges the parameters with their EMA (Trainer(use_ema_for_eval=True)); call again to swap back"""
+        s = self.model.store
+        if self.ema is None:
+            return
+        with torch.cuda.stream(self.stream):
+            tmp = s.flat_p.clone()
+            s.flat_p.copy_(self.ema)
+            self.ema.copy_(tmp)
+            s.split_all()
+
+    def evaluate(self, x: torch.Tensor, b: torch.Tensor) -> Dict[str, float]:
+        """loss_fn on a validation batch with the EMA parameters (use_ema_for_eval), fresh posterior noise"""
+        self.swap_in_ema()
+        self.set_batch(x, b)
+        with torch.cuda.stream(self.stream):
+            ops.normal_fill(self.eps_flat, self.seed + 104729, self.step_dev, stream_id=1000 + self.rank)
+            self.model(self.x, self.b, self.eps)
+        out = self.read_metrics()
+        self.swap_in_ema()
+        out.pop("grad_norm", None)
+        return out

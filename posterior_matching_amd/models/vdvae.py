@@ -236,6 +236,28 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.gelu_fwd(x2, None, x2g)
         return self.resnet.forward(x2g, res=x2)
 
+    def forward_partial(self, x_in: torch.Tensor, macts: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        """forward_partial_posterior / sample_partial_posterior (reference :689-703, :573-590): z is drawn from the
+        masked (TriL) posterior, z = loc + L eps; no KL terms."""
+        B, r, W, Z = x_in.shape[0], self.base, self.width, self.Z
+        sh = lambda c: (B, r, r, c)   # noqa: E731
+        am = self.buf("am", sh(2 * W))
+        ops.gelu_fwd(x_in, macts, am)
+        mp = self.masked_posterior.forward(am)
+        ap = self.buf("ap", sh(W))
+        ops.gelu_fwd(x_in, None, ap)
+        pr = self.prior.forward(ap)
+        x1 = self.buf("x1", sh(W))
+        ops.add_cols(x_in, pr, 2 * Z, x1)
+        z, scratch = self.buf("z", sh(Z)), self.buf("tril_kl_scratch", (B * r * r,))
+        ops.tril_sample_kl_fwd(mp.view(B * r * r, -1), eps.view(B * r * r, Z), z.view(B * r * r, Z), scratch)
+        x2 = self.buf("x2", sh(W))
+        ops.layer_forward(self.z_proj.g, z, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
+                          wsplit=self.store.split_view(self.z_proj.ws_f))
+        x2g = self.buf("x2g", sh(W))
+        ops.gelu_fwd(x2, None, x2g)
+        return self.resnet.forward(x2g, res=x2)
+
     def backward(self, dx3: torch.Tensor, dacts: torch.Tensor, dmacts: torch.Tensor, g_kl: float, g_pm: float) -> torch.Tensor:
         """dx3: gradient w.r.t. this block's output.  Accumulates into dacts / dmacts (the encoder
         activations of this resolution) and returns the gradient w.r.t. x_in."""
@@ -351,11 +373,7 @@ class PosteriorMatchingVDVAE(Module):
             if r in xs:
                 x_in = xs[r]
             else:
-                x_in = self.ws.get(f"decoder/x_start_{r}", (B, r, r, width))
-                if r in self.bias_res:
-                    ops.broadcast_rows(self.store.p[f"decoder/x_bias_{r}"], x_in)     # jnp.repeat(x, B, axis=0) (:669-670)
-                else:
-                    ops.fill_zero(x_in)                                                   # zeros_like(acts) (:667-668)
+                x_in = self._start_state(xs, r, B)     # jnp.repeat(x_bias, B, axis=0) (:669-670) or zeros_like(acts) (:667-668)
                 self._first_use[r] = i
             if blk.mixin is not None:
                 ops.resize_nearest_add(xs[blk.mixin], x_in)
@@ -373,6 +391,57 @@ class PosteriorMatchingVDVAE(Module):
         ops.dmol_ll_fwd(params, x, rec, nm, H * W_)
         ops.vdvae_loss(rec, kl, pm_kl, float(H * W_ * c["image_shape"][-1]), self.metrics)
         return {"reconstruction_ll": rec, "kl": kl, "pm_kl": pm_kl}
+
+    def _start_state(self, xs, r: int, B: int) -> torch.Tensor:
+        width = self.config["width"]
+        x_in = self.ws.get(f"decoder/x_start_{r}", (B, r, r, width))
+        if r in self.bias_res:
+            ops.broadcast_rows(self.store.p[f"decoder/x_bias_{r}"], x_in)
+        else:
+            ops.fill_zero(x_in)
+        return x_in
+
+    def impute(self, x: torch.Tensor, b: torch.Tensor, num_samples: int = 100, seed: int = 0,
+               eps: Optional[Sequence[Sequence[torch.Tensor]]] = None) -> torch.Tensor:
+        """reference vdvae.py:161-186: [B, num_samples, H, W, C] - the decoder driven by the masked posterior
+        only, observed pixels kept.  eps[s][i]: explicit noise of sample s / block i (parity mode); otherwise
+        device Philox keyed by (seed, s)."""
+        if self.store is None:
+            self.init(x.device)
+        c = self.config
+        B, H, W_, C = x.shape
+        nm = c["num_mixtures"]
+        xn = self.ws.get("vdvae/xn", tuple(x.shape))
+        ops.scale_shift(x, 1.0 / 127.5, -1.0, xn)
+        xob = self.ws.get("vdvae/x_o_b", (B, H, W_, 2))
+        ops.mask_concat(xn, b, xob)
+        macts = self.masked_encoder(xob)                    # identical for every sample: the scan body is deterministic in it
+        out = torch.empty((B, num_samples, H, W_, C), device=x.device)
+        shapes = self.eps_shapes(B)
+        noise = [self.ws.get(f"vdvae/impute_eps_{i}", sh) for i, sh in enumerate(shapes)] if eps is None else None
+        mean = self.ws.get("vdvae/impute_mean", (B, H, W_, C))
+        for s in range(num_samples):
+            xs: Dict[int, torch.Tensor] = {}
+            for i, blk in enumerate(self.dec_blocks):
+                r = blk.base
+                x_in = xs[r] if r in xs else self._start_state(xs, r, B)
+                if blk.mixin is not None:
+                    ops.resize_nearest_add(xs[blk.mixin], x_in)
+                if eps is None:
+                    ops.normal_fill(noise[i], seed + 7919 * s, None, stream_id=i)
+                    e = noise[i]
+                else:
+                    e = eps[s][i]
+                xs[r] = blk.forward_partial(x_in, macts[r], e)
+            px_z = self.ws.get("decoder/px_z", tuple(xs[H].shape))
+            ops.affine_fwd(xs[H], self.store.p["decoder/gain"], self.store.p["decoder/bias"], px_z)
+            params = self.ws.get("decoder/dmol_params", (B, H, W_, 3 * nm))
+            ops.layer_forward(self.out_net.g, px_z, self.store.p[self.out_net.w], self.store.p[self.out_net.b], params,
+                              wsplit=self.store.split_view(self.out_net.ws_f))
+            ops.dmol_mean(params, mean, nm)
+            out[:, s].copy_(mean)
+        ops.impute_blend(x, b, out, 1.0, 0.0)               # jnp.where(b == 1, x, mean): no clipping
+        return out
 
     def reconstruction(self) -> torch.Tensor:
         """decoder_dist.mean() of the last call (reference :93)"""
@@ -432,3 +501,10 @@ class PosteriorMatchingVDVAE(Module):
 
     def load_params(self, values) -> None:
         self.store.load_dict(values)
+
+
+def vdvae_imputation_psnr(imputations: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """eval_pm_vdvae_imputation.py:123-128: PSNR [B] of the mean imputation, pixel values scaled by 1/255."""
+    psnr = torch.empty(x.shape[0], device=x.device)
+    ops.imputation_psnr(imputations, x, psnr, 1.0 / 255.0)
+    return psnr

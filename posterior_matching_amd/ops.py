@@ -533,16 +533,16 @@ def categorical_sample(logits, gumbel, idx, P: int, pos: int) -> None:
     _call("pm_categorical_sample", _ptr(logits), _ptr(gumbel), _iptr(idx), gumbel.shape[0], K, P, pos)
 
 
-def impute_blend(x, mask, imp) -> None:
-    """imp [B,S,...image] <- clip(where(mask, x, imp), 0, 1) in place"""
+def impute_blend(x, mask, imp, lo: float = 0.0, hi: float = 1.0) -> None:
+    """imp [B,S,...image] <- clip(where(mask, x, imp), lo, hi) in place (lo > hi: no clipping)"""
     B, S = imp.shape[0], imp.shape[1]
     D, C, Cm = x.numel() // B, x.shape[-1], mask.shape[-1]
-    _call("pm_impute_blend", _ptr(x), _ptr(mask), _ptr(imp), B, S, D, C, Cm)
+    _call("pm_impute_blend", _ptr(x), _ptr(mask), _ptr(imp), B, S, D, C, Cm, lo, hi)
 
 
-def imputation_psnr(imp, x, psnr) -> None:
+def imputation_psnr(imp, x, psnr, scale: float = 1.0) -> None:
     B, S = imp.shape[0], imp.shape[1]
-    _call("pm_imputation_psnr", _ptr(imp), _ptr(x), _ptr(psnr), B, S, x.numel() // B)
+    _call("pm_imputation_psnr", _ptr(imp), _ptr(x), _ptr(psnr), B, S, x.numel() // B, scale)
 
 
 def gumbel_fill(out, seed: int, step_dev=None, stream_id: int = 0) -> None:

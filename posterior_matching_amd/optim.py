@@ -71,10 +71,32 @@ def scale(factor) -> Scale:
 
 
 @dataclass
+class ClipByGlobalNorm:
+    """optax.clip_by_global_norm(max_norm)"""
+
+    max_norm: float
+
+
+def clip_by_global_norm(max_norm) -> ClipByGlobalNorm:
+    return ClipByGlobalNorm(float(max_norm))
+
+
+def constant_schedule(value) -> ExponentialDecay:
+    """`schedule = lambda _: config.lr` (train_pm_vdvae.py:128-129)"""
+    return ExponentialDecay(float(value), 1.0, 1.0)
+
+
+def linear_schedule(init_value, end_value, transition_steps, transition_begin=0):
+    raise NotImplementedError("optax.linear_schedule (the VDVAE warm-up, train_pm_vdvae.py:124-127) is not lowered to the "
+                              "fused optimizer; the reference configs set no warm_up")
+
+
+@dataclass
 class Chain:
     adam: ScaleByAdam
     decay: AddDecayedWeights
     schedule: ExponentialDecay
+    clip: Optional[ClipByGlobalNorm] = None
 
     def adam_cfg(self, grad_scale: float = 1.0):
         from ._lib import AdamCfg
@@ -91,6 +113,10 @@ class Chain:
 def chain(*transforms) -> Chain:
     """optax.chain(scale_by_adam, [add_decayed_weights,] scale_by_schedule(exponential_decay), scale(-1)):
     the 4-transform form of train_pm_vae.py:74-83 or the 3-transform form of train_pm_vqvae.py:115-120."""
+    if len(transforms) == 5 and isinstance(transforms[0], ClipByGlobalNorm):          # train_pm_vdvae.py:131-144
+        c = chain(*transforms[1:])
+        c.clip = transforms[0]
+        return c
     if len(transforms) == 3 and isinstance(transforms[0], ScaleByAdam) and isinstance(transforms[1], ScaleBySchedule):
         transforms = (transforms[0], AddDecayedWeights(0.0), transforms[1], transforms[2])
     if (len(transforms) != 4 or not isinstance(transforms[0], ScaleByAdam)

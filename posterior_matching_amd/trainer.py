@@ -16,7 +16,7 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional
 import torch
 
 from . import ops
-from .engine import PMVAETrainStep, PMVQVAETrainStep, VQVAETrainStep
+from .engine import PMVAETrainStep, PMVQVAETrainStep, VDVAETrainStep, VQVAETrainStep
 from .models.vae import PosteriorMatchingVAE
 from .models.vqvae import VQVAE
 from .optim import Chain
@@ -48,6 +48,13 @@ class PMVQVAELoss:
     def __init__(self, config: Mapping[str, Any], vqvae: VQVAE, partial_encoder, pixel_cnn, data_key: str = "image"):
         self.config, self.model, self.data_key = config, vqvae, data_key
         self.partial_encoder, self.pixel_cnn = partial_encoder, pixel_cnn
+
+
+class VDVAELoss:
+    """loss_fn of train_pm_vdvae.py:109-120 as an object: loss = -mean(rec_ll - kl) + mean(pm_kl), aux = the means and bpd."""
+
+    def __init__(self, config: Mapping[str, Any], model, data_key: str = "image"):
+        self.config, self.model, self.data_key = config, model, data_key
 
 
 @dataclass
@@ -90,7 +97,10 @@ class Trainer:
                                                     or not trainable_predicate("pixel_cnn", "w", None)):
                 raise NotImplementedError("only the reference's predicate (freeze 'vqvae/...') is lowered")
             trainable_predicate = None
-        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss, PMVQVAELoss)):
+        self.ema_rate, self.skip_nonfinite = ema_rate, skip_nonfinite_updates
+        if isinstance(loss_fn, VDVAELoss):     # train_pm_vdvae.py:146-154: the flags the fused VDVAE step implements
+            skip_nonfinite_updates, ema_rate, use_ema_for_eval = False, None, False
+        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss, PMVQVAELoss, VDVAELoss)):
             raise NotImplementedError("Trainer lowers PMVAELoss / VQVAELoss (the loss_fn of train_pm_vae.py / "
                                       "train_vqvae.py) to the fused HIP step; arbitrary Python loss functions have "
                                       "no HIP path")
@@ -104,6 +114,12 @@ class Trainer:
                              "process per GPU, start it with torch.distributed.run --nproc-per-node num_devices")
 
     def _state(self, ts) -> TrainState:
+        if isinstance(ts, VDVAETrainStep):
+            store = ts.model.store
+            ema = {k: v.cpu() for k, v in ts.ema_params().items()} if ts.ema is not None else None
+            return TrainState(step=int(ts.step_dev.item()), params={k: v.cpu() for k, v in store.to_dict("p").items()},
+                              opt_state={"mu": store.flat_m.cpu(), "nu": store.flat_v.cpu(),
+                                         "count": int(ts.opt_count.item())}, ema_params=ema)
         if isinstance(ts, PMVQVAETrainStep):
             # the reference's TrainState holds frozen and trainable parameters in one tree (vqvae/ prefix, :123)
             params = {f"vqvae/{k}": v.cpu() for k, v in ts.vqvae.params_dict().items()}
@@ -125,8 +141,11 @@ class Trainer:
         first = next(it)
         x0 = first[key]
         B, x_shape = x0.shape[0], tuple(x0.shape[1:])
-        if model.store is None:
-            model.init(x_shape, device=torch.device("cuda", self.local_rank), seed=self.seed)   # same init on all ranks
+        if model.store is None:                                                              # same init on all ranks
+            if isinstance(lf, VDVAELoss):
+                model.init(device=torch.device("cuda", self.local_rank), seed=self.seed)
+            else:
+                model.init(x_shape, device=torch.device("cuda", self.local_rank), seed=self.seed)
         def strip(d):     # stage-1 checkpoints may carry the reference's "vqvae/" module prefix (train_pm_vqvae.py:123)
             return {(k[len("vqvae/"):] if k.startswith("vqvae/") else k): v for k, v in d.items()}
 
@@ -137,7 +156,13 @@ class Trainer:
         dev = model.store.device
         is_vq = isinstance(lf, VQVAELoss)
         is_pmvq = isinstance(lf, PMVQVAELoss)
-        if is_pmvq:
+        if isinstance(lf, VDVAELoss):
+            opt = self.optimizer
+            ts = VDVAETrainStep(model, opt.schedule.init_value, B, gradient_clip=opt.clip.max_norm if opt.clip else 0.0,
+                                ema_rate=self.ema_rate, weight_decay=opt.decay.weight_decay,
+                                adam={"b1": opt.adam.b1, "b2": opt.adam.b2, "eps": opt.adam.eps}, seed=self.seed,
+                                world_size=self.world, rank=self.rank, skip_nonfinite_updates=self.skip_nonfinite)
+        elif is_pmvq:
             ts = PMVQVAETrainStep(model, lf.partial_encoder, lf.pixel_cnn, self.optimizer, B, x_shape, seed=self.seed,
                                   world_size=self.world, rank=self.rank)
         elif is_vq:
@@ -180,7 +205,7 @@ class Trainer:
         for i, vb in enumerate(batches):
             if isinstance(ts, VQVAETrainStep):
                 out = ts.evaluate(vb[key].to(dev))
-            elif isinstance(ts, PMVQVAETrainStep):
+            elif isinstance(ts, (PMVQVAETrainStep, VDVAETrainStep)):
                 out = ts.evaluate(vb[key].to(dev), vb["mask"].to(dev))
             else:
                 x, b = vb[key].to(dev), vb["mask"].to(dev)

@@ -312,3 +312,65 @@ def test_vdvae_reference_config_small_batch():
     gd = m.grads_dict()
     for n in names:
         assert rel_err(gd[n], grads[n]) < 5e-4, (n, rel_err(gd[n], grads[n]))
+
+
+def test_vdvae_impute_and_psnr_match_oracle():
+    """PosteriorMatchingVDVAE.impute (reference vdvae.py:161-186) with explicit noise and the held-out PSNR
+    of eval_pm_vdvae_imputation.py:123-128."""
+    from posterior_matching_amd.models.vdvae import vdvae_imputation_psnr
+
+    B, S = 3, 2
+    m, p64, x, b, _ = _setup(TINY, B, seed=12)
+    rng = np.random.default_rng(4)
+    eps = [[torch.tensor(rng.normal(size=s)) for s in m.eps_shapes(B)] for _ in range(S)]
+    want = DO.vdvae_impute(p64, TINY["model"], x, b, eps)
+    got = m.impute(f32d(x), f32d(b), num_samples=S, eps=[[f32d(e) for e in es] for es in eps])
+    psnr = vdvae_imputation_psnr(got, f32d(x))
+    torch.cuda.synchronize()
+    assert got.shape == (B, S, 7, 7, 1)
+    # the mean is rounded to an integer pixel value: identical unless the oracle's pre-rounding value sits on a .5 tie
+    diff = (got.cpu().double() - want).abs()
+    assert (diff > 0).float().mean().item() < 0.01 and diff.max().item() <= 1.0
+    assert rel_err(psnr, DO.imputation_psnr(want, x)) < 1e-2
+    obs = b.bool().expand(B, 7, 7, 1)
+    assert torch.equal(got.cpu()[:, 0][obs], x.float()[obs])
+    a = m.impute(f32d(x), f32d(b), num_samples=2, seed=3)
+    c = m.impute(f32d(x), f32d(b), num_samples=2, seed=3)
+    assert torch.equal(a, c) and a.min() >= 0 and a.max() <= 255
+
+
+def test_train_and_eval_vdvae_scripts_end_to_end(tmp_path):
+    """train_pm_vdvae.py for a few steps on a small network, then eval_pm_vdvae_imputation.py on its checkpoint."""
+    import json
+    import os
+    import pickle
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(script, *argv):
+        out = subprocess.run([sys.executable, os.path.join(root, script), *argv], cwd=tmp_path, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        return out.stdout
+
+    run("train_pm_vdvae.py", "--config", os.path.join(root, "configs", "pm_vdvae_mnist.py"), "--config.steps=6",
+        "--config.validation_freq=3", "--config.seed=2", "--config.model.width=32", "--config.model.latent_dim=4",
+        "--config.data.train_batch_size=4", "--config.data.val_batch_size=4",
+        "--config.model.encoder_blocks=28x1,28d2,14x1,14d2,7x1,7d2,3x1,3d2,1x1",
+        "--config.model.decoder_blocks=1x1,3m1,3x1,7m3,7x1,14m7,14x1,28m14,28x1")
+    rd = os.path.join(tmp_path, "runs", os.listdir(os.path.join(tmp_path, "runs"))[0])
+    lines = [json.loads(l) for l in open(os.path.join(rd, "tb", "scalars.jsonl"))]
+    assert [l["step"] for l in lines] == [3, 6]
+    assert all(np.isfinite(l["train_loss"]) and np.isfinite(l["val_loss"]) and l["learning_rate"] == 0.00015 for l in lines)
+    imp = np.load(os.path.join(rd, "tb", "imputations_6.npy"))
+    assert imp.dtype == np.uint8 and imp.shape == (4, 28, 28 * 10, 1)
+    sys.path.insert(0, root)
+    st = pickle.load(open(os.path.join(rd, "train_state.pkl"), "rb"))
+    assert st.step == 6 and st.opt_state["count"] == 6 and st.ema_params is not None
+    k = "decoder/block_0/resnet/c1/w"
+    assert not torch.equal(st.ema_params[k], st.params[k])
+    out = run("eval_pm_vdvae_imputation.py", "--run_dir", rd, "--num_instances", "8", "--batch_size", "4", "--num_samples", "2")
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["num_instances"] == 8 and np.isfinite(res["mean_psnr"]) and 0.0 < res["mean_psnr"] < 60.0
