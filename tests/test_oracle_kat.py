@@ -384,3 +384,81 @@ def test_pixelcnn_dropout_and_sampling_helpers():
     assert (PO.pixel_cnn_sample(p, "pc", cfg, cond, 3, g2) == 4).all()
     x = torch.rand(2, 4, 4, 1)
     assert torch.allclose(PO.imputation_psnr((x + 0.1)[:, None].repeat(1, 3, 1, 1, 1), x), torch.full((2,), 20.0))
+
+
+# ----------------------------------------------------------------------------------------------
+# VDVAE oracle (oracle/vdvae_oracle.py) - SURVEY.md 8c items (iv), (viii), (ix), (xi)
+# ----------------------------------------------------------------------------------------------
+def test_vdvae_primitives():
+    from oracle import vdvae_oracle as DO
+
+    # gelu tanh form: known values
+    assert DO.gelu(torch.tensor([0.0, 1.0, -1.0, 3.0])).tolist() == pytest.approx([0.0, 0.8411919906, -0.1588080094, 2.9963627], abs=1e-7)
+    assert DO.nearest_index(7, 3) == [0, 0, 1, 1, 1, 2, 2] and DO.nearest_index(3, 1) == [0, 0, 0]
+    assert DO.nearest_index(14, 7) == [i // 2 for i in range(14)] and DO.nearest_index(28, 14) == [i // 2 for i in range(28)]
+    x = torch.arange(49.0).reshape(1, 7, 7, 1)
+    p = DO.avg_pool(x, 2)                                   # VALID: 7 -> 3, the last row / column is dropped
+    assert p.shape == (1, 3, 3, 1) and p[0, 0, 0, 0].item() == (0 + 1 + 7 + 8) / 4 and p[0, 2, 2, 0].item() == (32 + 33 + 39 + 40) / 4
+    assert DO.parse_layer_string("1x2,3m1,3x2,7d2,5") == [(1, None), (1, None), (3, 1), (3, None), (3, None), (7, 2), (5, None)]
+    # KL closed forms against torch.distributions
+    gen = torch.Generator().manual_seed(0)
+    la, lb = torch.randn(5, 4, generator=gen), torch.randn(5, 4, generator=gen)
+    sa, sb = torch.rand(5, 4, generator=gen) + 0.3, torch.rand(5, 4, generator=gen) + 0.3
+    td = torch.distributions
+    want = td.kl_divergence(td.Independent(td.Normal(la, sa), 1), td.Independent(td.Normal(lb, sb), 1))
+    assert torch.allclose(DO.mvn_diag_kl(la, sa, lb, sb), want, rtol=1e-12)
+    L = torch.tril(torch.randn(5, 4, 4, generator=gen)) * 0.3 + torch.diag_embed(torch.rand(5, 4, generator=gen) + 0.5)
+    want = td.kl_divergence(td.MultivariateNormal(la, scale_tril=torch.diag_embed(sa)), td.MultivariateNormal(lb, scale_tril=L))
+    assert torch.allclose(DO.mvn_diag_tril_kl(la, sa, lb, L), want, rtol=1e-10)
+
+
+def test_discretised_logistic_mixture_is_normalised_with_open_edge_bins():
+    from oracle import vdvae_oracle as DO
+
+    gen = torch.Generator().manual_seed(1)
+    params = torch.randn(1, 1, 1, 30, generator=gen)
+    lp = torch.stack([DO.logistic_mixture_log_prob(params, torch.full((1, 1, 1, 1), float(v)), 10) for v in range(256)])
+    assert torch.exp(lp).sum().item() == pytest.approx(1.0, abs=1e-12)
+    # one very sharp component far below 0: all of its mass lands in the open bin at 0
+    sharp = torch.zeros(1, 1, 1, 3)
+    sharp[..., 1], sharp[..., 2] = -3.0, -20.0
+    assert DO.logistic_mixture_log_prob(sharp, torch.zeros(1, 1, 1, 1), 1).item() == pytest.approx(0.0, abs=1e-9)
+    assert DO.logistic_mixture_mean(sharp, 1).item() == 0.0           # loc clipped to -1 -> pixel 0
+
+
+def test_vdvae_fresh_prior_block_and_param_count():
+    from oracle import vdvae_oracle as DO
+    from tests.ref_configs import pm_vdvae_mnist
+
+    cfg = pm_vdvae_mnist()["model"]
+    p = DO.init_params(cfg, seed=3)
+    assert sum(t.numel() for t in p.values()) == 7266942
+    x = torch.randn(2, 3, 3, 192)
+    pr = DO.block(p, "decoder/block_3/prior", x, True, False)
+    assert pr.abs().max().item() == 0.0                                   # zero_last: loc = 0, h = 0
+    assert (O.softplus(pr[..., 16:32]) + 1e-5)[0, 0, 0, 0].item() == pytest.approx(0.693157, abs=1e-6)
+    assert p["decoder/gain"].eq(1).all() and p["decoder/x_bias_7"].shape == (1, 7, 7, 192)
+
+
+def test_vdvae_gradcheck_tiny():
+    from oracle import vdvae_oracle as DO
+
+    cfg = {"model": {"image_shape": (7, 7, 1), "encoder_blocks": "7x1,7d2,3x1,3d2,1x1", "decoder_blocks": "1x1,3m1,3x1,7m3,7x1",
+                     "latent_dim": 3, "width": 8, "bottleneck_multiple": 0.5, "no_bias_above": 64, "num_mixtures": 4}}
+    gen = torch.Generator().manual_seed(2)
+    p = {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in DO.init_params(cfg["model"], seed=1).items()}
+    x = torch.randint(0, 256, (2, 7, 7, 1), generator=gen).double()
+    b = (torch.rand(2, 7, 7, 1, generator=gen) < 0.5).double()
+    eps = [torch.randn(2, r, r, 3, generator=gen) for r, _ in DO.parse_layer_string(cfg["model"]["decoder_blocks"])]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, _, _ = DO.vdvae_loss(leaves, cfg, x, b, eps)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    # finite differences see through stop_gradient, autograd does not: only parameters whose influence never
+    # passes the stop_gradient(x) in front of a LATER masked-posterior block can be checked this way
+    for name in ("decoder/block_2/masked_posterior/c4/w", "decoder/block_4/resnet/c2/w", "masked_encoder/block_0/c1/w",
+                 "decoder/out_net/w", "decoder/gain"):
+        d = torch.randn(p[name].shape, generator=gen)
+        h = 1e-6
+        lp = DO.vdvae_loss({**p, name: p[name] + h * d}, cfg, x, b, eps)[0]
+        lm = DO.vdvae_loss({**p, name: p[name] - h * d}, cfg, x, b, eps)[0]
+        assert (lp - lm).item() / (2 * h) == pytest.approx((grads[name] * d).sum().item(), rel=2e-5), name
