@@ -115,10 +115,14 @@ class PosteriorMatchingVAE(Module):
             pfeat = self.partial_encoder_net(Feat(xob), is_training=is_training)
         feat = self.encoder_net(Feat(x), is_training=is_training)
         z, kl = self.posterior_dist.sample_and_kl(feat, eps)
+        # the posterior-matching log-prob only needs z and the masked encoder's features: it runs on the
+        # side stream beside the decoder
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            mll = self.partial_posterior_dist.log_prob(pfeat, z)
         dec = self.decoder_net(Feat(z), is_training=is_training)
         rec = self.decoder_dist.log_prob_sum(dec, x)
         main.wait_stream(side)
-        mll = self.partial_posterior_dist.log_prob(pfeat, z)
         self._z = z
         return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll}
 
