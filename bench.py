@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events")
     ap.add_argument("--f32", action="store_true", help="every GEMM on the f32 MFMA (strict-parity mode) instead of the "
                                                       "default bf16x3 split on the bf16 matrix cores")
+    ap.add_argument("--wgrad-streams", action="store_true", help="weight-gradient kernels on companion streams")
     ap.add_argument("--serial", action="store_true", help="one stream (clean per-kernel durations for rocprofv3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 path with several ranks on ONE GPU)")
@@ -95,6 +96,7 @@ def main():
     model.init(xs)
     model.store.use_bf16 = not args.f32
     model.concurrent = not args.serial
+    model.ws.overlap_wgrad = args.wgrad_streams
     opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg.get("weight_decay", 0.0)),
                       optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
     ts = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=world, rank=rank, use_graph=args.graph)

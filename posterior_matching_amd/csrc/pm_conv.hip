@@ -893,7 +893,9 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
 
     const int m = blockIdx.x * 128 + wave * 32 + i;
     int rbase = 0, rpy = ROW_INVALID, rqx = ROW_INVALID, rowoff = -1;
-    const int cchunks = g.C / BK;
+    // channels are walked in chunks of 32; when C % 32 != 0 the last chunk of a tap reads past the row's
+    // channels (the next pixel, or zeros past the tensor end) against zero-padded weights
+    const int cchunks = (g.C + BK - 1) / BK;
     int nsteps_all;
     if constexpr (DENSE) {
         if (m < g.M) {
@@ -1132,28 +1134,52 @@ struct SplitJob {
     int kw, kws;         // compact tap t reads weight-layout tap (t / kw) * kws + t % kw
 };
 
+// One workgroup = one (tap, 32-channel chunk, 32-column tile) of one job: 1024 elements.  The source tile is
+// read along whichever of its axes is contiguous in the parameter buffer (columns n for HWIO forward weights,
+// channels c for the data-gradient direction) and written k-contiguous; a 32 x 33 LDS tile does the transpose.
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ params, __bf16* __restrict__ out,
                                                               const SplitJob* __restrict__ jobs, int njobs) {
-    // find the job of this block (jobs are few: linear scan)
-    int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
-    const SplitJob job = jobs[j];
-    const long long total = (long long)job.taps * (job.C / BK) * job.npad * BK;
-    const long long e = ((long long)blockIdx.x - job.first_block) * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int k = (int)(e % BK);
-    const int n = (int)((e / BK) % job.npad);
-    const long long tc = e / ((long long)BK * job.npad);
-    const int cc = (int)(tc % (job.C / BK));
-    const int tap = (int)(tc / (job.C / BK));
-    float v = 0.f;
-    if (n < job.N)
-        v = params[job.src_off + (long long)((tap / job.kw) * job.kws + tap % job.kw) * job.wts +
-                   (long long)(cc * BK + k) * job.wcs + (long long)n * job.wns];
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
-    out[job.dst_off + e] = hi;
-    out[job.dst_off + job.plane + e] = lo;
+    __shared__ float tile[32][33];
+    // jobs are sorted by first_block: binary search for the job of this workgroup
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= jobs[mid].first_block) lo = mid;
+        else hi = mid - 1;
+    }
+    const SplitJob job = jobs[lo];
+    const int cch = (job.C + BK - 1) / BK;   // channel chunks per tap, the last one zero-padded
+    const int ntiles = job.npad / 32;
+    int t = (int)blockIdx.x - job.first_block;
+    if (t >= job.taps * cch * ntiles) return;
+    const int nt = t % ntiles;
+    t /= ntiles;
+    const int cc = t % cch;
+    const int tap = t / cch;
+    const long long base = job.src_off + (long long)((tap / job.kw) * job.kws + tap % job.kw) * job.wts;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads, 4 passes
+    const bool n_contig = job.wns <= job.wcs;                       // which source axis is the faster one
+#pragma unroll
+    for (int pss = 0; pss < 4; ++pss) {
+        const int a = ty + 8 * pss;                                  // slow index of this pass
+        const int k = n_contig ? a : tx;                             // channel within the chunk
+        const int n = (n_contig ? tx : a) + 32 * nt;                 // output column
+        float v = 0.f;
+        if (n < job.N && cc * BK + k < job.C)
+            v = params[base + (long long)(cc * BK + k) * job.wcs + (long long)n * job.wns];
+        tile[n_contig ? a : tx][n_contig ? tx : a] = v;              // tile[k][n - 32 nt]
+    }
+    __syncthreads();
+    const long long dst0 = job.dst_off + ((long long)(tap * cch + cc) * job.npad + 32 * nt) * BK;
+#pragma unroll
+    for (int pss = 0; pss < 4; ++pss) {
+        const int nl = ty + 8 * pss;                                 // column within the tile
+        const float v = tile[tx][nl];                                // k = tx: k-contiguous stores
+        const __bf16 hi16 = (__bf16)v;
+        const __bf16 lo16 = (__bf16)(v - (float)hi16);
+        out[dst0 + (long long)nl * BK + tx] = hi16;
+        out[dst0 + job.plane + (long long)nl * BK + tx] = lo16;
+    }
 }
 
 // ------------------------------------ weight gradient ----------------------------------------
@@ -1795,9 +1821,9 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
                                    const float* bias, const float* aux, const float* res, float* out) {
     GemmArgs a;
     if (!fill_geom(d, a.g, true) || !in || !wsplit || !out) return PM_EINVAL;
-    if (d->C % BK != 0 || (d->groups != 1 && d->w_gs % 8 != 0)) return PM_EINVAL;
+    if (d->C % 8 != 0 || (d->groups != 1 && d->w_gs % 8 != 0)) return PM_EINVAL;   // C % 32 != 0: zero-padded weight chunks
     if (!aligned16(in) || !aligned16(wsplit) || (d->in_gs % 4) != 0) return PM_EINVAL;
-    if (a.g.KH * a.g.KW * (a.g.C / BK) > DMAXSTEPS || a.g.KH > 15 || a.g.KW > 15) return PM_EINVAL;
+    if (a.g.KH * a.g.KW * ((a.g.C + BK - 1) / BK) > DMAXSTEPS || a.g.KH > 15 || a.g.KW > 15) return PM_EINVAL;
     if ((long long)a.g.B * a.g.IH * a.g.IW * a.g.C * 4 >= 0x7ffffff0LL) return PM_EINVAL;
     if (d->d != 1 && d->d != 2) return PM_EINVAL;
     a.in = in; a.w = nullptr; a.bias = bias; a.aux = aux; a.res = res; a.out = out;
@@ -1810,7 +1836,7 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
         if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
     }
     const int npad = (a.g.N + 31) / 32 * 32;
-    const long long plane = (long long)a.g.KH * a.g.KW * a.g.C * npad;
+    const long long plane = (long long)a.g.KH * a.g.KW * ((a.g.C + BK - 1) / BK) * BK * npad;
     const int rn = a.g.N > 32 ? 2 : 1;
     dim3 grid((a.g.M + 127) / 128, (a.g.N + 32 * rn - 1) / (32 * rn), G * a.ksplit);
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);

@@ -122,11 +122,11 @@ class ParamStore:
         for pname, geom, mode, kw in self._split_requests:
             d = geom._desc(1, mode, **{k: v for k, v in kw.items() if k != "B"})
             groups = d.groups
-            if d.C % 32 != 0:
+            if d.C % 8 != 0:
                 views.append(None)
                 continue
             npad = (d.N + 31) // 32 * 32
-            plane = d.KH * d.KW * d.C * npad
+            plane = d.KH * d.KW * ((d.C + 31) // 32 * 32) * npad      # channels zero-padded to whole 32-chunks per tap
             start = off
             for gi in range(groups):
                 j = SplitJob()
@@ -135,7 +135,7 @@ class ParamStore:
                 j.taps, j.C, j.N, j.npad = d.KH * d.KW, d.C, d.N, npad
                 j.wts, j.wcs, j.wns = d.wts, d.wcs, d.wns
                 j.kw, j.kws = d.KW, d.kws
-                j.first_block, j.num_blocks = blk, (plane + 255) // 256
+                j.first_block, j.num_blocks = blk, plane // 1024        # one workgroup per 32 x 32 tile
                 blk += j.num_blocks
                 off += 2 * plane
                 jobs.append(j)

@@ -257,7 +257,7 @@ def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
 
 def bf16_supported(desc: GatherDesc) -> bool:
     """pm_gather_gemm_bf16 preconditions (include/pmhip.h)."""
-    return desc.C % 32 == 0 and desc.d in (1, 2) and desc.KH * desc.KW * (desc.C // 32) <= 256
+    return desc.C % 8 == 0 and desc.d in (1, 2) and desc.KH * desc.KW * ((desc.C + 31) // 32) <= 256
 
 
 def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None:

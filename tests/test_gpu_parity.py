@@ -47,6 +47,9 @@ CONV_CASES = [
     ("conv", 8, 28, 1, 16, 4, 2, "SAME"), ("conv", 8, 14, 16, 32, 4, 2, "SAME"), ("conv", 32, 7, 32, 32, 3, 1, "SAME"),
     ("conv", 32, 7, 32, 32, 1, 1, "SAME"), ("conv", 32, 7, 32, 64, 1, 1, "SAME"), ("conv", 32, 7, 64, 32, 3, 1, "SAME"),
     ("convT", 8, 7, 32, 16, 4, 2, "SAME"), ("convT", 8, 14, 16, 1, 4, 2, "SAME"),
+    # VDVAE bottleneck layers (reference vdvae.py:282-292 at width 192, bottleneck 48): C % 32 != 0 on the bf16 path
+    ("conv", 4, 14, 48, 48, 3, 1, "SAME"), ("conv", 4, 7, 48, 192, 1, 1, "SAME"), ("conv", 4, 7, 192, 48, 1, 1, "SAME"),
+    ("conv", 3, 3, 48, 152, 1, 1, "SAME"), ("conv", 2, 28, 48, 224, 1, 1, "SAME"), ("dense", 70, 1, 24, 40, 1, 1, "VALID"),
 ]
 
 
@@ -558,7 +561,7 @@ def test_masked_conv_fwd_dgrad_wgrad(B, H, ci, co, full, vr, vc, bf16x3):
             j.src_off, j.dst_off, j.plane = 0, 0, plane
             j.taps, j.C, j.N, j.npad = desc.KH * desc.KW, desc.C, desc.N, npad
             j.wts, j.wcs, j.wns, j.kw, j.kws = desc.wts, desc.wcs, desc.wns, desc.KW, desc.kws
-            j.first_block, j.num_blocks = 0, (plane + 255) // 256
+            j.first_block, j.num_blocks = 0, plane // 1024
             out = torch.zeros(2 * plane, dtype=torch.bfloat16, device=d)
             jobs = torch.frombuffer(bytearray(bytes(j)), dtype=torch.uint8).to(d)
             ops.split_weights(wd.reshape(-1), out, jobs, 1, j.num_blocks)
