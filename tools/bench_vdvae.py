@@ -42,4 +42,10 @@ for B in [int(v) for v in args.batches.split(",")]:
                 fp.write(f"{k:48s} calls/step {v['calls']:4d}  ms/step {v['ms']:9.3f}  "
                          f"TFLOP/s {(v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else 0:7.2f}  GB/s {v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f}\n")
             fp.write(f"sum of kernel time per step: {tot:.3f} ms over {sum(v['calls'] for v in summ.values())} launches\n")
+            agg = {}
+            for tag, detail, ms, fl in timer.per_call():
+                a = agg.setdefault((tag, detail), [0, 0.0, 0.0])
+                a[0] += 1; a[1] += ms; a[2] += fl
+            for (tag, detail), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+                fp.write(f"{tag:44s} {detail:50s} x{n:4d} avg {ms / n * 1e3:7.1f} us  {fl / (ms * 1e-3) / 1e12 if fl else 0:6.2f} TFLOP/s\n")
     del ts, m
