@@ -209,20 +209,32 @@ class PosteriorMatchingDecoderBlock(Module):
         self.resnet = Block(store, ws, f"{name}/resnet", res, res, width, mid, width, u3, out_init_div=num_blocks)
 
     def forward(self, x_in: torch.Tensor, acts: torch.Tensor, macts: torch.Tensor, eps: torch.Tensor,
-                kl: torch.Tensor, pm_kl: torch.Tensor) -> torch.Tensor:
+                kl: torch.Tensor, pm_kl: torch.Tensor, streams=None) -> torch.Tensor:
+        """streams = (s1, s2): the posterior, masked-posterior and prior Blocks only share x_in, so the latter two
+        run on companion streams (every kernel here is a few workgroups: latency, not throughput, bounds the step)."""
         B, r, W, Z = x_in.shape[0], self.base, self.width, self.Z
         P = r * r
         sh = lambda c: (B, r, r, c)   # noqa: E731
         self._x_in, self._acts, self._macts, self._eps = x_in, acts, macts, eps
+        main = torch.cuda.current_stream(x_in.device)
+        s1, s2 = streams if streams is not None else (main, main)
+        if streams is not None:
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            am = self.buf("am", sh(2 * W))
+            ops.gelu_fwd(x_in, macts, am)                  # stop_gradient(x): handled in backward (:536-538)
+            self._mp = self.masked_posterior.forward(am)
+        with torch.cuda.stream(s2):
+            ap = self.buf("ap", sh(W))
+            ops.gelu_fwd(x_in, None, ap)
+            self._pr = self.prior.forward(ap)
         a = self.buf("a", sh(2 * W))
         ops.gelu_fwd(x_in, acts, a)
         self._pp = self.posterior.forward(a)
-        am = self.buf("am", sh(2 * W))
-        ops.gelu_fwd(x_in, macts, am)                      # stop_gradient(x): handled in backward (:536-538)
-        self._mp = self.masked_posterior.forward(am)
-        ap = self.buf("ap", sh(W))
-        ops.gelu_fwd(x_in, None, ap)
-        self._pr = self.prior.forward(ap)
+        if streams is not None:
+            main.wait_stream(s1)
+            main.wait_stream(s2)
         x1 = self.buf("x1", sh(W))
         ops.add_cols(x_in, self._pr, 2 * Z, x1)              # x += h (:558)
         self._z = self.buf("z", sh(Z))
@@ -258,12 +270,15 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.gelu_fwd(x2, None, x2g)
         return self.resnet.forward(x2g, res=x2)
 
-    def backward(self, dx3: torch.Tensor, dacts: torch.Tensor, dmacts: torch.Tensor, g_kl: float, g_pm: float) -> torch.Tensor:
+    def backward(self, dx3: torch.Tensor, dacts: torch.Tensor, dmacts: torch.Tensor, g_kl: float, g_pm: float,
+                 streams=None) -> torch.Tensor:
         """dx3: gradient w.r.t. this block's output.  Accumulates into dacts / dmacts (the encoder
-        activations of this resolution) and returns the gradient w.r.t. x_in."""
+        activations of this resolution; dmacts only ever on streams[1]) and returns the gradient w.r.t. x_in."""
         B, r, W, Z = dx3.shape[0], self.base, self.width, self.Z
         P = r * r
         sh = lambda c: (B, r, r, c)   # noqa: E731
+        main = torch.cuda.current_stream(dx3.device)
+        s1, s2 = streams if streams is not None else (main, main)
         dx2 = self.buf("dx2", sh(W))
         self.resnet.backward(dx3, dx2, x_pre=self._x2, res=dx3)                 # dx2 = dx1
         self.wgrad(self.z_proj.g, self._z, dx2, self.store.g[self.z_proj.w], self.store.g[self.z_proj.b])
@@ -274,13 +289,21 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.copy_cols(dx2, dpr, 2 * Z)                                            # d h = d x1
         dmp = self.buf("dmp", tuple(self._mp.shape))
         ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, P)
+        if streams is not None:
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            da = self.buf("da", sh(2 * W))
+            self.posterior.backward(dpp, da)
+        with torch.cuda.stream(s2):
+            dam = self.buf("dam", sh(2 * W))
+            self.masked_posterior.backward(dmp, dam)
+            ops.gelu_bwd(self._x_in, self._macts, dam, None, dmacts, accumulate=True)   # no gradient into stop_gradient(x)
         dxin = self.buf("dxin", sh(W))
         self.prior.backward(dpr, dxin, x_pre=self._x_in, res=dx2)               # + the direct x1 = x_in + h path
-        da = self.buf("da", sh(2 * W))
-        self.posterior.backward(dpp, da)
+        if streams is not None:
+            main.wait_stream(s1)
         ops.gelu_bwd(self._x_in, self._acts, da, dxin, dacts, accumulate=True)
-        self.masked_posterior.backward(dmp, da)
-        ops.gelu_bwd(self._x_in, self._macts, da, None, dmacts, accumulate=True)   # no gradient into stop_gradient(x)
         return dxin
 
 
@@ -304,6 +327,15 @@ class PosteriorMatchingVDVAE(Module):
         self.masked_encoder = Encoder(width, encoder_blocks, bottleneck_multiple)
         self._device, self._seed = device, seed
         self.store: Optional[ParamStore] = None
+        self.concurrent = True      # independent chains (the two encoders; the three Blocks of a decoder block) on companion streams
+        self._streams = None
+
+    def _branch_streams(self, device):
+        if not self.concurrent:
+            return None
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return self._streams
 
     def init(self, device=None, seed: Optional[int] = None) -> None:
         if not torch.cuda.is_available():
@@ -359,8 +391,17 @@ class PosteriorMatchingVDVAE(Module):
         ops.scale_shift(x, 1.0 / 127.5, -1.0, xn)
         xob = self.ws.get("vdvae/x_o_b", (B, H, W_, 2))
         ops.mask_concat(xn, b, xob)
-        acts = self.encoder(xn)
-        macts = self.masked_encoder(xob)
+        streams = self._branch_streams(x.device)
+        main = torch.cuda.current_stream(x.device)
+        if streams is not None:
+            streams[0].wait_stream(main)
+            with torch.cuda.stream(streams[0]):
+                macts = self.masked_encoder(xob)
+            acts = self.encoder(xn)
+            main.wait_stream(streams[0])
+        else:
+            acts = self.encoder(xn)
+            macts = self.masked_encoder(xob)
         self._acts, self._macts = acts, macts
         kl, pm_kl = self.ws.get("vdvae/kl", (B,)), self.ws.get("vdvae/pm_kl", (B,))
         ops.fill_zero(kl)
@@ -377,7 +418,7 @@ class PosteriorMatchingVDVAE(Module):
                 self._first_use[r] = i
             if blk.mixin is not None:
                 ops.resize_nearest_add(xs[blk.mixin], x_in)
-            xs[r] = blk.forward(x_in, acts[r], macts[r], eps[i], kl, pm_kl)
+            xs[r] = blk.forward(x_in, acts[r], macts[r], eps[i], kl, pm_kl, streams=streams)
         top = xs[H]
         self._top = top
         px_z = self.ws.get("decoder/px_z", tuple(top.shape))
@@ -473,10 +514,12 @@ class PosteriorMatchingVDVAE(Module):
         dmacts = {r: self.ws.get(f"vdvae/dmacts_{r}", tuple(t.shape)) for r, t in self._macts.items()}
         for t in list(dacts.values()) + list(dmacts.values()):
             ops.fill_zero(t)
+        streams = self._branch_streams(self._x.device)
+        main = torch.cuda.current_stream(self._x.device)
         for i in reversed(range(len(self.dec_blocks))):
             blk = self.dec_blocks[i]
             r = blk.base
-            dxin = blk.backward(dxs[r], dacts[r], dmacts[r], g, g)
+            dxin = blk.backward(dxs[r], dacts[r], dmacts[r], g, g, streams=streams)
             if blk.mixin is not None:
                 ops.resize_nearest_add_bwd(dxin, dxs[blk.mixin])
             if self._first_use[r] == i:
@@ -486,8 +529,18 @@ class PosteriorMatchingVDVAE(Module):
                 # x_in was the previous block of this resolution's output, and this block its only consumer (mix-in
                 # sources are always the LAST state of a coarser resolution): hand dxin over as that block's dx3
                 dxs[r] = dxin
-        self.encoder.backward(dacts)
-        self.masked_encoder.backward(dmacts)
+        if streams is not None:
+            s1, s2 = streams
+            s1.wait_stream(s2)                       # dmacts were accumulated on s2
+            s1.wait_stream(main)
+            with torch.cuda.stream(s1):
+                self.masked_encoder.backward(dmacts)
+            self.encoder.backward(dacts)
+            main.wait_stream(s1)
+            main.wait_stream(s2)
+        else:
+            self.encoder.backward(dacts)
+            self.masked_encoder.backward(dmacts)
         self.ws.join_aux()
 
     def zero_grad(self) -> None:
