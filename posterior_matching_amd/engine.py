@@ -18,6 +18,35 @@ from .models.vae import PosteriorMatchingVAE
 from .optim import Chain
 
 
+class _PlannedStep:
+    """Host side of a train step: the first call runs the model classes eagerly (allocating every buffer), the
+    second call runs them again while recording an ops.LaunchPlan, every later call replays the plan (same
+    launches, same streams and cross-stream waits, ~2 us of host time per launch).  `use_plan = False` keeps the
+    eager path; a KernelTimer (bench.py's profiling pass) also forces it."""
+
+    use_plan = True
+    _plan: Optional["ops.LaunchPlan"] = None
+    _warm = False
+
+    def _planned(self, sequence) -> None:
+        if self._plan is not None:
+            self._plan.replay()
+            return
+        if self.use_plan and self._warm and ops._timer is None:
+            ops.begin_recording()
+            try:
+                sequence()
+            finally:
+                plan = ops.end_recording()
+            self._plan = plan
+        else:
+            sequence()
+            self._warm = True
+
+    def invalidate_plan(self) -> None:
+        self._plan, self._warm = None, False
+
+
 def loss_cfg_from_config(config: Mapping[str, Any], batch_size: int) -> LossCfg:
     """get_beta_schedule + the loss weights of loss_fn (train_pm_vae.py:28-43,62-70)."""
     c = LossCfg()
@@ -39,12 +68,12 @@ def loss_cfg_from_config(config: Mapping[str, Any], batch_size: int) -> LossCfg:
     return c
 
 
-class PMVAETrainStep:
+class PMVAETrainStep(_PlannedStep):
     """Fused train step over static device buffers (x, b, eps are copied/generated in place)."""
 
     def __init__(self, model: PosteriorMatchingVAE, config: Mapping[str, Any], optimizer: Chain, batch_size: int,
                  x_shape, seed: int = 0, world_size: int = 1, rank: int = 0, use_graph: bool = False,
-                 external_eps: bool = False):
+                 external_eps: bool = False, use_plan: bool = True):
         """use_graph=False (default): eager launches, the ELBO and posterior-matching chains overlap on
         two HIP streams.  use_graph=True: one HIP graph replay per step; ROCm 7.2 serialises the
         branches of a captured graph, so this form runs the two chains back to back (measured:
@@ -68,6 +97,7 @@ class PMVAETrainStep:
         self.g_mll = torch.zeros(batch_size, device=dev)
         self.external_eps = external_eps
         self.use_graph = use_graph
+        self.use_plan = use_plan and not use_graph
         if use_graph:
             model.concurrent = False
         # HIP graph capture is not allowed on the NULL stream: the step owns a side stream
@@ -96,7 +126,13 @@ class PMVAETrainStep:
     def _allreduce(self) -> None:
         from .parallel import allreduce_sum_
 
-        allreduce_sum_(self.model.store.flat_g)           # sum over ranks; Adam divides by world_size
+        ops.host_call(allreduce_sum_, self.model.store.flat_g)           # sum over ranks; Adam divides by world_size
+
+    def _eager_sequence(self) -> None:
+        self._forward_backward()
+        if self.world_size > 1:
+            self._allreduce()
+        self._update()
 
     # -- one optimizer step on whatever is in self.x / self.b (/ self.eps) ---------------------
     def step(self) -> None:
@@ -105,10 +141,7 @@ class PMVAETrainStep:
 
     def _step(self) -> None:
         if not self.use_graph:
-            self._forward_backward()
-            if self.world_size > 1:
-                self._allreduce()
-            self._update()
+            self._planned(self._eager_sequence)
             return
         if self._graph_fb is None:
             # run once eagerly so that every workspace buffer exists before capture
@@ -165,12 +198,12 @@ class PMVAETrainStep:
         return {"loss": v[0], "reconstruction_ll": v[1], "kl": v[2], "matching_ll": v[3], "beta": v[4]}
 
 
-class VQVAETrainStep:
+class VQVAETrainStep(_PlannedStep):
     """train_vqvae.py:67-111 as one launch sequence: VQVAE forward (EMA codebook update inside, as in
     haiku) -> loss -> backward -> [gradient all-reduce] -> Adam -> step += 1."""
 
     def __init__(self, model, optimizer: Chain, batch_size: int, x_shape, world_size: int = 1, rank: int = 0,
-                 use_graph: bool = False):
+                 use_graph: bool = False, use_plan: bool = True):
         if model.store is None:
             model.init(x_shape)
         dev = model.store.device
@@ -180,6 +213,7 @@ class VQVAETrainStep:
         self.x = torch.zeros((batch_size,) + tuple(x_shape), device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.use_graph = use_graph and world_size == 1
+        self.use_plan = use_plan and not self.use_graph
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         self._graph: Optional[ops.Graph] = None
@@ -192,7 +226,7 @@ class VQVAETrainStep:
         if self.world_size > 1:
             from .parallel import allreduce_sum_
 
-            allreduce_sum_(s.flat_g)
+            ops.host_call(allreduce_sum_, s.flat_g)
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
         s.split_all()
         ops.counter_increment(self.step_dev)
@@ -200,7 +234,7 @@ class VQVAETrainStep:
     def step(self) -> None:
         with torch.cuda.stream(self.stream):
             if not self.use_graph:
-                self._sequence()
+                self._planned(self._sequence)
             elif self._graph is None:
                 self._sequence()                    # eager once: every workspace buffer exists before capture
                 self.stream.synchronize()
@@ -231,7 +265,7 @@ class VQVAETrainStep:
         return self.read_metrics()
 
 
-class PMVQVAETrainStep:
+class PMVQVAETrainStep(_PlannedStep):
     """train_pm_vqvae.py:81-123 as one launch sequence: frozen VQ-VAE encode (is_training=False) ->
     code indices; partial encoder on [x*b | b] -> conditional vector; loss = -mean PixelCNN.log_prob;
     backward through the PixelCNN and the partial encoder only (trainable_predicate: every module
@@ -263,6 +297,7 @@ class PMVQVAETrainStep:
         self.g_ll = torch.zeros(batch_size, device=dev)
         self.dropout_masks = None          # parity tests set explicit masks (external_dropout)
         self.external_dropout = external_dropout
+        self.use_plan = not external_dropout   # explicit masks are new tensors every step: nothing static to replay
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
 
@@ -293,14 +328,14 @@ class PMVQVAETrainStep:
         if self.world_size > 1:
             from .parallel import allreduce_sum_
 
-            allreduce_sum_(s.flat_g)
+            ops.host_call(allreduce_sum_, s.flat_g)
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
         s.split_all()
         ops.counter_increment(self.step_dev)
 
     def step(self) -> None:
         with torch.cuda.stream(self.stream):
-            self._sequence()
+            self._planned(self._sequence)
 
     def set_batch(self, x: torch.Tensor, b: torch.Tensor) -> None:
         self.stream.wait_stream(torch.cuda.current_stream(self.x.device))
@@ -322,7 +357,7 @@ class PMVQVAETrainStep:
         return self.read_metrics()
 
 
-class VDVAETrainStep:
+class VDVAETrainStep(_PlannedStep):
     """train_pm_vdvae.py:109-154 as one launch sequence: eps -> PosteriorMatchingVDVAE forward ->
     loss = -mean(rec_ll - kl) + mean(pm_kl) -> backward -> [gradient all-reduce] -> global-norm clip +
     Adam (+ parameter EMA, non-finite steps skipped) -> step += 1."""
@@ -372,7 +407,7 @@ class VDVAETrainStep:
         if self.world_size > 1:
             from .parallel import allreduce_sum_
 
-            allreduce_sum_(s.flat_g)
+            ops.host_call(allreduce_sum_, s.flat_g)
         ops.sumsq(s.flat_g, self.gnorm_sq)
         ops.adam_step_clip_ema(s.flat_p, s.flat_g, s.flat_m, s.flat_v, self.ema, s.n_decay, self.opt_count, self.gnorm_sq,
                                self.adam_cfg, self.clip, self.ema_rate if self.ema_rate is not None else 0.0, self.skip)
@@ -381,7 +416,7 @@ class VDVAETrainStep:
 
     def step(self) -> None:
         with torch.cuda.stream(self.stream):
-            self._sequence()
+            self._planned(self._sequence)
 
     def set_batch(self, x: torch.Tensor, b: torch.Tensor, eps: Optional[Sequence[torch.Tensor]] = None) -> None:
         self.stream.wait_stream(torch.cuda.current_stream(self.x.device))

@@ -197,7 +197,7 @@ class Workspace:
         cur = torch.cuda.current_stream(self.device)
         aux = self._aux_streams.get(cur.cuda_stream)
         if aux is not None and self.overlap_wgrad:
-            cur.wait_stream(aux)
+            ops.wait_stream(cur, aux)
 
     def get(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         key = (name, tuple(int(s) for s in shape))
@@ -237,6 +237,6 @@ class Module:
         if aux is cur:
             ops.layer_wgrad(*args, **kw)
             return
-        aux.wait_stream(cur)
+        ops.wait_stream(aux, cur)
         with torch.cuda.stream(aux):
             ops.layer_wgrad(*args, **kw)

@@ -108,7 +108,7 @@ class PosteriorMatchingVAE(Module):
         # run it on a second HIP stream so that the two chains fill the chip together (most layers
         # launch only 1-2 workgroups per CU).  Under graph capture this becomes a forked branch.
         main, side = torch.cuda.current_stream(x.device), self._side_stream(x.device)
-        side.wait_stream(main)
+        ops.wait_stream(side, main)
         with torch.cuda.stream(side):
             xob = self.ws.get("x_o_b", tuple(x.shape[:-1]) + (x.shape[-1] + b.shape[-1],))
             ops.mask_concat(x, b, xob)
@@ -117,12 +117,12 @@ class PosteriorMatchingVAE(Module):
         z, kl = self.posterior_dist.sample_and_kl(feat, eps)
         # the posterior-matching log-prob only needs z and the masked encoder's features: it runs on the
         # side stream beside the decoder
-        side.wait_stream(main)
+        ops.wait_stream(side, main)
         with torch.cuda.stream(side):
             mll = self.partial_posterior_dist.log_prob(pfeat, z)
         dec = self.decoder_net(Feat(z), is_training=is_training)
         rec = self.decoder_dist.log_prob_sum(dec, x)
-        main.wait_stream(side)
+        ops.wait_stream(main, side)
         self._z = z
         return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll}
 
@@ -140,22 +140,22 @@ class PosteriorMatchingVAE(Module):
         main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
         want_dz = not self._matching_ll_stop_gradients                      # vae.py:136-137
         dz_pm = self.ws.get("dz_matching", self._z.shape) if want_dz else None
-        side.wait_stream(main)
+        ops.wait_stream(side, main)
         with torch.cuda.stream(side):     # posterior-matching branch: AR-GMM / TriL head + partial encoder
             dpenc = self.partial_posterior_dist.backward_log_prob(g_mll, dz_pm)
             dz_ready = torch.cuda.Event()
-            dz_ready.record(side)
+            ops.record_event(dz_ready, side)
             self.partial_encoder_net.backward(dpenc, need_input_grad=False)
             self.ws.join_aux()
         dpre = self.decoder_dist.backward(g_rec)                            # ELBO branch on the main stream
         dz = self.decoder_net.backward(dpre, need_input_grad=True)
         if want_dz:
-            main.wait_event(dz_ready)
+            ops.wait_event(main, dz_ready)
             ops.axpy1(dz_pm, dz)
         denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
         self.encoder_net.backward(denc, need_input_grad=False)
         self.ws.join_aux()
-        main.wait_stream(side)
+        ops.wait_stream(main, side)
 
     def zero_grad(self) -> None:
         ops.fill_zero(self.store.flat_g)

@@ -219,8 +219,8 @@ class PosteriorMatchingDecoderBlock(Module):
         main = torch.cuda.current_stream(x_in.device)
         s1, s2 = streams if streams is not None else (main, main)
         if streams is not None:
-            s1.wait_stream(main)
-            s2.wait_stream(main)
+            ops.wait_stream(s1, main)
+            ops.wait_stream(s2, main)
         with torch.cuda.stream(s1):
             am = self.buf("am", sh(2 * W))
             ops.gelu_fwd(x_in, macts, am)                  # stop_gradient(x): handled in backward (:536-538)
@@ -233,8 +233,8 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.gelu_fwd(x_in, acts, a)
         self._pp = self.posterior.forward(a)
         if streams is not None:
-            main.wait_stream(s1)
-            main.wait_stream(s2)
+            ops.wait_stream(main, s1)
+            ops.wait_stream(main, s2)
         x1 = self.buf("x1", sh(W))
         ops.add_cols(x_in, self._pr, 2 * Z, x1)              # x += h (:558)
         self._z = self.buf("z", sh(Z))
@@ -290,8 +290,8 @@ class PosteriorMatchingDecoderBlock(Module):
         dmp = self.buf("dmp", tuple(self._mp.shape))
         ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, P)
         if streams is not None:
-            s1.wait_stream(main)
-            s2.wait_stream(main)
+            ops.wait_stream(s1, main)
+            ops.wait_stream(s2, main)
         with torch.cuda.stream(s1):
             da = self.buf("da", sh(2 * W))
             self.posterior.backward(dpp, da)
@@ -302,7 +302,7 @@ class PosteriorMatchingDecoderBlock(Module):
         dxin = self.buf("dxin", sh(W))
         self.prior.backward(dpr, dxin, x_pre=self._x_in, res=dx2)               # + the direct x1 = x_in + h path
         if streams is not None:
-            main.wait_stream(s1)
+            ops.wait_stream(main, s1)
         ops.gelu_bwd(self._x_in, self._acts, da, dxin, dacts, accumulate=True)
         return dxin
 
@@ -394,11 +394,11 @@ class PosteriorMatchingVDVAE(Module):
         streams = self._branch_streams(x.device)
         main = torch.cuda.current_stream(x.device)
         if streams is not None:
-            streams[0].wait_stream(main)
+            ops.wait_stream(streams[0], main)
             with torch.cuda.stream(streams[0]):
                 macts = self.masked_encoder(xob)
             acts = self.encoder(xn)
-            main.wait_stream(streams[0])
+            ops.wait_stream(main, streams[0])
         else:
             acts = self.encoder(xn)
             macts = self.masked_encoder(xob)
@@ -531,13 +531,13 @@ class PosteriorMatchingVDVAE(Module):
                 dxs[r] = dxin
         if streams is not None:
             s1, s2 = streams
-            s1.wait_stream(s2)                       # dmacts were accumulated on s2
-            s1.wait_stream(main)
+            ops.wait_stream(s1, s2)                       # dmacts were accumulated on s2
+            ops.wait_stream(s1, main)
             with torch.cuda.stream(s1):
                 self.masked_encoder.backward(dmacts)
             self.encoder.backward(dacts)
-            main.wait_stream(s1)
-            main.wait_stream(s2)
+            ops.wait_stream(main, s1)
+            ops.wait_stream(main, s2)
         else:
             self.encoder.backward(dacts)
             self.masked_encoder.backward(dmacts)

@@ -310,8 +310,8 @@ class VectorQuantizerEMA(Module):
             if self.cross_replica_axis is not None:
                 from ..parallel import allreduce_sum_
 
-                allreduce_sum_(counts)           # jax.lax.psum over the pmap axis
-                allreduce_sum_(dw)
+                ops.host_call(allreduce_sum_, counts)           # jax.lax.psum over the pmap axis
+                ops.host_call(allreduce_sum_, dw)
             ops.vq_ema_update(counts, dw, st["ema_cluster_size/hidden"], st["ema_cluster_size/average"],
                               st["ema_dw/hidden"], st["ema_dw/average"], st["embeddings"], st["counter"],
                               self.decay, self.epsilon)

@@ -63,11 +63,78 @@ def set_timer(t: Optional[KernelTimer]) -> None:
     _timer = t
 
 
+# ---- launch plans: the host side of a training step recorded once, replayed without the Python model code ------
+_recording: Optional[list] = None
+
+
+class LaunchPlan:
+    """The C-ABI calls (bound function + final argument tuple, stream handle included) and the cross-stream
+    synchronisation calls of one step, in issue order.  Every buffer of a step is static, so replaying the list
+    reproduces the step; it keeps the multi-stream overlap that a captured HIP graph loses on ROCm 7.2 and costs
+    ~2 us of host time per launch instead of ~11 us through the model classes."""
+
+    def __init__(self, calls):
+        self.calls = calls
+
+    def __len__(self):
+        return len(self.calls)
+
+    def replay(self) -> None:
+        for fn, args, name in self.calls:
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc, name)
+
+
+def begin_recording() -> None:
+    global _recording
+    if _timer is not None:
+        raise RuntimeError("cannot record a launch plan while a KernelTimer is active")
+    _recording = []
+
+
+def end_recording() -> LaunchPlan:
+    global _recording
+    plan, _recording = LaunchPlan(_recording or []), None
+    return plan
+
+
+def wait_stream(waiter, other) -> None:
+    """waiter.wait_stream(other), recorded into the active launch plan"""
+    if waiter is other or waiter == other:
+        return
+    waiter.wait_stream(other)
+    if _recording is not None:
+        _recording.append((waiter.wait_stream, (other,), "wait_stream"))
+
+
+def record_event(event, stream) -> None:
+    event.record(stream)
+    if _recording is not None:
+        _recording.append((event.record, (stream,), "event.record"))
+
+
+def wait_event(stream, event) -> None:
+    stream.wait_event(event)
+    if _recording is not None:
+        _recording.append((stream.wait_event, (event,), "wait_event"))
+
+
+def host_call(fn, *args) -> None:
+    """a host-side call that belongs to the step (the gradient all-reduce), recorded into the active plan"""
+    fn(*args)
+    if _recording is not None:
+        _recording.append((fn, args, getattr(fn, "__name__", "host_call")))
+
+
 def _call(fname: str, *args, tag: Optional[str] = None, work: Optional[dict] = None) -> None:
     lib = _lib.load()
     fn = getattr(lib, fname)
     if _timer is None:
-        _lib.check(fn(_stream(), *args), fname)
+        full = (_stream(),) + args
+        _lib.check(fn(*full), fname)
+        if _recording is not None:
+            _recording.append((fn, full, fname))
         return
     e0, e1 = Event(), Event()
     e0.record()
