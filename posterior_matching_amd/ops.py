@@ -82,7 +82,7 @@ class LaunchPlan:
     def replay(self) -> None:
         for fn, args, name in self.calls:
             rc = fn(*args)
-            if rc:
+            if type(rc) is int and rc:          # C-ABI status; stream / collective calls return None or a tensor
                 _lib.check(rc, name)
 
 
