@@ -21,6 +21,7 @@
 // loaders are written to cost a few VALU instructions per row (tap decode and weight base are
 // wave-uniform scalars, per-row state is precomputed), otherwise address arithmetic - not the
 // matrix pipe - bounds the kernel.
+#include <cstdlib>
 #include <type_traits>
 #include "pm_common.h"
 
@@ -1104,6 +1105,232 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
     }
 }
 
+// ----------------------- stride-1 convolutions, patch-staged form (bf16x3) -----------------------
+// The direct form above re-reads every input element once per tap from L2 (25x for a 5x5 kernel: the
+// measured limiter, FETCH_SIZE 1.6x the algorithmic bytes and 40 % of the kernel time in the gather).
+// For a = d = 1 problems (stride-1 conv / transposed conv, forward and data-gradient) a workgroup owns a
+// TH x TW tile of ONE image: the (TH+KH-1) x (TW+KW-1) x C input patch is loaded ONCE, split into hi / lo
+// bf16 planes ONCE (zero outside the image), and every tap's MFMA A fragment is a shifted 16-byte LDS
+// read; the k-loop has no global loads of the gathered operand, no bounds checks and no conversions.
+// Weights: the same pre-split K-contiguous copy and double-buffered LDS stages as the direct form.
+constexpr int PDGS = 2;   // k-steps per weight stage of the patch form: LDS is what limits its workgroups per CU
+
+template <int RN>
+__global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
+                                                              long long plane, int tw_log2) {
+    constexpr int NB = 32 * RN;
+    constexpr int STEP_E = 2 * NB * BROW;
+    constexpr int BTILE = PDGS * STEP_E;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    __bf16* Bs = reinterpret_cast<__bf16*>(dsm);                        // 2 stages = BTILE floats
+    KStepB* kd = reinterpret_cast<KStepB*>(dsm + BTILE);
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int n0 = blockIdx.y * NB;
+    const int TW = 1 << tw_log2, TH = 128 >> tw_log2;
+    const int PH = TH + g.KH - 1, PW = TW + g.KW - 1;
+    const int PS = g.C + 8;                                             // bf16 per patch position (16 B pad)
+    const int cch = g.C / BK;
+    const int nsteps = g.KH * g.KW * cch;
+    __bf16* Ph = reinterpret_cast<__bf16*>(dsm + BTILE) + (size_t)(nsteps + PDGS) * (sizeof(KStepB) / 2);
+    __bf16* Pl = Ph + (size_t)PH * PW * PS;
+
+    const int tiles_x = (g.OW + TW - 1) >> tw_log2;
+    const int tiles_y = (g.OH + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = tyi * TH, x0 = txi << tw_log2;
+    // source coordinate of patch position (0,0); patch row of tap ky = ky (cs > 0) or KH-1-ky (cs < 0)
+    const int sy0 = y0 + g.off + (g.cs < 0 ? -(g.KH - 1) : 0);
+    const int sx0 = x0 + g.offx + (g.cs < 0 ? -(g.KW - 1) : 0);
+
+    for (int s = tid; s < nsteps + PDGS; s += 256) {
+        KStepB k{0, 0, 0, 0};
+        if (s < nsteps) {
+            const int tap = s / cch, cc = s - tap * cch;
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            k.dy = g.cs > 0 ? ky : g.KH - 1 - ky;
+            k.dx = g.cs > 0 ? kx : g.KW - 1 - kx;
+            k.c0 = cc * BK;
+            k.woff = (tap * cch + cc) * npad * BK;
+        }
+        kd[s] = k;
+    }
+    {   // the patch: f32 -> hi / lo bf16, zero outside the image.  Loads are issued in batches of 8 per thread so
+        // that a workgroup pays ~2 global latencies for its patch instead of one per 16 bytes
+        const float* img = p.in + (size_t)b * g.IH * g.IW * g.C;
+        const int c4n = g.C >> 2;
+        const int total = PH * PW * c4n;
+        constexpr int PB = 8;
+        for (int e0 = tid; e0 < total; e0 += 256 * PB) {
+            f32x4 v[PB];
+            int dst[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int e = e0 + 256 * j;
+                const int ee = e < total ? e : total - 1;
+                const int pos = ee / c4n, c4 = ee - pos * c4n;
+                const int py = pos / PW, px = pos - py * PW;
+                const int gy = sy0 + py, gx = sx0 + px;
+                const bool ok = e < total && (unsigned)gy < (unsigned)g.IH && (unsigned)gx < (unsigned)g.IW;
+                const size_t so = ok ? ((size_t)gy * g.IW + gx) * g.C + 4 * c4 : 0;
+                v[j] = *reinterpret_cast<const f32x4*>(img + so);
+                if (!ok) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dst[j] = e < total ? pos * PS + 4 * c4 : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                if (dst[j] < 0) continue;
+                u32x2 h2, l2;
+                split4(v[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + dst[j]) = h2;
+                *reinterpret_cast<u32x2*>(Pl + dst[j]) = l2;
+            }
+        }
+    }
+
+    // weight stages (identical to the direct form)
+    constexpr int PIECES = 2 * NB * 4;
+    constexpr int PPT = (PIECES + 255) / 256;
+    const __bf16* wg = wsplit;
+    u32x4 breg[PDGS][PPT];
+    auto load_b = [&](int s0) {
+#pragma unroll
+        for (int st = 0; st < PDGS; ++st) {
+            const int wo = kd[s0 + st].woff;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                const int nrow = n0 + row < npad ? n0 + row : 0;
+                breg[st][j] = *reinterpret_cast<const u32x4*>(wg + (size_t)pl * plane + wo + nrow * BK + qtr * 8);
+            }
+        }
+    };
+    auto store_b = [&](__bf16* dst) {
+#pragma unroll
+        for (int st = 0; st < PDGS; ++st)
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                *reinterpret_cast<u32x4*>(dst + st * STEP_E + (pl * NB + row) * BROW + qtr * 8) = breg[st][j];
+            }
+    };
+
+    // this lane's tile position and its A-fragment base inside the patch
+    const int ml = wave * 32 + i;
+    const int ty = ml >> tw_log2, tx = ml & (TW - 1);
+    const int abase = (ty * PW + tx) * PS + 8 * h;
+    const int gy = y0 + ty, gx = x0 + tx;
+    const int rowoff = (gy < g.OH && gx < g.OW) ? ((b * g.OH + gy) * g.OW + gx) * g.N : -1;
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    __syncthreads();                 // kd table visible
+    load_b(0);
+    store_b(Bs);
+    __syncthreads();                 // patch + first weight stage visible
+
+    bf16x8 ah[2][2], al[2][2];       // [register set][k16 half]
+    auto read_a = [&](int s, int set) {
+        const KStepB k = kd[s];
+        const int o = abase + (k.dy * PW + k.dx) * PS + k.c0;
+        ah[set][0] = *reinterpret_cast<const bf16x8*>(Ph + o);
+        ah[set][1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
+        al[set][0] = *reinterpret_cast<const bf16x8*>(Pl + o);
+        al[set][1] = *reinterpret_cast<const bf16x8*>(Pl + o + 16);
+    };
+    auto mma = [&](const __bf16* bstep, int set) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                const __bf16* brow = bstep + (r * 32 + i) * BROW + 16 * kk + 8 * h;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(brow);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(brow + NB * BROW);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][kk], bh, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][kk], bl, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][kk], bh, acc[r], 0, 0, 0);
+            }
+    };
+
+    read_a(0, 0);
+    int stage = 0;
+    for (int s0 = 0; s0 < nsteps; s0 += PDGS) {
+        const __bf16* bcur = Bs + stage * BTILE;
+        const bool more = s0 + PDGS < nsteps;
+        if (more) load_b(s0 + PDGS);                    // in flight during the MFMAs below
+#pragma unroll
+        for (int st = 0; st < PDGS; ++st) {
+            if (s0 + st < nsteps) {
+                if (s0 + st + 1 < nsteps) read_a(s0 + st + 1, (st + 1) & 1);   // next step's fragments
+                mma(bcur + st * STEP_E, st & 1);
+            }
+        }
+        if (more) store_b(Bs + (stage ^ 1) * BTILE);
+        __syncthreads();
+        stage ^= 1;
+    }
+
+    const float* bias = p.bias;
+    const float* aux = p.aux;
+    const float* res = p.res;
+    float* out = p.out;
+    int ro[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ro[e] = __shfl(rowoff, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
+#pragma unroll
+    for (int r = 0; r < RN; ++r) {
+        int n = n0 + r * 32 + i;
+        if (n >= g.N) continue;
+        float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (ro[e] < 0) continue;
+            size_t o = (size_t)ro[e] + n;
+            out[o] = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
+        }
+    }
+}
+
+// host-side plan of the patch form: tile shape and dynamic LDS size; returns false when the problem does not qualify
+struct PatchPlan { int tw_log2; size_t lds; dim3 grid; };
+bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
+    if (groups != 1 || g.a != 1 || g.d != 1 || g.C % BK != 0 || g.in_act != PM_ACT_NONE) return false;
+    if (g.KH * g.KW < 4 || g.OW < 12 || g.OH < 4) return false;        // 1x1 / tiny grids: the direct form is fine
+    pp.tw_log2 = g.OW > 16 ? 5 : 4;
+    const int TW = 1 << pp.tw_log2, TH = 128 >> pp.tw_log2;
+    const int tiles_x = (g.OW + TW - 1) / TW, tiles_y = (g.OH + TH - 1) / TH;
+    if ((long long)tiles_x * TW * tiles_y * TH * 2 > 3LL * g.OH * g.OW) return false;   // > 50 % padded slots
+    const int NB = 32 * rn;
+    const size_t bt = (size_t)PDGS * 2 * NB * BROW * 2 * 2;             // two stages, bytes
+    const int nsteps = g.KH * g.KW * (g.C / BK);
+    if (nsteps > 4096) return false;
+    const size_t kdb = (size_t)(nsteps + PDGS) * sizeof(KStepB);
+    const size_t patch = (size_t)(TH + g.KH - 1) * (TW + g.KW - 1) * (g.C + 8) * 2 * 2;
+    pp.lds = bt + kdb + patch;
+    if (pp.lds > 150 * 1024) return false;
+    pp.grid = dim3((unsigned)(g.B * tiles_y * tiles_x), (g.N + NB - 1) / NB, 1);
+    return true;
+}
+
 template <int RN, int DD>
 void launch_direct_bf16(hipStream_t s, const GemmArgs& a, dim3 grid, const __bf16* ws, int npad, long long plane) {
     const Geom& g = a.g;
@@ -1833,16 +2060,32 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     hipStream_t s = (hipStream_t)stream;
     const int G = d->groups;
+    const int npad = (a.g.N + 31) / 32 * 32;
+    const long long plane = (long long)a.g.KH * a.g.KW * ((a.g.C + BK - 1) / BK) * BK * npad;
+    const int rn = a.g.N > 32 ? 2 : 1;
+    const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
+    PatchPlan pp;
+    static const bool patch_off = getenv("PM_NO_PATCH") != nullptr;      // A/B switch for measurements
+    if (!patch_off && plan_patch(a.g, G, rn, pp)) {   // stride-1 convs on grids >= 12 wide: patch-staged form
+        a.ksplit = 1;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_bf16_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_bf16_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        if (rn == 1) hipLaunchKernelGGL(patch_conv_bf16_kernel<1>, pp.grid, dim3(256), pp.lds, s, a, ws, npad, plane, pp.tw_log2);
+        else hipLaunchKernelGGL(patch_conv_bf16_kernel<2>, pp.grid, dim3(256), pp.lds, s, a, ws, npad, plane, pp.tw_log2);
+        return pm_check_launch("pm_gather_gemm_bf16(patch)");
+    }
     const GemmPlan p = plan_gemm(a.g, G, true);
     a.ksplit = p.ksplit;
     if (p.ksplit > 1) {
         if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
     }
-    const int npad = (a.g.N + 31) / 32 * 32;
-    const long long plane = (long long)a.g.KH * a.g.KW * ((a.g.C + BK - 1) / BK) * BK * npad;
-    const int rn = a.g.N > 32 ? 2 : 1;
     dim3 grid((a.g.M + 127) / 128, (a.g.N + 32 * rn - 1) / (32 * rn), G * a.ksplit);
-    const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
     if (rn == 1 && d->d == 1) launch_direct_bf16<1, 1>(s, a, grid, ws, npad, plane);
     else if (rn == 1) launch_direct_bf16<1, 2>(s, a, grid, ws, npad, plane);
     else if (d->d == 1) launch_direct_bf16<2, 1>(s, a, grid, ws, npad, plane);

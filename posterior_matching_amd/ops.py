@@ -327,12 +327,30 @@ def bf16_supported(desc: GatherDesc) -> bool:
     return desc.C % 8 == 0 and desc.d in (1, 2) and desc.KH * desc.KW * ((desc.C + 31) // 32) <= 256
 
 
+def _patch_form(d: GatherDesc) -> bool:
+    """mirrors plan_patch (csrc/pm_conv.hip): stride-1 problems on grids >= 12 wide run the patch-staged kernel"""
+    if d.groups != 1 or d.a != 1 or d.d != 1 or d.C % 32 != 0 or d.in_act != ACT_NONE:
+        return False
+    if d.KH * d.KW < 4 or d.OW < 12 or d.OH < 4:
+        return False
+    tw = 32 if d.OW > 16 else 16
+    th = 128 // tw
+    tiles = -(-d.OW // tw) * tw * -(-d.OH // th) * th
+    if tiles * 2 > 3 * d.OH * d.OW:
+        return False
+    nb = 64 if d.N > 32 else 32
+    lds = 2 * 2 * nb * 40 * 2 * 2 + (d.KH * d.KW * (d.C // 32) + 2) * 16 + (th + d.KH - 1) * (tw + d.KW - 1) * (d.C + 8) * 4
+    return lds <= 150 * 1024
+
+
 def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None:
     tag = work = None
     if _timer is not None:
         dense = desc.KH == desc.KW == desc.IH == desc.IW == desc.OH == desc.OW == 1 and desc.d == 1
         tag = (f"direct_gemm_bf16_kernel<{2 if desc.N > 32 else 1}, {desc.d}, {desc.in_act}, "
                f"{'true' if dense else 'false'}>")   # template args
+        if _patch_form(desc):
+            tag = f"patch_conv_bf16_kernel<{2 if desc.N > 32 else 1}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
     _call("pm_gather_gemm_bf16", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
           _ptr(out), tag=tag, work=work)

@@ -50,6 +50,9 @@ CONV_CASES = [
     # VDVAE bottleneck layers (reference vdvae.py:282-292 at width 192, bottleneck 48): C % 32 != 0 on the bf16 path
     ("conv", 4, 14, 48, 48, 3, 1, "SAME"), ("conv", 4, 7, 48, 192, 1, 1, "SAME"), ("conv", 4, 7, 192, 48, 1, 1, "SAME"),
     ("conv", 3, 3, 48, 152, 1, 1, "SAME"), ("conv", 2, 28, 48, 224, 1, 1, "SAME"), ("dense", 70, 1, 24, 40, 1, 1, "VALID"),
+    # stride-1 layers on grids >= 12 wide: the patch-staged bf16x3 form (tiles 4x32 / 8x16, ragged edges, 3x3 / 5x5 / 7x7)
+    ("convT", 2, 28, 32, 32, 5, 1, "SAME"), ("conv", 3, 28, 32, 32, 3, 1, "SAME"), ("conv", 2, 13, 32, 32, 5, 1, "SAME"),
+    ("conv", 2, 30, 64, 64, 3, 1, "SAME"), ("conv", 1, 17, 96, 40, 7, 1, "SAME"), ("convT", 3, 12, 64, 96, 3, 1, "SAME"),
 ]
 
 
