@@ -149,8 +149,17 @@ def main():
         achieved = flops_per_launch / avg_s / 1e12
         is_bf16 = "bf16" in name
         peak = BF16_MFMA_PEAK_TFLOPS if is_bf16 else F32_MFMA_PEAK_TFLOPS
+        # HBM-side bytes per launch of this kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, with the
+        # gfx950 2x correction for wide loads) of the same command, committed under profiles/ (counters cannot be read
+        # from inside the process)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")) as fp:
+                traffic = json.load(fp).get(name, {}).get("traffic_bytes")
+        except OSError:
+            pass
         roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "note": ("achieved = ALGORITHMIC (float32-equivalent) flops / time; this kernel issues 3 bf16 MFMA "
                              "products per algorithmic MAC (bf16x3 split), so the matrix pipe runs at 3x this rate; "
                              "against the f32 MFMA peak of 157.3 TFLOP/s the fraction is "
@@ -158,7 +167,9 @@ def main():
                             "f32 MFMA (v_mfma_f32_32x32x2_f32) runs on the VALU pipeline on gfx950",
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": r["calls"] // args.profile_steps,
                     "share_of_kernel_time": round(r["ms"] / total_ms, 3),
-                    "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3)}
+                    "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                    "algorithmic_bytes_per_launch": round(r["bytes"] / r["calls"]),
+                    "traffic_source": "profiles/r01_final_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch)"}
         if os.environ.get("PM_BENCH_KERNEL_TABLE"):
             rows = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
             with open(os.environ["PM_BENCH_KERNEL_TABLE"], "w") as fp:
