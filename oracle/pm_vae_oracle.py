@@ -238,6 +238,12 @@ def tril_gaussian_params(p: Params, prefix: str, feats: Tensor, event_size: int)
     return prm[:, :event_size], fill_scale_tril(prm[:, event_size:])
 
 
+def diagonal_gaussian_params(p: Params, prefix: str, feats: Tensor, event_size: int) -> Tuple[Tensor, Tensor]:
+    """DiagonalGaussian.__call__ (distributions.py:73-84): Flatten -> Linear(2k); loc, scale = softplus(raw) + 1e-5."""
+    prm = linear(feats.reshape(feats.shape[0], -1), p[f"{prefix}/linear/w"], p[f"{prefix}/linear/b"])
+    return prm[:, :event_size], softplus(prm[:, event_size:]) + 1e-5
+
+
 def gmm_log_prob_columns(head: Tensor, value: Tensor, event_size: int, num_components: int) -> Tensor:
     """OneDimensionalGMM (distributions.py:124-134) + MixtureSameFamily.log_prob -> [B, event]."""
     prm = head.reshape(head.shape[0], event_size, 3 * num_components)
@@ -315,10 +321,14 @@ def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor
     post_kind = model_cfg["posterior_dist"]
     ppost_kind = model_cfg.get("partial_posterior_dist", post_kind)
     ppost_cfg = dict(model_cfg.get("partial_posterior_dist_config", model_cfg.get("posterior_dist_config", {})) or {})
-    assert post_kind == "TriLGaussian", "only the posterior head the hot-path configs use"
-
     feats = _net(p, enc_kind, enc_cfg, "encoder_net", x)
-    loc, tril = tril_gaussian_params(p, "posterior_dist", feats, k)
+    if post_kind == "TriLGaussian":
+        loc, tril = tril_gaussian_params(p, "posterior_dist", feats, k)
+    elif post_kind == "DiagonalGaussian":                                 # distributions.py:58-84: MultivariateNormalDiag
+        loc, scale = diagonal_gaussian_params(p, "posterior_dist", feats, k)
+        tril = torch.diag_embed(scale)
+    else:
+        raise KeyError(post_kind)
     z = loc + torch.einsum("bij,bj->bi", tril, eps)                       # vae.py:124
 
     dec = _net(p, dec_kind, dec_cfg, "decoder_net", z)
@@ -345,6 +355,9 @@ def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor
     elif ppost_kind == "TriLGaussian":
         ploc, ptril = tril_gaussian_params(p, "partial_posterior_dist", pfeats, k)
         mll = mvn_tril_log_prob(zm, ploc, ptril)
+    elif ppost_kind == "DiagonalGaussian":
+        ploc, pscale = diagonal_gaussian_params(p, "partial_posterior_dist", pfeats, k)
+        mll = mvn_tril_log_prob(zm, ploc, torch.diag_embed(pscale))
     else:
         raise KeyError(ppost_kind)
     return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll, "z": z}
@@ -481,6 +494,8 @@ def param_shapes(model_cfg: dict, x_shape: Sequence[int]) -> Dict[str, Tuple[int
         fin = int(math.prod(feat_shape))
         if kind == "TriLGaussian":
             add_linear(f"{prefix}/linear", fin, k + k * (k + 1) // 2)
+        elif kind == "DiagonalGaussian":
+            add_linear(f"{prefix}/linear", fin, 2 * k)
         elif kind == "AutoregressiveGMM":
             hu = cfg.get("hidden_units", 256)
             add_net("ResidualMLP", {"hidden_units": hu, "residual_blocks": cfg.get("residual_blocks", 2)},

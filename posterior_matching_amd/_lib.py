@@ -88,6 +88,10 @@ SIGNATURES = {
     "pm_tril_sample_kl_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
     "pm_tril_logprob_fwd": [_P, _P, _P, _P, _I, _I],
     "pm_tril_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
+    "pm_diag_gaussian_sample_kl_fwd": [_P, _P, _P, _P, _P, _I, _I],
+    "pm_diag_gaussian_sample_kl_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
+    "pm_diag_gaussian_logprob_fwd": [_P, _P, _P, _P, _I, _I],
+    "pm_diag_gaussian_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
     "pm_bernoulli_ll_fwd": [_P, _P, _P, _P, _I, _I],
     "pm_bernoulli_ll_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F],
     "pm_normal_ll_fwd": [_P, _P, _P, _P, _P, _I, _I, _F],

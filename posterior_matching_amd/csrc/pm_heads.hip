@@ -237,6 +237,56 @@ __global__ __launch_bounds__(256) void normal_ll_bwd_kernel(const float* __restr
     if (threadIdx.x == 0) atomicAdd(d_log_scale, s * e * inv);  // d sigma / d log_scale = exp(log_scale)
 }
 
+// DiagonalGaussian head (reference distributions.py:58-84): params [B, 2k] = (loc | raw), scale = softplus(raw) + 1e-5.
+// One wave per example.  MODE 0: z = loc + scale*eps, out[b] = KL(N(loc, scale) || N(0, I));  MODE 1: out[b] = log N(z; loc, scale).
+template <int MODE>
+__global__ __launch_bounds__(256) void diag_gaussian_fwd_kernel(const float* __restrict__ params,
+                                                                 const float* __restrict__ ez, float* __restrict__ z,
+                                                                 float* __restrict__ out, int B, int k) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float part = 0.f;
+    for (int j = lane; j < k; j += 64) {
+        const float mu = params[(size_t)b * 2 * k + j];
+        const float sc = pm_softplus(params[(size_t)b * 2 * k + k + j]) + kDiagShift;
+        const float e = ez[(size_t)b * k + j];
+        if (MODE == 0) {
+            z[(size_t)b * k + j] = mu + sc * e;
+            part += -logf(sc) + 0.5f * (sc * sc + mu * mu - 1.f);
+        } else {
+            const float u = (e - mu) / sc;
+            part += -0.5f * u * u - logf(sc) - 0.5f * kLog2Pi;
+        }
+    }
+    part = pm_wave_sum(part);
+    if (lane == 0) out[b] = part;
+}
+
+// MODE 0: dparams from dz [B,k] and g (d loss / d kl[b]);  MODE 1: dparams and dz (may be NULL) from g (d loss / d lp[b]).
+template <int MODE>
+__global__ __launch_bounds__(256) void diag_gaussian_bwd_kernel(const float* __restrict__ params,
+                                                                 const float* __restrict__ ez, const float* __restrict__ dz,
+                                                                 const float* __restrict__ g, float* __restrict__ dparams,
+                                                                 float* __restrict__ dzo, long long total, int k) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / k;
+    const int j = (int)(i - b * k);
+    const float mu = params[b * 2 * k + j], raw = params[b * 2 * k + k + j];
+    const float sc = pm_softplus(raw) + kDiagShift, e = ez[i], gb = g[b];
+    if (MODE == 0) {
+        const float gz = dz[i];
+        dparams[b * 2 * k + j] = gz + gb * mu;
+        dparams[b * 2 * k + k + j] = (gz * e + gb * (sc - 1.f / sc)) * pm_sigmoid(raw);
+    } else {
+        const float u = (e - mu) / sc;
+        dparams[b * 2 * k + j] = gb * u / sc;
+        dparams[b * 2 * k + k + j] = gb * (u * u - 1.f) / sc * pm_sigmoid(raw);
+        if (dzo) dzo[i] = -gb * u / sc;
+    }
+}
+
 __global__ __launch_bounds__(256) void mask_concat_kernel(const float* __restrict__ x, const float* __restrict__ b,
                                                             float* __restrict__ out, long long R, int C, int Cb) {
     const int W = C + Cb;
@@ -476,4 +526,37 @@ extern "C" int pm_gmm_logprob_bwd(pm_stream_t stream, const float* head, const f
     hipLaunchKernelGGL(gmm_logprob_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, head, z, g, (float*)nullptr, dhead, dz, B, k, nc, accumulate_dz);
     return pm_check_launch("pm_gmm_logprob_bwd");
+}
+
+extern "C" int pm_diag_gaussian_sample_kl_fwd(pm_stream_t stream, const float* params, const float* eps, float* z,
+                                              float* kl, int B, int k) {
+    if (!params || !eps || !z || !kl || B <= 0 || k <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(diag_gaussian_fwd_kernel<0>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, eps, z, kl, B, k);
+    return pm_check_launch("pm_diag_gaussian_sample_kl_fwd");
+}
+
+extern "C" int pm_diag_gaussian_sample_kl_bwd(pm_stream_t stream, const float* params, const float* eps, const float* dz,
+                                              const float* g_kl, float* dparams, int B, int k) {
+    if (!params || !eps || !dz || !g_kl || !dparams || B <= 0 || k <= 0) return PM_EINVAL;
+    const long long total = (long long)B * k;
+    hipLaunchKernelGGL(diag_gaussian_bwd_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       params, eps, dz, g_kl, dparams, (float*)nullptr, total, k);
+    return pm_check_launch("pm_diag_gaussian_sample_kl_bwd");
+}
+
+extern "C" int pm_diag_gaussian_logprob_fwd(pm_stream_t stream, const float* params, const float* z, float* lp, int B,
+                                            int k) {
+    if (!params || !z || !lp || B <= 0 || k <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(diag_gaussian_fwd_kernel<1>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, z,
+                       (float*)nullptr, lp, B, k);
+    return pm_check_launch("pm_diag_gaussian_logprob_fwd");
+}
+
+extern "C" int pm_diag_gaussian_logprob_bwd(pm_stream_t stream, const float* params, const float* z, const float* g,
+                                            float* dparams, float* dz, int B, int k) {
+    if (!params || !z || !g || !dparams || B <= 0 || k <= 0) return PM_EINVAL;
+    const long long total = (long long)B * k;
+    hipLaunchKernelGGL(diag_gaussian_bwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       params, z, (const float*)nullptr, g, dparams, dz, total, k);
+    return pm_check_launch("pm_diag_gaussian_logprob_bwd");
 }

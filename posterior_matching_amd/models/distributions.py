@@ -141,13 +141,44 @@ class TriLGaussian(_LinearHead):
         return self._linear_bwd(dprm)
 
 
-class DiagonalGaussian(Module):
-    """reference distributions.py:58-84.  Registry entry only: no BASELINE config uses it
-    (VaDE / lookahead models, out of the hot-path scope)."""
+class DiagonalGaussian(_LinearHead):
+    """reference distributions.py:58-84: Linear(2k) -> loc, scale = softplus(raw) + 1e-5, MultivariateNormalDiag.
+    Usable as posterior_dist (sample + KL) and as partial_posterior_dist (log_prob), like TriLGaussian."""
 
     def __init__(self, event_size: int, w_init=None, b_init=None, name: Optional[str] = None):
         super().__init__(name)
-        raise NotImplementedError("DiagonalGaussian has no HIP path (not on the PM-VAE hot path, SURVEY 8a-10)")
+        if w_init is not None or b_init is not None:
+            raise NotImplementedError("custom initialisers")
+        self._event_size = event_size
+        self._num_params = 2 * event_size
+
+    def build(self, store, prefix, feat_shape):
+        self._build_linear(store, prefix, feat_shape, self._num_params)
+
+    def sample_and_kl(self, feat: Feat, eps: torch.Tensor):
+        prm = self._linear_fwd(feat)
+        B, k = eps.shape
+        self._prm, self._eps = prm, eps
+        z, kl = self.buf("z", (B, k)), self.buf("kl", (B,))
+        ops.diag_gaussian_sample_kl_fwd(prm, eps, z, kl)
+        return z, kl
+
+    def backward_sample_kl(self, dz: torch.Tensor, g_kl: torch.Tensor) -> torch.Tensor:
+        dprm = self.buf("dparams", self._prm.shape)
+        ops.diag_gaussian_sample_kl_bwd(self._prm, self._eps, dz, g_kl, dprm)
+        return self._linear_bwd(dprm)
+
+    def log_prob(self, feat: Feat, z: torch.Tensor) -> torch.Tensor:
+        prm = self._linear_fwd(feat)
+        self._prm, self._z = prm, z
+        lp = self.buf("lp", (z.shape[0],))
+        ops.diag_gaussian_logprob_fwd(prm, z, lp)
+        return lp
+
+    def backward_log_prob(self, g: torch.Tensor, dz: Optional[torch.Tensor]):
+        dprm = self.buf("dparams", self._prm.shape)
+        ops.diag_gaussian_logprob_bwd(self._prm, self._z, g, dprm, dz)
+        return self._linear_bwd(dprm)
 
 
 class AutoregressiveGMM(Module):

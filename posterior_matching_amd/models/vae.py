@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..ops import ACT_NONE
 from .core import Feat, Module, ParamStore, Workspace
-from .distributions import AutoregressiveGMM, TriLGaussian, get_distribution
+from .distributions import AutoregressiveGMM, DiagonalGaussian, TriLGaussian, get_distribution
 from .networks import get_network
 
 
@@ -33,10 +33,10 @@ class PosteriorMatchingVAE(Module):
         self._seed = seed
         self.concurrent = True   # run the ELBO and the posterior-matching chains on two HIP streams
         self.store: Optional[ParamStore] = None
-        if not isinstance(posterior_dist, TriLGaussian):
-            raise NotImplementedError("posterior_dist must be TriLGaussian (the only posterior head on the hot path)")
-        if not isinstance(partial_posterior_dist, (AutoregressiveGMM, TriLGaussian)):
-            raise NotImplementedError("partial_posterior_dist must be AutoregressiveGMM or TriLGaussian")
+        if not isinstance(posterior_dist, (TriLGaussian, DiagonalGaussian)):
+            raise NotImplementedError("posterior_dist must be TriLGaussian or DiagonalGaussian")
+        if not isinstance(partial_posterior_dist, (AutoregressiveGMM, TriLGaussian, DiagonalGaussian)):
+            raise NotImplementedError("partial_posterior_dist must be AutoregressiveGMM, TriLGaussian or DiagonalGaussian")
 
     @classmethod
     def from_config(cls, config: Mapping[str, Any], name: Optional[str] = None, device: Optional[str] = None,

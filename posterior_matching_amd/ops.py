@@ -482,6 +482,26 @@ def tril_logprob_bwd(params, z, g, dparams, dz) -> None:
     _call("pm_tril_logprob_bwd", _ptr(params), _ptr(z), _ptr(g), _ptr(dparams), _ptr(dz), B, k)
 
 
+def diag_gaussian_sample_kl_fwd(params, eps, z, kl) -> None:
+    B, k = eps.shape
+    _call("pm_diag_gaussian_sample_kl_fwd", _ptr(params), _ptr(eps), _ptr(z), _ptr(kl), B, k)
+
+
+def diag_gaussian_sample_kl_bwd(params, eps, dz, g_kl, dparams) -> None:
+    B, k = eps.shape
+    _call("pm_diag_gaussian_sample_kl_bwd", _ptr(params), _ptr(eps), _ptr(dz), _ptr(g_kl), _ptr(dparams), B, k)
+
+
+def diag_gaussian_logprob_fwd(params, z, lp) -> None:
+    B, k = z.shape
+    _call("pm_diag_gaussian_logprob_fwd", _ptr(params), _ptr(z), _ptr(lp), B, k)
+
+
+def diag_gaussian_logprob_bwd(params, z, g, dparams, dz) -> None:
+    B, k = z.shape
+    _call("pm_diag_gaussian_logprob_bwd", _ptr(params), _ptr(z), _ptr(g), _ptr(dparams), _ptr(dz), B, k)
+
+
 def bernoulli_ll_fwd(logits, x, ll) -> None:
     B = x.shape[0]
     _call("pm_bernoulli_ll_fwd", _ptr(logits), _ptr(x), _ptr(ll), B, x.numel() // B)

@@ -583,3 +583,58 @@ def test_masked_conv_fwd_dgrad_wgrad(B, H, ci, co, full, vr, vc, bf16x3):
     assert torch.equal(dwd.cpu()[vr:], torch.zeros_like(dwd.cpu()[vr:]))
     assert torch.equal(dwd.cpu()[:, vc:], torch.zeros_like(dwd.cpu()[:, vc:]))
     assert rel_err(dbd, br.grad) < 1e-5
+
+
+def test_diagonal_gaussian_heads_and_model():
+    """DiagonalGaussian (reference distributions.py:58-84) as posterior (sample + KL) and as partial posterior
+    (log_prob): kernels in isolation, then a whole PM-VAE (gas networks) with both heads diagonal."""
+    from posterior_matching_amd import ops
+    from posterior_matching_amd.engine import loss_cfg_from_config
+
+    gen = torch.Generator().manual_seed(8)
+    B, k = 37, 16
+    prm, eps, dz, g = g32((B, 2 * k), gen), g32((B, k), gen), g32((B, k), gen), g32((B,), gen)
+    pr = prm.clone().requires_grad_(True)
+    loc, sc = pr[:, :k], O.softplus(pr[:, k:]) + 1e-5
+    z = loc + sc * eps
+    kl = O.mvn_tril_kl_to_std_normal(loc, torch.diag_embed(sc))
+    ((z * dz).sum() + (kl * g).sum()).backward()
+    d = dev()
+    zd, kld, dp = torch.empty((B, k), device=d), torch.empty(B, device=d), torch.empty((B, 2 * k), device=d)
+    ops.diag_gaussian_sample_kl_fwd(prm.float().to(d), eps.float().to(d), zd, kld)
+    assert rel_err(zd, z) < 1e-6 and rel_err(kld, kl) < 2e-6
+    ops.diag_gaussian_sample_kl_bwd(prm.float().to(d), eps.float().to(d), dz.float().to(d), g.float().to(d), dp)
+    assert rel_err(dp, pr.grad) < 2e-6
+    zz = g32((B, k), gen)
+    pr2, zr = prm.clone().requires_grad_(True), zz.clone().requires_grad_(True)
+    lp = O.mvn_tril_log_prob(zr, pr2[:, :k], torch.diag_embed(O.softplus(pr2[:, k:]) + 1e-5))
+    (lp * g).sum().backward()
+    lpd, dzo = torch.empty(B, device=d), torch.empty((B, k), device=d)
+    ops.diag_gaussian_logprob_fwd(prm.float().to(d), zz.float().to(d), lpd)
+    assert rel_err(lpd, lp) < 2e-6
+    ops.diag_gaussian_logprob_bwd(prm.float().to(d), zz.float().to(d), g.float().to(d), dp, dzo)
+    assert rel_err(dp, pr2.grad) < 2e-6 and rel_err(dzo, zr.grad) < 2e-6
+
+    cfg = pm_vae_gas()
+    cfg["model"] = dict(cfg["model"], posterior_dist="DiagonalGaussian", partial_posterior_dist="DiagonalGaussian",
+                        matching_ll_stop_gradients=False)
+    rng = np.random.default_rng(3)
+    x, b = torch.tensor(rng.normal(size=(B, 8))), torch.tensor((rng.uniform(size=(B, 8)) < 0.5) * 1.0)
+    e = torch.tensor(rng.normal(size=(B, 16)))
+    m = _product_model(cfg, (8,), bf16x3=False)
+    p64 = {n: t.cpu().double() for n, t in m.params_dict().items()}
+    assert list(p64) == list(O.param_shapes(cfg["model"], (8,)))
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, aux, out = O.pm_vae_loss(leaves, cfg, x, b, e, 30000)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    got = m(x.float().to(d), b.float().to(d), is_training=True, eps=e.float().to(d))
+    for key in ("reconstruction_ll", "kl", "matching_ll"):
+        assert rel_err(got[key], out[key]) < 1e-5, key
+    step_dev, metrics = torch.tensor([30000], dtype=torch.int32, device=d), torch.zeros(8, device=d)
+    gs = [torch.empty(B, device=d) for _ in range(3)]
+    ops.pmvae_loss(got["reconstruction_ll"], got["kl"], got["matching_ll"], loss_cfg_from_config(cfg, B), step_dev, metrics, *gs)
+    m.zero_grad()
+    m.backward(*gs)
+    torch.cuda.synchronize()
+    for n, gt in m.grads_dict().items():
+        assert rel_err(gt, grads[n]) < 5e-5, n
