@@ -154,8 +154,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     const long long e0 = r0 * N, e1 = r1 * N;
-    // each thread walks a fixed column set when 256 % N == 0, so it can keep a private sum
-    if (256 % N == 0) {
+    if (N % 4 == 0 && (1024 % N == 0) && ((e0 & 3) == 0)) {
+        // 16-byte loads; a thread's four columns never change (1024 % N == 0), so it keeps private sums
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        long long q = (e0 >> 2) + threadIdx.x;
+        const long long q1 = e1 >> 2;
+        for (; q + 768 < q1; q += 1024) {                 // 4 independent loads in flight
+            const f32x4 a = x4[q], b = x4[q + 256], c = x4[q + 512], d = x4[q + 768];
+            acc += (a + b) + (c + d);
+        }
+        for (; q < q1; q += 256) acc += x4[q];
+        const int c0 = (int)(((e0 >> 2) + threadIdx.x) * 4 % N);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&sums[c0 + j], acc[j]);
+    } else if (256 % N == 0) {
         float acc = 0.f;
         for (long long e = e0 + threadIdx.x; e < e1; e += 256) acc += x[e];
         atomicAdd(&sums[(int)((e0 + threadIdx.x) % N)], acc);
@@ -373,6 +386,7 @@ extern "C" int pm_fill_zero(pm_stream_t stream, void* ptr, long long nbytes) {
 extern "C" int pm_colsum(pm_stream_t stream, const float* x, float* out, long long M, int N) {
     if (!x || !out || M <= 0 || N <= 0 || N > 8192) return PM_EINVAL;
     int rows = 256;
+    while (rows < 4096 && (M + rows - 1) / rows > 1024) rows *= 2;     // ~1000 workgroups, >= 32 KB each for large tensors
     long long blocks = (M + rows - 1) / rows;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream,
                        x, out, M, N, rows);
