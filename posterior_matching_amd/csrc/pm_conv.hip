@@ -1815,6 +1815,198 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
     }
 }
 
+// ----------------------- stride-1 weight gradients, patch-staged form (bf16x3) -----------------------
+// gather_wgrad_bf16_kernel gives every (tap x 32 channels) block its own workgroups: each of them re-gathers the
+// input rows and re-reads the dense operand (measured on the 28x28 5x5 layers: 212 MB of HBM-side traffic per
+// launch against 51 MB of operands).  Here a persistent workgroup walks 128-position tiles of the images; per tile
+// the input patch (with halo) and the dense tile are loaded ONCE, split to hi / lo bf16 planes in LDS, and every
+// tap's operand is a shifted transposed LDS read.  The 4 waves own disjoint tap subsets (accumulators for
+// TPW taps x 32 x 32*RN stay in registers across all tiles of the workgroup), so there is no cross-wave reduction;
+// one atomic flush per workgroup at the end.  Needs a = d = 1 and C == 32.
+template <int RN, int TPW>
+__global__ __launch_bounds__(256) void patch_wgrad_bf16_kernel(WgradArgs p, int tw_log2, int ntiles) {
+    constexpr int NB = 32 * RN;
+    constexpr int DS = NB + 8;                     // bf16 per dense-tile row (16 B pad)
+    constexpr int NPL = 10;                        // 16-byte patch loads per thread and tile (<= 2560 / 256)
+    constexpr int NDL = 4 * RN;                    // 16-byte dense-tile loads per thread and tile
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int TW = 1 << tw_log2, TH = 128 >> tw_log2;
+    const int PH = TH + g.KH - 1, PW = TW + g.KW - 1;
+    const int PS = g.C + 8;
+    short* Ph = reinterpret_cast<short*>(dsm);
+    short* Pl = Ph + PH * PW * PS;
+    short* Dh = Pl + PH * PW * PS;
+    short* Dl = Dh + 128 * DS;
+    const int tiles_x = (g.OW + TW - 1) >> tw_log2;
+    const int tiles_y = (g.OH + TH - 1) / TH;
+    const int ntaps = g.KH * g.KW;
+    const int c4n = g.C >> 2;
+    const int ptotal = PH * PW * c4n;
+
+    // this wave's taps: unit u = wave + 4 j  ->  patch offset of the tap
+    int toff[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tap = wave + 4 * j;
+        const int tt = tap < ntaps ? tap : 0;
+        const int ky = tt / g.KW, kx = tt - ky * g.KW;
+        const int pdy = g.cs > 0 ? ky : g.KH - 1 - ky, pdx = g.cs > 0 ? kx : g.KW - 1 - kx;
+        toff[j] = (pdy * PW + pdx) * PS;
+    }
+    // transposed-read lane geometry (see gather_wgrad_bf16_kernel)
+    const int gq = lane >> 4;
+    const int q = (lane & 15) >> 2;
+    const int pq = lane & 3;
+    const int tr_row = 8 * (gq >> 1) + q;
+    const int tr_col = 16 * (gq & 1) + 4 * pq;
+
+    f32x16 acc[TPW][RN];
+    f32x16 accb[RN];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][b][e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < RN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[b][e] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const bool do_bias = p.db != nullptr && wave == 0;
+
+    f32x4 pv[NPL], dv[NDL];
+    auto issue = [&](int tile) {                   // global loads of one tile into registers
+        int t = tile;
+        const int txi = t % tiles_x;
+        t /= tiles_x;
+        const int tyi = t % tiles_y;
+        const int b = t / tiles_y;
+        const int y0 = tyi * TH, x0 = txi << tw_log2;
+        const int sy0 = y0 + g.off + (g.cs < 0 ? -(g.KH - 1) : 0);
+        const int sx0 = x0 + g.offx + (g.cs < 0 ? -(g.KW - 1) : 0);
+        const float* img = p.gathered + (size_t)b * g.IH * g.IW * g.C;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int e = tid + 256 * j;
+            const int ee = e < ptotal ? e : ptotal - 1;
+            const int pos = ee / c4n, c4 = ee - pos * c4n;
+            const int py = pos / PW, px = pos - py * PW;
+            const int gy = sy0 + py, gx = sx0 + px;
+            const bool ok = e < ptotal && (unsigned)gy < (unsigned)g.IH && (unsigned)gx < (unsigned)g.IW;
+            const size_t so = ok ? ((size_t)gy * g.IW + gx) * g.C + 4 * c4 : 0;
+            pv[j] = *reinterpret_cast<const f32x4*>(img + so);
+            if (!ok) pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* dimg = p.dense + (size_t)b * g.OH * g.OW * g.N;
+#pragma unroll
+        for (int j = 0; j < NDL; ++j) {
+            const int e = tid + 256 * j;                      // (position, 4-column group) of the 128 x NB tile
+            const int pos = e / (NB / 4), n4 = e - pos * (NB / 4);
+            const int ty = pos >> tw_log2, tx = pos & (TW - 1);
+            const int gy = y0 + ty, gx = x0 + tx;
+            const bool ok = gy < g.OH && gx < g.OW && 4 * n4 < g.N;
+            const size_t so = ok ? ((size_t)gy * g.OW + gx) * g.N + 4 * n4 : 0;
+            dv[j] = *reinterpret_cast<const f32x4*>(dimg + so);
+            if (!ok) dv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&]() {                           // registers -> hi / lo bf16 planes in LDS
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int e = tid + 256 * j;
+            if (e < ptotal) {
+                const int pos = e / c4n, c4 = e - pos * c4n;
+                u32x2 h2, l2;
+                split4(pv[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + pos * PS + 4 * c4) = h2;
+                *reinterpret_cast<u32x2*>(Pl + pos * PS + 4 * c4) = l2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NDL; ++j) {
+            const int e = tid + 256 * j;
+            const int pos = e / (NB / 4), n4 = e - pos * (NB / 4);
+            u32x2 h2, l2;
+            split4(dv[j], h2, l2);
+            *reinterpret_cast<u32x2*>(Dh + pos * DS + 4 * n4) = h2;
+            *reinterpret_cast<u32x2*>(Dl + pos * DS + 4 * n4) = l2;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        stage();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);      // next tile's loads fly during the MFMAs
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {           // 16 consecutive positions of one tile row per k16 step
+            const int pos0 = 16 * ks;
+            const int ty = pos0 >> tw_log2, tx0 = pos0 & (TW - 1);
+            bf16x8 bh[RN], bl[RN];
+#pragma unroll
+            for (int b = 0; b < RN; ++b) {
+                bh[b] = tr_frag(Dh + (pos0 + tr_row) * DS + 32 * b + tr_col, DS);
+                bl[b] = tr_frag(Dl + (pos0 + tr_row) * DS + 32 * b + tr_col, DS);
+            }
+            const int abase = (ty * PW + tx0 + tr_row) * PS + tr_col;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const bf16x8 ah = tr_frag(Ph + abase + toff[j], PS);
+                const bf16x8 al = tr_frag(Pl + abase + toff[j], PS);
+#pragma unroll
+                for (int b = 0; b < RN; ++b) {
+                    acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[b], acc[j][b], 0, 0, 0);
+                    acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[b], acc[j][b], 0, 0, 0);
+                    acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[b], acc[j][b], 0, 0, 0);
+                }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int b = 0; b < RN; ++b) {
+                    accb[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bh[b], accb[b], 0, 0, 0);
+                    accb[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bl[b], accb[b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // flush: C/D layout row (= channel) = (e&3) + 8*(e>>2) + 4*h, column (= n) = lane & 31
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tap = wave + 4 * j;
+        if (tap >= ntaps) continue;
+        const int wtap = (tap / g.KW) * g.kws + tap % g.KW;
+#pragma unroll
+        for (int b = 0; b < RN; ++b) {
+            const int n = 32 * b + i;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
+                atomicAdd(p.dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[j][b][e]);
+            }
+        }
+    }
+    if (do_bias && h == 0) {
+#pragma unroll
+        for (int b = 0; b < RN; ++b) {
+            const int n = 32 * b + i;
+            if (n < g.N) atomicAdd(p.db + n, accb[b][0]);
+        }
+    }
+}
+
 bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     if (!d || d->B <= 0 || d->C <= 0 || d->N <= 0 || d->KH <= 0 || d->KW <= 0 || d->d <= 0 || d->groups <= 0)
         return false;
@@ -2116,6 +2308,47 @@ extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d,
     if (!aligned16(gathered) || !aligned16(dense) || d->in_gs % 4 != 0 || d->out_gs % 4 != 0) return PM_EINVAL;
     a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    {   // stride-1 problems with 32 gathered channels on grids >= 12 wide: patch-staged persistent form
+        static const bool patch_off = getenv("PM_NO_PATCH_WGRAD") != nullptr;
+        const Geom& g = a.g;
+        const int taps = g.KH * g.KW;
+        if (!patch_off && d->groups == 1 && g.a == 1 && g.d == 1 && g.C == 32 && g.in_act == PM_ACT_NONE && g.N <= 64 &&
+            g.N % 4 == 0 && (taps == 25 || taps == 9) && g.OW >= 12 && g.OH >= 4) {
+            const int tw_log2 = g.OW > 16 ? 5 : 4;
+            const int TW = 1 << tw_log2, TH = 128 >> tw_log2;
+            const int tiles_x = (g.OW + TW - 1) / TW, tiles_y = (g.OH + TH - 1) / TH;
+            const int rn = g.N > 32 ? 2 : 1;
+            const size_t patch = (size_t)(TH + g.KH - 1) * (TW + g.KW - 1) * (g.C + 8) * 2 * 2;
+            const size_t lds = patch + (size_t)128 * (32 * rn + 8) * 2 * 2;
+            const int ptotal = (TH + g.KH - 1) * (TW + g.KW - 1) * (g.C / 4);
+            if ((long long)tiles_x * TW * tiles_y * TH * 2 <= 3LL * g.OH * g.OW && lds <= 150 * 1024 && ptotal <= 2560) {
+                const int ntiles = g.B * tiles_y * tiles_x;
+                // persistent workgroups: each flushes taps x 32 x N accumulators with atomics at the end, so give
+                // every workgroup several tiles to amortise that (PM_PW_TILES: tiles per workgroup, for experiments)
+                // measured (B = 256): 28x28 layers 7-8 tiles per workgroup, 14x14 layers 4; more tiles per workgroup
+                // lengthen the serial tile loop faster than they shorten the flush
+                static const int tpw_env = getenv("PM_PW_TILES") ? atoi(getenv("PM_PW_TILES")) : 0;
+                const int tpw = tpw_env > 0 ? tpw_env : (ntiles >= 1024 ? 8 : 4);
+                int grid = (ntiles + tpw - 1) / tpw;
+                if (grid > 256) grid = 256;
+                if (grid < 1) grid = 1;
+                hipStream_t s = (hipStream_t)stream;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_wgrad_bf16_kernel<1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_wgrad_bf16_kernel<2, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_wgrad_bf16_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_wgrad_bf16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                    attr_set = true;
+                }
+                if (taps == 25 && rn == 1) hipLaunchKernelGGL((patch_wgrad_bf16_kernel<1, 7>), dim3(grid), dim3(256), lds, s, a, tw_log2, ntiles);
+                else if (taps == 25) hipLaunchKernelGGL((patch_wgrad_bf16_kernel<2, 7>), dim3(grid), dim3(256), lds, s, a, tw_log2, ntiles);
+                else if (rn == 1) hipLaunchKernelGGL((patch_wgrad_bf16_kernel<1, 3>), dim3(grid), dim3(256), lds, s, a, tw_log2, ntiles);
+                else hipLaunchKernelGGL((patch_wgrad_bf16_kernel<2, 3>), dim3(grid), dim3(256), lds, s, a, tw_log2, ntiles);
+                return pm_check_launch("pm_gather_wgrad_bf16(patch)");
+            }
+        }
+    }
     const WgradPlan p = plan_wgrad(a.g, d->groups, true, true);
     a.chunks_per_split = p.chunks_per_split;
     const int hw = a.g.OH * a.g.OW;

@@ -365,6 +365,8 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False) 
         tag = work = None
         if _timer is not None:
             tag = f"gather_wgrad_bf16_kernel<{2 if desc.C % 64 == 0 and desc.KH * desc.KW * desc.C >= 64 else 1}, {2 if desc.N > 32 else 1}, {desc.d}>"
+            if (_patch_form(desc) and desc.C == 32 and desc.N <= 64 and desc.KH * desc.KW in (9, 25)):
+                tag = f"patch_wgrad_bf16_kernel<{2 if desc.N > 32 else 1}, {7 if desc.KH * desc.KW == 25 else 3}>"
             work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
         _call("pm_gather_wgrad_bf16", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
         return
