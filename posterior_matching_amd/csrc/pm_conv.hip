@@ -1048,11 +1048,14 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
         }
     };
 
+    // A fragments run 3 k-steps ahead of the MFMAs in 4 register sets (set = step index % 4: the set a step
+    // prefetches into was consumed by the step before it)
     if (sb < se) {
         load_b(sb);
         store_b(Bs);
         issue_a(sb, std::integral_constant<int, 0>{});
         if (sb + 1 < se) issue_a(sb + 1, std::integral_constant<int, 1>{});
+        if (sb + 2 < se) issue_a(sb + 2, std::integral_constant<int, 2>{});
     }
     __syncthreads();
     int stage = 0;
@@ -1060,18 +1063,18 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
         const __bf16* bcur = Bs + stage * BTILE;
         const bool more = s0 + DGS < se;
         if (more) load_b(s0 + DGS);
-        if (s0 + 2 < se) issue_a(s0 + 2, std::integral_constant<int, 2>{});
+        if (s0 + 3 < se) issue_a(s0 + 3, std::integral_constant<int, 3>{});
         mma_step(bcur, std::integral_constant<int, 0>{});
         if (s0 + 1 < se) {
-            if (s0 + 3 < se) issue_a(s0 + 3, std::integral_constant<int, 3>{});
+            if (s0 + 4 < se) issue_a(s0 + 4, std::integral_constant<int, 0>{});
             mma_step(bcur + STEP_E, std::integral_constant<int, 1>{});
         }
         if (s0 + 2 < se) {
-            if (s0 + 4 < se) issue_a(s0 + 4, std::integral_constant<int, 0>{});
+            if (s0 + 5 < se) issue_a(s0 + 5, std::integral_constant<int, 1>{});
             mma_step(bcur + 2 * STEP_E, std::integral_constant<int, 2>{});
         }
         if (s0 + 3 < se) {
-            if (s0 + 5 < se) issue_a(s0 + 5, std::integral_constant<int, 1>{});
+            if (s0 + 6 < se) issue_a(s0 + 6, std::integral_constant<int, 2>{});
             mma_step(bcur + 3 * STEP_E, std::integral_constant<int, 3>{});
         }
         if (more) store_b(Bs + (stage ^ 1) * BTILE);

@@ -178,6 +178,7 @@ class Workspace:
         self._bufs: Dict[Tuple[str, Tuple[int, ...]], torch.Tensor] = {}
         self._aux_streams: Dict[int, "torch.cuda.Stream"] = {}
         self.overlap_wgrad = False   # measured on MI355X: 4 streams (3.23 ms/step) lose to 2 (2.93 ms/step)
+        self.wgrad_stream = None     # set by a model while a chain whose weight gradients should run elsewhere is issued
 
     def aux_stream(self) -> "torch.cuda.Stream":
         """A companion stream of the current stream for weight-gradient kernels.  The weight and
@@ -185,6 +186,8 @@ class Workspace:
         chain: the f32 MFMA of the weight-gradient kernels executes on the VALU pipeline while the
         bf16x3 data-gradient kernels occupy the matrix cores."""
         cur = torch.cuda.current_stream(self.device)
+        if self.wgrad_stream is not None:       # weight gradients of the current chain are lent to another chain's stream
+            return self.wgrad_stream
         if not self.overlap_wgrad:
             return cur
         aux = self._aux_streams.get(cur.cuda_stream)
@@ -234,7 +237,7 @@ class Module:
         cur = torch.cuda.current_stream(self.ws.device)
         aux = self.ws.aux_stream()
         kw.setdefault("bf16", self.store.use_bf16)
-        if aux is cur:
+        if aux is cur or aux == cur:
             ops.layer_wgrad(*args, **kw)
             return
         ops.wait_stream(aux, cur)

@@ -6,6 +6,7 @@ arithmetic runs in libpmhip.so.  JAX's functional autodiff is replaced by an exp
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, Mapping, Optional
 
 import torch
@@ -32,6 +33,7 @@ class PosteriorMatchingVAE(Module):
         self._device = device
         self._seed = seed
         self.concurrent = True   # run the ELBO and the posterior-matching chains on two HIP streams
+        self.lend_wgrad = ""     # "dec" / "all": weight gradients of the ELBO chain's decoder / decoder+encoder on the side stream
         self.store: Optional[ParamStore] = None
         if not isinstance(posterior_dist, (TriLGaussian, DiagonalGaussian)):
             raise NotImplementedError("posterior_dist must be TriLGaussian or DiagonalGaussian")
@@ -147,13 +149,22 @@ class PosteriorMatchingVAE(Module):
             ops.record_event(dz_ready, side)
             self.partial_encoder_net.backward(dpenc, need_input_grad=False)
             self.ws.join_aux()
-        dpre = self.decoder_dist.backward(g_rec)                            # ELBO branch on the main stream
+        # ELBO branch on the main stream.  It is the longer chain; its weight gradients only feed the optimizer, so
+        # (lend_wgrad) they are queued on the side stream behind the posterior-matching branch instead of sitting
+        # between the data-gradient kernels of the critical path.
+        lend = os.environ.get("PM_LEND_WGRAD", self.lend_wgrad) if self.concurrent else ""
+        dpre = self.decoder_dist.backward(g_rec)
+        if lend in ("dec", "all"):
+            self.ws.wgrad_stream = side
         dz = self.decoder_net.backward(dpre, need_input_grad=True)
+        if lend == "dec":
+            self.ws.wgrad_stream = None
         if want_dz:
             ops.wait_event(main, dz_ready)
             ops.axpy1(dz_pm, dz)
         denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
         self.encoder_net.backward(denc, need_input_grad=False)
+        self.ws.wgrad_stream = None
         self.ws.join_aux()
         ops.wait_stream(main, side)
 
