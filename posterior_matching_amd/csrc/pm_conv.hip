@@ -2140,7 +2140,7 @@ WgradPlan plan_wgrad(const Geom& g, int groups, bool vec4, bool dvec4) {
     // several 128-row chunks - its LDS reduction and atomics are a fixed cost per workgroup
     long long blocks = (long long)p.nkb * p.nnb * groups;
     int splits = (int)((1024 + blocks - 1) / blocks);
-    int max_splits = total_chunks / 4;
+    int max_splits = total_chunks / 4;      // measured flat optimum: 2..8 chunks per workgroup within 1 % (PM-VAE, PM-VQVAE)
     if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
