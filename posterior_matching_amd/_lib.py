@@ -82,6 +82,8 @@ SIGNATURES = {
     "pm_split_weights": [_P, _P, _P, _P, _I, _I],
     "pm_gather_wgrad_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
     "pm_thin_conv": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
+    "pm_thin_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P],
+    "pm_thin_to1_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
     "pm_tap_shift_add": [_P, C.POINTER(GatherDesc), _P, _I, _P, _P],
     "pm_mask_concat": [_P, _P, _P, _P, _LL, _I, _I],
     "pm_tril_sample_kl_fwd": [_P, _P, _P, _P, _P, _I, _I],

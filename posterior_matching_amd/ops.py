@@ -359,7 +359,17 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None
 USE_BF16_WGRAD = True   # weight gradients on the bf16 matrix cores when the shape qualifies
 
 
-def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False) -> None:
+def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, db_gathered=None) -> None:
+    """db_gathered: bias gradient taken over the GATHERED operand (transposed convs); only the thin lane form
+    fuses it - callers must check the return value (True = db_gathered was accumulated)."""
+    if _lane_form(desc):
+        tag = work = None
+        if _timer is not None:
+            tag = f"thin_wgrad_lane_kernel<{desc.C}, {desc.KH}, 32>"
+            work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
+        _call("pm_thin_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), _ptr(db_gathered),
+              tag=tag, work=work)
+        return True
     if (bf16 and USE_BF16_WGRAD and desc.C % 32 == 0 and desc.N % 4 == 0 and desc.d in (1, 2)
             and gathered.data_ptr() % 16 == 0 and dense.data_ptr() % 16 == 0):
         tag = work = None
@@ -380,14 +390,34 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False) 
     _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
 
+def _lane_form(d: GatherDesc) -> bool:
+    """csrc/pm_thin.hip lane_form_ok: stride-1 layers whose thin side has 1 or 2 channels"""
+    return (d.groups == 1 and d.d == 1 and d.a == 1 and d.KH == d.KW and d.KH in (3, 5) and d.C in (1, 2)
+            and d.N <= 32 and d.OW <= 128 and d.OH <= 128 and d.off_x == d.off and d.kws == d.KW)
+
+
+def _to1_form(d: GatherDesc) -> bool:
+    """wide -> 1 channel, stride 1 (thin_to1_kernel)"""
+    return (d.groups == 1 and d.d == 1 and d.a == 1 and d.N == 1 and d.C % 4 == 0 and d.OW <= 256
+            and d.off_x == d.off and d.kws == d.KW
+            and (d.KH * d.KW * d.C + d.KH * (d.OW + d.KW - 1) * (d.C + 4)) * 4 <= 64 * 1024)
+
+
 def _thin_ok(d: GatherDesc) -> bool:
+    if _lane_form(d) or _to1_form(d):
+        return True
     return (d.groups == 1 and d.d == 1 and d.KH * d.KW * d.C <= 64 and d.N <= 32 and d.N % 8 == 0
             and d.off_x == d.off and d.kws == d.KW)
 
 
 def thin_conv(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
-    work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
-    _call("pm_thin_conv", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), work=work)
+    tag = work = None
+    if _timer is not None:
+        tag = ("thin_to1_kernel" if _to1_form(desc) and inp.data_ptr() % 16 == 0 else
+               f"thin_conv_lane_kernel<{desc.C}, {desc.KH}>" if _lane_form(desc) else "thin_conv_kernel")
+        work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
+    _call("pm_thin_conv", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), tag=tag,
+          work=work)
 
 
 def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE, res=None, wsplit=None,
@@ -398,6 +428,15 @@ def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE,
     B = group_kw.pop("B", None) or x.shape[0]
     d = g._desc(B, "fwd", **group_kw)
     d.in_act, d.out_act = in_act, out_act
+    if (wsplit is not None and _to1_form(d) and d.C in (32, 64) and d.KH * d.KW <= 32 and x.data_ptr() % 16 == 0
+            and d.KH * d.IW * ((d.KH * d.KW) | 1) * 4 <= 64 * 1024):
+        work = {"flops": _algorithmic_flops(d), "bytes": _nbytes(x, res, out), "detail": _detail(d)}
+        _call("pm_thin_to1_bf16", C.byref(d), _ptr(x), _ptr(w), _ptr(b), None, _ptr(res), _ptr(out),
+              tag=f"thin_to1_bf16_kernel<{d.C // 32}>", work=work)
+        return
+    if _thin_ok(d):
+        thin_conv(d, x, w, b, None, res, out)
+        return
     if g.kind == "convT" and g.CO == 1 and g.s == 1 and tmp is not None and res is None and in_act == ACT_NONE:
         # out[p] = sum_tap (x[p + tap] . w[tap]):  T = x @ W' (one GEMM, N = taps) then a shifted sum
         taps = g.k * g.k
@@ -406,9 +445,6 @@ def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE,
         gather_gemm(dt, x, w, None, None, None, tmp)
         work = {"bytes": _nbytes(tmp, out), "detail": _detail(d)}
         _call("pm_tap_shift_add", C.byref(d), _ptr(tmp), taps, _ptr(b), _ptr(out), work=work)
-        return
-    if _thin_ok(d):
-        thin_conv(d, x, w, b, None, res, out)
         return
     if wsplit is not None and bf16_supported(d):
         if d.groups > 1:
@@ -450,8 +486,8 @@ def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, bf16: bool = True,
     if in_act != ACT_NONE:
         raise NotImplementedError("transposed-conv weight gradient with a pending input activation")
     d = g._desc(B, "dgrad", **group_kw)
-    gather_wgrad(d, dy, x, dw, None, bf16=bf16)
-    if db is not None:
+    fused = gather_wgrad(d, dy, x, dw, None, bf16=bf16, db_gathered=db)
+    if db is not None and not fused:
         colsum(dy, db)
 
 

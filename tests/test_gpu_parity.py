@@ -53,6 +53,11 @@ CONV_CASES = [
     # stride-1 layers on grids >= 12 wide: the patch-staged bf16x3 form (tiles 4x32 / 8x16, ragged edges, 3x3 / 5x5 / 7x7)
     ("convT", 2, 28, 32, 32, 5, 1, "SAME"), ("conv", 3, 28, 32, 32, 3, 1, "SAME"), ("conv", 2, 13, 32, 32, 5, 1, "SAME"),
     ("conv", 2, 30, 64, 64, 3, 1, "SAME"), ("conv", 1, 17, 96, 40, 7, 1, "SAME"), ("convT", 3, 12, 64, 96, 3, 1, "SAME"),
+    # thin layers, lane = channel / wide -> 1 forms (csrc/pm_thin.hip): 3x3 and 5x5, ragged widths, N < 32, more
+    # images than workgroups, both tap directions
+    ("conv", 3, 11, 2, 16, 3, 1, "SAME"), ("conv", 300, 14, 1, 24, 5, 1, "SAME"), ("convT", 2, 10, 8, 1, 3, 1, "SAME"),
+    ("conv", 2, 12, 16, 1, 5, 1, "SAME"), ("convT", 3, 9, 2, 20, 5, 1, "SAME"), ("conv", 2, 40, 1, 32, 3, 1, "SAME"),
+    ("convT", 2, 9, 64, 1, 3, 1, "SAME"), ("conv", 2, 12, 32, 1, 5, 1, "SAME"),   # wide -> 1 on the matrix cores
 ]
 
 
@@ -142,6 +147,39 @@ def test_epilogue_aux_res_inact():
 # ----------------------------------------------------------------------------------------------
 # heads
 # ----------------------------------------------------------------------------------------------
+def test_thin_forms_inact_aux_res():
+    """pending input activation, act'(aux) and residual on the thin kernels' lane / wide->1 forms, and the
+    input activation of the thin weight gradient."""
+    from posterior_matching_amd import ops
+    from posterior_matching_amd.ops import ACT_RELU, LayerGeom
+
+    gen = torch.Generator().manual_seed(5)
+    d = dev()
+    for ci, co, H in ((2, 32, 13), (32, 1, 13)):
+        B = 3
+        geom = LayerGeom.conv(H, H, ci, co, 5, 1, "SAME")
+        x, w, bias = g32((B, H, H, ci), gen), g32(geom.weight_shape, gen, 0.2), g32((co,), gen)
+        aux, res = g32((B, H, H, co), gen), g32((B, H, H, co), gen)
+        want = O.conv2d(O.relu(x), w, bias, 1, "SAME") * (aux > 0).double() + res
+        desc = geom._desc(B, "fwd")
+        desc.in_act, desc.aux_act = ACT_RELU, ACT_RELU
+        assert ops._thin_ok(desc)
+        out = torch.empty((B, H, H, co), device=d)
+        ops.thin_conv(desc, x.float().to(d), w.float().to(d), bias.float().to(d), aux.float().to(d),
+                      res.float().to(d), out)
+        assert rel_err(out, want) < 2e-6
+    # wgrad with relu pending on the gathered operand
+    B, H, ci, co = 4, 13, 2, 32
+    geom = LayerGeom.conv(H, H, ci, co, 5, 1, "SAME")
+    x, dy = g32((B, H, H, ci), gen), g32((B, H, H, co), gen)
+    wr = g32(geom.weight_shape, gen).requires_grad_(True)
+    O.conv2d(O.relu(x), wr, None, 1, "SAME").backward(dy)
+    dw, db = torch.zeros(geom.weight_shape, device=d), torch.zeros(co, device=d)
+    ops.layer_wgrad(geom, x.float().to(d), dy.float().to(d), dw, db, in_act=ACT_RELU)
+    assert rel_err(dw, wr.grad) < 2e-6
+    assert rel_err(db, dy.sum((0, 1, 2))) < 2e-6
+
+
 @pytest.mark.parametrize("B,k", [(5, 32), (7, 16), (256, 32)])
 def test_tril_sample_kl(B, k):
     from posterior_matching_amd import ops

@@ -25,7 +25,16 @@ CASES = [
     ("dec5 wgrad", LayerGeom.conv_t(28, 28, 32, 32, 5, 1, "SAME"), "wgrad"),
     ("enc3 wgrad", LayerGeom.conv(14, 14, 32, 64, 5, 1, "SAME"), "wgrad"),
     ("mlp wgrad 8192x256x256", LayerGeom.dense(256, 256), "wgrad8192"),
+    ("thin enc0 fwd 28x28 1->32 k5", LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME"), "fwd"),
+    ("thin penc0 fwd 28x28 2->32 k5", LayerGeom.conv(28, 28, 2, 32, 5, 1, "SAME"), "fwd"),
+    ("thin dec6 fwd 28x28 32->1 k5", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "fwd"),
+    ("thin dec6 dgrad 28x28 1->32 k5", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "dgrad"),
+    ("thin enc0 wgrad", LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME"), "wgrad"),
+    ("thin penc0 wgrad", LayerGeom.conv(28, 28, 2, 32, 5, 1, "SAME"), "wgrad"),
+    ("thin dec6 wgrad", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "wgrad"),
 ]
+if os.environ.get("PM_CASES"):
+    CASES = [c for c in CASES if os.environ["PM_CASES"] in c[0]]
 
 
 def main():
@@ -47,7 +56,12 @@ def main():
                 st.allocate(d)
                 st.load_dict({"w": w.cpu()})
                 ws = st.split_view(hf) if os.environ.get("PM_BF16", "1") == "1" else None
-                fn = lambda: ops.layer_forward(g, x, w, b, y, out_act=ACT_LEAKY, wsplit=ws)
+                tmp = torch.empty((B, g.IH, g.IW, g.k * g.k), device=d) if g.CO == 1 else None
+                fn = lambda: ops.layer_forward(g, x, w, b, y, out_act=ACT_LEAKY, wsplit=ws, tmp=tmp)
+            elif what == "dgrad":
+                y.normal_()
+                tmp = None
+                fn = lambda: ops.layer_dgrad(g, y, w, x)
             else:
                 y.normal_()
                 fn = lambda: ops.layer_wgrad(g, x, y, dw, db)
