@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark of single layers through the C ABI (HIP events, L2-warm, back-to-back).
     python tools/bench_layer.py [libpath]      # optional alternative libpmhip build (experiments)
+Times are host-side (events around 50 back-to-back launches): kernels under ~15 us read as the launch rate.
+PM_TIMER=1 prints device-side per-kernel averages instead (ops.KernelTimer).
 """
 import os
 import sys
@@ -25,6 +27,14 @@ CASES = [
     ("dec5 wgrad", LayerGeom.conv_t(28, 28, 32, 32, 5, 1, "SAME"), "wgrad"),
     ("enc3 wgrad", LayerGeom.conv(14, 14, 32, 64, 5, 1, "SAME"), "wgrad"),
     ("mlp wgrad 8192x256x256", LayerGeom.dense(256, 256), "wgrad8192"),
+    ("enc4 fwd 14->7 s2 64->64", LayerGeom.conv(14, 14, 64, 64, 5, 2, "SAME"), "fwd"),
+    ("enc2 wgrad 28->14 s2 32->32", LayerGeom.conv(28, 28, 32, 32, 5, 2, "SAME"), "wgrad"),
+    ("enc4 wgrad 14->7 s2 64->64", LayerGeom.conv(14, 14, 64, 64, 5, 2, "SAME"), "wgrad"),
+    ("enc4 dgrad 7->14 d2 64->64", LayerGeom.conv(14, 14, 64, 64, 5, 2, "SAME"), "dgrad"),
+    ("enc5 fwd 7x7x64->128 k7", LayerGeom.conv(7, 7, 64, 128, 7, 1, "VALID"), "fwd"),
+    ("enc5 dgrad", LayerGeom.conv(7, 7, 64, 128, 7, 1, "VALID"), "dgrad"),
+    ("enc5 wgrad", LayerGeom.conv(7, 7, 64, 128, 7, 1, "VALID"), "wgrad"),
+    ("mlp dgrad 8192x256x256", LayerGeom.dense(256, 256), "dgrad8192"),
     ("thin enc0 fwd 28x28 1->32 k5", LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME"), "fwd"),
     ("thin penc0 fwd 28x28 2->32 k5", LayerGeom.conv(28, 28, 2, 32, 5, 1, "SAME"), "fwd"),
     ("thin dec6 fwd 28x28 32->1 k5", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "fwd"),
@@ -34,7 +44,7 @@ CASES = [
     ("thin dec6 wgrad", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "wgrad"),
 ]
 if os.environ.get("PM_CASES"):
-    CASES = [c for c in CASES if os.environ["PM_CASES"] in c[0]]
+    CASES = [c for c in CASES if any(k in c[0] for k in os.environ["PM_CASES"].split(","))]
 
 
 def main():
@@ -58,10 +68,16 @@ def main():
                 ws = st.split_view(hf) if os.environ.get("PM_BF16", "1") == "1" else None
                 tmp = torch.empty((B, g.IH, g.IW, g.k * g.k), device=d) if g.CO == 1 else None
                 fn = lambda: ops.layer_forward(g, x, w, b, y, out_act=ACT_LEAKY, wsplit=ws, tmp=tmp)
-            elif what == "dgrad":
+            elif what.startswith("dgrad"):
+                from posterior_matching_amd.models.core import ParamStore
+                st = ParamStore()
+                st.add("w", g.weight_shape, fan_in=1)
+                hd = st.request_split("w", g, "dgrad")
+                st.allocate(d)
+                st.load_dict({"w": w.cpu()})
+                ws = st.split_view(hd) if os.environ.get("PM_BF16", "1") == "1" else None
                 y.normal_()
-                tmp = None
-                fn = lambda: ops.layer_dgrad(g, y, w, x)
+                fn = lambda: ops.layer_dgrad(g, y, w, x, aux=x.clone(), aux_act=ACT_LEAKY, wsplit=ws)
             else:
                 y.normal_()
                 fn = lambda: ops.layer_wgrad(g, x, y, dw, db)
@@ -78,7 +94,13 @@ def main():
             macs = B * g.OH * g.OW * g.k * g.k * g.CI * g.CO if g.kind != "convT" or g.s == 1 else B * g.IH * g.IW * g.k * g.k * g.CI * g.CO
             if g.kind == "conv" and g.s > 1:
                 macs = B * g.OH * g.OW * g.k * g.k * g.CI * g.CO
-            print(f"{name:30s} {us:8.1f} us  {2 * macs / us / 1e6:7.1f} TFLOP/s (nominal)")
+            kt = ops.KernelTimer()
+            ops.set_timer(kt)
+            for _ in range(10):
+                fn()
+            ops.set_timer(None)
+            dev_us = " + ".join(f"{v['ms'] / v['calls'] * 1e3:.1f}" for v in kt.summary().values())
+            print(f"{name:30s} {us:8.1f} us host-paced  {2 * macs / us / 1e6:7.1f} TFLOP/s (nominal)   device: {dev_us} us")
 
 
 if __name__ == "__main__":
