@@ -57,6 +57,16 @@ class AdamCfg(C.Structure):
     ]
 
 
+class MaskComponent(C.Structure):
+    """struct pm_mask_component (include/pmhip.h)."""
+
+    _fields_ = [
+        ("kind", C.c_int), ("p", C.c_float),
+        ("y1", C.c_int), ("x1", C.c_int), ("y2", C.c_int), ("x2", C.c_int),
+        ("size", C.c_int), ("min_prop", C.c_float), ("max_prop", C.c_float), ("cum_weight", C.c_float),
+    ]
+
+
 class SplitJob(C.Structure):
     """struct pm_split_job (include/pmhip.h)."""
 
@@ -123,6 +133,9 @@ SIGNATURES = {
     "pm_impute_blend": [_P, _P, _P, _P, _LL, _I, _LL, _I, _I, _F, _F],
     "pm_imputation_psnr": [_P, _P, _P, _P, _LL, _I, _LL, _F],
     "pm_gumbel_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
+    "pm_image_mask_mixture": [_P, _P, _I, _I, _I, C.POINTER(MaskComponent), _I, C.c_ulonglong, _P, _I, _P],
+    "pm_bernoulli_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
+    "pm_uniform_mask": [_P, _P, _I, _I, _I, _I, C.c_ulonglong, _P, _I],
     "pm_dropout_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
     "pm_gelu_fwd": [_P, _P, _P, _P, _LL, _I, _I],
     "pm_gelu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I],

@@ -1,0 +1,216 @@
+// Device-side observed-feature masks (1 = observed, 0 = missing): the generators of the reference's
+// masking.py evaluated on the GPU from a counter-based Philox4x32-10 stream, so that the input pipeline
+// never leaves the device (the reference builds every mask in a Python loop inside
+// tf.py_function, masking.py:44-47,338-342).
+//   image mixtures  masking.py:24-47 (per-example component choice), :94-104 (pixel Bernoulli),
+//                   :107-140 (random rectangle, area-bounded by rejection), :143-157 (fixed rectangle),
+//                   :160-174 (random square), :235-286 (MNIST / Omniglot / CIFAR-10 mixtures)
+//   feature masks   masking.py:84-91 (Bernoulli), :50-81 (uniform: q observed features, q uniform)
+// The reference's generators own un-seeded NumPy RandomStates, so its bit streams cannot be reproduced by
+// anyone; what is reproduced is each generator's distribution.  The streams below are defined by
+// oracle/masking_oracle.py (same Philox counters), against which the kernels are bit-exact.
+#include "pm_common.h"
+
+namespace {
+
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned)p1;
+        c[3] = (unsigned)p0;
+        c[0] = n0;
+        c[2] = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// uniform integer in [0, n) from one 32-bit draw (multiply-shift)
+__device__ __forceinline__ int rand_below(unsigned r, int n) { return (int)(((unsigned long long)r * (unsigned)n) >> 32); }
+// Bernoulli(p) from one 32-bit draw: u = r * 2^-32 < p, evaluated in integers (threshold = floor(p * 2^32))
+__device__ __forceinline__ bool bern(unsigned r, unsigned long long thr) { return (unsigned long long)r < thr; }
+
+struct MixArgs {
+    pm_mask_component comp[PM_MASK_MAX_COMPONENTS];
+    int ncomp;
+    int B, H, W;
+    unsigned k0, k1;
+    int stream_id;
+};
+
+constexpr unsigned DESC_TAG = 0x80000000u;   // descriptor draws live on their own Philox stream id
+constexpr int RECT_MAX_TRIES = 256;
+
+// One workgroup per example.  Thread 0 draws the example's component and its parameters:
+//   counter (b, 0, step, stream|TAG)      word 0 -> component (inverse CDF over cum_weight), words 1,2 -> square x, y
+//   counter (b, 1 + t, step, stream|TAG)  try t of the random rectangle: x1, x2, y1, y2
+// then every thread fills pixels; pixel-Bernoulli examples draw word (e & 3) of counter (e >> 2, 0, step, stream)
+// with e the element's flat index in [B, H, W].
+__global__ __launch_bounds__(256) void image_mask_mixture_kernel(MixArgs a, const int* __restrict__ step_dev,
+                                                                  float* __restrict__ mask, int* __restrict__ desc_out) {
+    __shared__ int d[6];   // kind, y1, x1, y2, x2 (exclusive ends), component
+    const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        unsigned c[4] = {(unsigned)b, 0u, step, (unsigned)a.stream_id | DESC_TAG};
+        philox4x32_10(c, a.k0, a.k1);
+        const float u = (float)(c[0] >> 8) * 5.9604644775390625e-08f;   // 24-bit uniform in [0, 1): exact in f32
+        int ci = a.ncomp - 1;
+        for (int i = 0; i < a.ncomp; ++i)
+            if (u < a.comp[i].cum_weight) {
+                ci = i;
+                break;
+            }
+        const pm_mask_component& m = a.comp[ci];
+        int y1 = 0, x1 = 0, y2 = 0, x2 = 0;
+        if (m.kind == PM_MASK_FIXED_RECT) {
+            y1 = m.y1; x1 = m.x1; y2 = m.y2; x2 = m.x2;
+        } else if (m.kind == PM_MASK_SQUARE) {
+            x1 = rand_below(c[1], a.W - m.size);
+            y1 = rand_below(c[2], a.H - m.size);
+            x2 = x1 + m.size;
+            y2 = y1 + m.size;
+        } else if (m.kind == PM_MASK_RECT) {
+            const float area = (float)(a.W * a.H);
+            for (int t = 0; t < RECT_MAX_TRIES; ++t) {
+                unsigned r[4] = {(unsigned)b, (unsigned)(1 + t), step, (unsigned)a.stream_id | DESC_TAG};
+                philox4x32_10(r, a.k0, a.k1);
+                int xa = rand_below(r[0], a.W), xb = rand_below(r[1], a.W);
+                int ya = rand_below(r[2], a.H), yb = rand_below(r[3], a.H);
+                x1 = xa < xb ? xa : xb; x2 = xa < xb ? xb : xa;
+                y1 = ya < yb ? ya : yb; y2 = ya < yb ? yb : ya;
+                const float cover = (float)((x2 - x1 + 1) * (y2 - y1 + 1));
+                if (m.min_prop * area <= cover && cover <= m.max_prop * area) break;
+            }
+            x2 += 1;   // the reference blanks [y1 : y2 + 1, x1 : x2 + 1]
+            y2 += 1;
+        }
+        d[0] = m.kind; d[1] = y1; d[2] = x1; d[3] = y2; d[4] = x2; d[5] = ci;
+        if (desc_out) {
+            int* o = desc_out + 6 * b;
+            o[0] = m.kind; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2; o[5] = ci;
+        }
+    }
+    __syncthreads();
+    const int kind = d[0], y1 = d[1], x1 = d[2], y2 = d[3], x2 = d[4];
+    const int hw = a.H * a.W;
+    float* mb = mask + (size_t)b * hw;
+    if (kind == PM_MASK_PIXEL_BERNOULLI) {
+        const unsigned long long thr = (unsigned long long)((double)a.comp[d[5]].p * 4294967296.0);
+        const long long e0 = (long long)b * hw;
+        for (long long q = (e0 >> 2) + threadIdx.x; q * 4 < e0 + hw; q += 256) {
+            unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), step, (unsigned)a.stream_id};
+            philox4x32_10(c, a.k0, a.k1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long e = q * 4 + j;
+                if (e >= e0 && e < e0 + hw) mb[e - e0] = bern(c[j], thr) ? 1.f : 0.f;
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < hw; e += 256) {
+            const int y = e / a.W, x = e - y * a.W;
+            mb[e] = (y >= y1 && y < y2 && x >= x1 && x < x2) ? 0.f : 1.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bernoulli_mask_kernel(float* __restrict__ mask, long long n, unsigned long long thr,
+                                                               unsigned k0, unsigned k1, const int* __restrict__ step_dev,
+                                                               int stream_id) {
+    const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+    const long long quads = (n + 3) / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += stride) {
+        unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), step, (unsigned)stream_id};
+        philox4x32_10(c, k0, k1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) mask[q * 4 + j] = bern(c[j], thr) ? 1.f : 0.f;
+    }
+}
+
+// Row b observes q = lo + floor(u * span) features chosen uniformly without replacement: feature i is observed iff
+// fewer than q features have a smaller (key, index).  Keys: word (i & 3) of counter (b*ceil(D/4) + (i >> 2), 0, ...);
+// q from word 0 of the descriptor counter (b, 0, step, stream|TAG).
+__global__ __launch_bounds__(256) void uniform_mask_kernel(float* __restrict__ mask, int B, int D, int lo, int span,
+                                                             unsigned k0, unsigned k1, const int* __restrict__ step_dev,
+                                                             int stream_id) {
+    extern __shared__ unsigned keys[];
+    const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
+    const int b = blockIdx.x;
+    const int dq = (D + 3) / 4;
+    for (int q = threadIdx.x; q < dq; q += 256) {
+        const long long ctr = (long long)b * dq + q;
+        unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), step, (unsigned)stream_id};
+        philox4x32_10(c, k0, k1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < D) keys[q * 4 + j] = c[j];
+    }
+    unsigned dsc[4] = {(unsigned)b, 0u, step, (unsigned)stream_id | DESC_TAG};
+    philox4x32_10(dsc, k0, k1);
+    int nobs = lo + rand_below(dsc[0], span);
+    if (nobs > D) nobs = D;
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const unsigned ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < D; ++j) {
+            const unsigned kj = keys[j];
+            rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+        }
+        mask[(size_t)b * D + i] = rank < nobs ? 1.f : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int pm_image_mask_mixture(pm_stream_t stream, float* mask, int B, int H, int W,
+                                     const pm_mask_component* comps, int ncomp, unsigned long long seed,
+                                     const int* step_dev, int stream_id, int* desc_out) {
+    if (!mask || !comps || B <= 0 || H <= 0 || W <= 0 || ncomp <= 0 || ncomp > PM_MASK_MAX_COMPONENTS) return PM_EINVAL;
+    if ((long long)B * H * W >= (1LL << 40) || stream_id < 0) return PM_EINVAL;
+    MixArgs a;
+    float prev = 0.f;
+    for (int i = 0; i < ncomp; ++i) {
+        const pm_mask_component& m = comps[i];
+        if (m.cum_weight < prev || m.cum_weight > 1.0001f) return PM_EINVAL;
+        prev = m.cum_weight;
+        switch (m.kind) {
+            case PM_MASK_PIXEL_BERNOULLI: if (!(m.p >= 0.f && m.p <= 1.f)) return PM_EINVAL; break;
+            case PM_MASK_FIXED_RECT: break;
+            case PM_MASK_SQUARE: if (m.size <= 0 || m.size >= H || m.size >= W) return PM_EINVAL; break;
+            case PM_MASK_RECT: if (!(m.min_prop <= m.max_prop) || m.max_prop <= 0.f) return PM_EINVAL; break;
+            default: return PM_EINVAL;
+        }
+        a.comp[i] = m;
+    }
+    a.ncomp = ncomp; a.B = B; a.H = H; a.W = W;
+    a.k0 = (unsigned)seed; a.k1 = (unsigned)(seed >> 32); a.stream_id = stream_id;
+    hipLaunchKernelGGL(image_mask_mixture_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, step_dev, mask, desc_out);
+    return pm_check_launch("pm_image_mask_mixture");
+}
+
+extern "C" int pm_bernoulli_mask(pm_stream_t stream, float* mask, long long n, float p, unsigned long long seed,
+                                 const int* step_dev, int stream_id) {
+    if (!mask || n <= 0 || !(p >= 0.f && p <= 1.f) || stream_id < 0) return PM_EINVAL;
+    long long blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const unsigned long long thr = (unsigned long long)((double)p * 4294967296.0);
+    hipLaunchKernelGGL(bernoulli_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, n, thr,
+                       (unsigned)seed, (unsigned)(seed >> 32), step_dev, stream_id);
+    return pm_check_launch("pm_bernoulli_mask");
+}
+
+extern "C" int pm_uniform_mask(pm_stream_t stream, float* mask, int B, int D, int lo, int span, unsigned long long seed,
+                               const int* step_dev, int stream_id) {
+    if (!mask || B <= 0 || D <= 0 || D > 8192 || lo < 0 || span <= 0 || stream_id < 0) return PM_EINVAL;
+    hipLaunchKernelGGL(uniform_mask_kernel, dim3(B), dim3(256), (size_t)D * 4, (hipStream_t)stream, mask, B, D, lo, span,
+                       (unsigned)seed, (unsigned)(seed >> 32), step_dev, stream_id);
+    return pm_check_launch("pm_uniform_mask");
+}

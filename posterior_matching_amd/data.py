@@ -22,13 +22,20 @@ class SyntheticDataset:
     ({"image"|"features": f32[B,...], "mask": f32[B,...]}), already resident on `device`."""
 
     def __init__(self, config: Mapping, batch_size: int, num_batches: int = 64, seed: int = 0, device="cpu",
-                 training: bool = True, arrays: Optional[np.ndarray] = None, normalize_images: bool = True):
+                 training: bool = True, arrays: Optional[np.ndarray] = None, normalize_images: bool = True,
+                 device_masks: bool = False):
+        """device_masks: draw a FRESH mask for every yielded batch on the GPU (masking.DeviceMaskGenerator, SURVEY.md
+        8(f)-1) instead of cycling the masks generated on the host with the pool."""
         rng = np.random.default_rng(seed)
         name = config["dataset"]
         shape = data_shape(name)
         self.key = "image" if len(shape) == 3 else "features"
         gen = None                                          # stage-1 VQ-VAE batches carry no mask (utils.py:338-350)
-        if config.get("mask_generator") is not None:
+        self._device_gen = None
+        if config.get("mask_generator") is not None and device_masks:
+            self._device_gen = get_mask_generator(config["mask_generator"], device=device, seed=seed + 1,
+                                                  **config.get("mask_generator_kwargs", {}))
+        elif config.get("mask_generator") is not None:
             gen = get_mask_generator(config["mask_generator"], seed=seed + 1, **config.get("mask_generator_kwargs", {}))
         self.batches: List[Dict[str, torch.Tensor]] = []
         for i in range(num_batches):
@@ -47,6 +54,9 @@ class SyntheticDataset:
             batch = {self.key: torch.from_numpy(x).to(device)}
             if gen is not None:
                 batch["mask"] = torch.from_numpy(gen((batch_size,) + shape)).to(device)
+            elif self._device_gen is not None:
+                mshape = (batch_size,) + (shape[:-1] + (1,) if self.key == "image" else shape)
+                batch["mask"] = torch.empty(mshape, dtype=torch.float32, device=device)
             self.batches.append(batch)
         self.batch_size, self.shape = batch_size, shape
 
@@ -56,7 +66,10 @@ class SyntheticDataset:
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         i = 0
         while True:
-            yield self.batches[i % len(self.batches)]
+            batch = self.batches[i % len(self.batches)]
+            if self._device_gen is not None:
+                self._device_gen(batch["mask"].shape, out=batch["mask"])
+            yield batch
             i += 1
 
 

@@ -688,6 +688,26 @@ def imputation_psnr(imp, x, psnr, scale: float = 1.0) -> None:
     _call("pm_imputation_psnr", _ptr(imp), _ptr(x), _ptr(psnr), B, S, x.numel() // B, scale)
 
 
+def image_mask_mixture(mask, comps, seed: int, step_dev=None, stream_id: int = 0, desc_out=None) -> None:
+    """mask [B,H,W,1] f32; comps: ctypes array of _lib.MaskComponent (host memory, copied into the launch)"""
+    B, H, W = mask.shape[0], mask.shape[1], mask.shape[2]
+    dptr = None
+    if desc_out is not None:
+        assert desc_out.is_cuda and desc_out.dtype == torch.int32 and desc_out.is_contiguous() and desc_out.numel() == 6 * B
+        dptr = desc_out.data_ptr()
+    _call("pm_image_mask_mixture", _ptr(mask), B, H, W, comps, len(comps), seed & (2 ** 64 - 1), _iptr(step_dev),
+          stream_id, dptr)
+
+
+def bernoulli_mask(mask, p: float, seed: int, step_dev=None, stream_id: int = 0) -> None:
+    _call("pm_bernoulli_mask", _ptr(mask), mask.numel(), float(p), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
+
+
+def uniform_mask(mask, lo: int, span: int, seed: int, step_dev=None, stream_id: int = 0) -> None:
+    B, D = mask.shape[0], mask.numel() // mask.shape[0]
+    _call("pm_uniform_mask", _ptr(mask), B, D, int(lo), int(span), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
+
+
 def gumbel_fill(out, seed: int, step_dev=None, stream_id: int = 0) -> None:
     _call("pm_gumbel_fill", _ptr(out), out.numel(), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
 

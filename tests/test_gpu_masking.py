@@ -1,0 +1,125 @@
+"""Device-side mask generation (csrc/pm_mask.hip) against oracle/masking_oracle.py: bit-exact streams, plus the
+distributional properties each reference generator defines (reference masking.py:24-286)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import masking_oracle as MO
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name,B,H,seed", [("MNISTMaskGenerator", 64, 28, 1), ("OmniglotMaskGenerator", 33, 28, 2),
+                                           ("Cifar10MaskGenerator", 40, 32, 3), ("MNISTMaskGenerator", 17, 14, 4)])
+def test_image_mixture_bit_exact(name, B, H, seed):
+    from posterior_matching_amd import ops
+    from posterior_matching_amd.masking import get_mask_generator
+
+    dim = H if name == "MNISTMaskGenerator" else None
+    gen = get_mask_generator(name, device=dev(), seed=seed, **({"dim": dim} if dim else {}))
+    comps = MO.image_mixture_components(name, dim)
+    for step in range(3):
+        desc = torch.zeros((B, 6), dtype=torch.int32, device=dev())
+        out = torch.empty((B, H, H, 1), device=dev())
+        gen.fill(out, desc_out=desc)
+        gen._advance()
+        want, wdesc = MO.image_mask_mixture(B, H, H, comps, seed, step=step)
+        assert np.array_equal(desc.cpu().numpy(), wdesc), step
+        assert np.array_equal(out.cpu().numpy(), want), step
+    # the public call path advances the stream by itself
+    m = gen((B, H, H, 1))
+    assert np.array_equal(m.cpu().numpy(), MO.image_mask_mixture(B, H, H, comps, seed, step=3)[0])
+
+
+def test_image_mixture_distribution_full_batch():
+    """4096 MNIST masks: component frequencies = weights/10, rectangles inside their area bounds, squares 14x14,
+    half planes exact, pixel-Bernoulli mean 0.5 (reference masking.py:235-249)."""
+    from posterior_matching_amd.masking import get_mask_generator
+
+    B, H = 4096, 28
+    gen = get_mask_generator("MNISTMaskGenerator", device=dev(), seed=11)
+    desc = torch.zeros((B, 6), dtype=torch.int32, device=dev())
+    out = torch.empty((B, H, H, 1), device=dev())
+    gen.fill(out, desc_out=desc)
+    d, m = desc.cpu().numpy(), out.cpu().numpy()[..., 0]
+    assert set(np.unique(m)) <= {0.0, 1.0}
+    freq = np.bincount(d[:, 5], minlength=7) / B
+    assert np.abs(freq - np.array([2, 1, 1, 1, 1, 2, 2]) / 10).max() < 0.03
+    missing = (1 - m).sum((1, 2))
+    bern = d[:, 5] == 0
+    assert abs(m[bern].mean() - 0.5) < 0.01
+    for ci, (y1, x1, y2, x2) in zip(range(1, 5), [(0, 0, 28, 14), (0, 0, 14, 28), (0, 14, 28, 28), (14, 0, 28, 28)]):
+        sel = m[d[:, 5] == ci]
+        want = np.ones((28, 28))
+        want[y1:y2, x1:x2] = 0
+        assert (sel == want).all()
+    sq = d[:, 5] == 5
+    assert (missing[sq] == 14 * 14).all()
+    assert d[sq, 1].min() >= 0 and d[sq, 1].max() <= 13 and d[sq, 2].max() <= 13      # randint(28 - 14): 0..13
+    assert len(np.unique(d[sq, 2])) == 14
+    rc = d[:, 5] == 6
+    area = (d[rc, 3] - d[rc, 1]) * (d[rc, 4] - d[rc, 2])
+    assert (area == missing[rc]).all()
+    assert area.min() >= 0.3 * 784 and area.max() <= 784
+
+
+@pytest.mark.parametrize("shape,p", [((37, 8), 0.5), ((5, 28, 28, 1), 0.2), ((3, 1001), 0.9)])
+def test_bernoulli_mask_bit_exact(shape, p):
+    from posterior_matching_amd.masking import get_mask_generator
+
+    gen = get_mask_generator("BernoulliMaskGenerator", device=dev(), seed=5, p=p)
+    for step in range(2):
+        got = gen(shape).cpu().numpy()
+        assert np.array_equal(got, MO.bernoulli_mask(shape, p, 5, step=step))
+    big = get_mask_generator("BernoulliMaskGenerator", device=dev(), seed=6, p=p)((4096, 512)).mean().item()
+    assert abs(big - p) < 2e-3
+
+
+@pytest.mark.parametrize("B,D,bounds", [(64, 8, None), (31, 43, None), (16, 300, (0.25, 0.5))])
+def test_uniform_mask_bit_exact(B, D, bounds):
+    from posterior_matching_amd.masking import get_mask_generator
+
+    gen = get_mask_generator("UniformMaskGenerator", device=dev(), seed=9, bounds=bounds)
+    lo, span = (0, D) if bounds is None else (int(D * bounds[0]), int(D * bounds[1]))
+    got = gen((B, D)).cpu().numpy()
+    assert np.array_equal(got, MO.uniform_mask(B, D, lo, span, 9, step=0))
+    counts = got.sum(1)
+    assert counts.min() >= lo and counts.max() <= min(D, lo + span - 1)
+
+
+def test_uniform_mask_counts_are_uniform():
+    from posterior_matching_amd.masking import get_mask_generator
+
+    got = get_mask_generator("UniformMaskGenerator", device=dev(), seed=1)((8192, 8)).cpu().numpy()
+    freq = np.bincount(got.sum(1).astype(int), minlength=8) / 8192           # q = choice(8): 0..7
+    assert got.sum(1).max() <= 7 and np.abs(freq - 1 / 8).max() < 0.02
+    assert np.abs(got.mean(0) - got.mean()).max() < 0.02                          # every feature equally likely
+
+
+def test_dataset_device_masks_feed_a_train_step():
+    """SyntheticDataset(device_masks=True): fresh masks every batch, consumed by the PM-VAE train step."""
+    from posterior_matching_amd import optim
+    from posterior_matching_amd.data import SyntheticDataset
+    from posterior_matching_amd.engine import PMVAETrainStep
+    from posterior_matching_amd.models import PosteriorMatchingVAE
+    from tests.ref_configs import pm_vae_mnist
+
+    cfg = pm_vae_mnist()
+    ds = SyntheticDataset({"dataset": "mnist", "mask_generator": "MNISTMaskGenerator"}, 16, 2, 0, dev(), device_masks=True)
+    it = iter(ds)
+    masks = [next(it)["mask"].clone() for _ in range(3)]
+    assert not torch.equal(masks[0], masks[2])          # batch 0 of the pool comes back with a new mask
+    model = PosteriorMatchingVAE.from_config(cfg["model"], device="cuda:0", seed=3)
+    model.init((28, 28, 1))
+    opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(0.0),
+                      optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
+    ts = PMVAETrainStep(model, cfg, opt, 16, (28, 28, 1), use_graph=False)
+    for _ in range(3):
+        batch = next(it)
+        ts.set_batch(batch["image"], batch["mask"])
+        ts.step()
+    assert np.isfinite(ts.read_metrics()["loss"])

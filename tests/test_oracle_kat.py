@@ -462,3 +462,43 @@ def test_vdvae_gradcheck_tiny():
         lp = DO.vdvae_loss({**p, name: p[name] + h * d}, cfg, x, b, eps)[0]
         lm = DO.vdvae_loss({**p, name: p[name] - h * d}, cfg, x, b, eps)[0]
         assert (lp - lm).item() / (2 * h) == pytest.approx((grads[name] * d).sum().item(), rel=2e-5), name
+
+
+# ----------------------------------------------------------------------------------------------
+# device-side mask generation (oracle/masking_oracle.py): Philox KATs and generator semantics
+# ----------------------------------------------------------------------------------------------
+def test_philox4x32_10_known_answers():
+    """Random123 kat_vectors, philox4x32 with 10 rounds."""
+    import numpy as np
+
+    from oracle.masking_oracle import philox4x32_10
+
+    kats = [([0, 0, 0, 0], (0, 0), [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+            ([0xffffffff] * 4, (0xffffffff, 0xffffffff), [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+            ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0),
+             [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kats:
+        assert [int(v) for v in philox4x32_10(np.array(ctr, dtype=np.uint32), key)] == want
+
+
+def test_mask_oracle_semantics():
+    """reference masking.py:94-174,235-249: structure of every component, on the oracle's own streams."""
+    import numpy as np
+
+    from oracle import masking_oracle as MO
+
+    comps = MO.image_mixture_components("MNISTMaskGenerator")
+    assert [c.weight for c in comps] == [2, 1, 1, 1, 1, 2, 2]
+    m, d = MO.image_mask_mixture(600, 28, 28, comps, seed=3)
+    m = m[..., 0]
+    assert np.abs(np.bincount(d[:, 5], minlength=7) / 600 - np.array([2, 1, 1, 1, 1, 2, 2]) / 10).max() < 0.06
+    left = m[d[:, 5] == 1]
+    assert (left[:, :, :14] == 0).all() and (left[:, :, 14:] == 1).all()       # FixedRectangle(0, 0, dim, half)
+    assert ((1 - m[d[:, 5] == 5]).sum((1, 2)) == 196).all()
+    rc = d[:, 5] == 6
+    area = (1 - m[rc]).sum((1, 2))
+    assert area.min() >= 0.3 * 784 and ((d[rc, 3] - d[rc, 1]) * (d[rc, 4] - d[rc, 2]) == area).all()
+    u = MO.uniform_mask(500, 8, 0, 8, seed=2)
+    assert u.sum(1).max() <= 7 and u.sum(1).min() == 0                          # q = choice(8) is 0..7
+    b = MO.bernoulli_mask((200, 50), 0.3, seed=4)
+    assert abs(b.mean() - 0.3) < 0.02

@@ -34,6 +34,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
     ap.add_argument("--data", default=None, help="optional .npy with the training examples")
+    ap.add_argument("--device_masks", action="store_true",
+                    help="draw a fresh mask for every training batch on the GPU (pm_image_mask_mixture & co.) "
+                         "instead of cycling host-generated masks")
     args, rest = ap.parse_known_args()
     config = load_config_file(args.config)
     apply_overrides(config, [r[len("--config."):] for r in rest if r.startswith("--config.")])
@@ -48,7 +51,7 @@ def main():
     device = torch.device("cuda", local_rank)
     arrays = np.load(args.data) if args.data else None
     train_dataset = SyntheticDataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
-                                     training=True, arrays=arrays)
+                                     training=True, arrays=arrays, device_masks=args.device_masks)
     val_dataset = SyntheticDataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
                                    training=False, arrays=arrays)
     data_key = train_dataset.key

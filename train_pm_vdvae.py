@@ -73,7 +73,8 @@ def main():
     arrays = np.load(args.data) if args.data else None
     # load_datasets(config.data, normalize_images=False) (train_pm_vdvae.py:107): raw 0..255 pixel values
     train_dataset = SyntheticDataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
-                                     training=True, arrays=arrays, normalize_images=False)
+                                     training=True, arrays=arrays, normalize_images=False,
+                                     device_masks=args.device_masks)
     val_dataset = SyntheticDataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
                                    training=False, arrays=arrays, normalize_images=False)
 
