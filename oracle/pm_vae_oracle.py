@@ -363,6 +363,137 @@ def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor
     return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll, "z": z}
 
 
+# ----------------------------------------------------------------------------------------------
+# Evaluation paths: impute (vae.py:146-169), is_log_prob (vae.py:171-226), NRMSE (eval_pm_vae_uci.py:60-66)
+# ----------------------------------------------------------------------------------------------
+def autoregressive_gmm_sample(p: Params, prefix: str, context: Tensor, gumbel: Tensor, eps: Tensor, event_size: int,
+                              num_components: int = 10, residual_blocks: int = 2) -> Tensor:
+    """_AutoregressiveDistribution._sample_n (distributions.py:168-190) for rows that already carry their own context
+    (the vmap over contexts and the broadcast over n flattened into rows).  Step i: net([x*mask_i, mask_i, ctx]) ->
+    MixtureSameFamily; only column i of its sample is kept (`updates = out.sample(...) * (arange == i)`).
+    The draw is explicit: component = argmax(logits + gumbel[:, i]) (jax.random.categorical is Gumbel-max),
+    value = mean_c + scale_c * eps[:, i].  gumbel [R, k, nc], eps [R, k]."""
+    R = context.shape[0]
+    ctx = context.reshape(R, -1)
+    ar = torch.arange(event_size, dtype=eps.dtype)
+    x = torch.zeros((R, event_size), dtype=eps.dtype)
+    nc = num_components
+    for i in range(event_size):
+        mask = (ar < i).to(eps.dtype).expand_as(x)
+        h = residual_mlp(p, f"{prefix}/mlp", torch.cat([x * mask, mask, ctx], -1), residual_blocks)
+        head = linear(h, p[f"{prefix}/gmm/linear/w"], p[f"{prefix}/gmm/linear/b"])
+        prm = head.reshape(R, event_size, 3 * nc)[:, i]
+        comp = torch.argmax(prm[:, :nc] + gumbel[:, i], -1, keepdim=True)
+        mean = torch.gather(prm[:, nc:2 * nc], 1, comp)[:, 0]
+        scale = torch.gather(softplus(prm[:, 2 * nc:]) + 1e-5, 1, comp)[:, 0]
+        x = x.clone()
+        x[:, i] = mean + scale * eps[:, i]
+    return x
+
+
+def _partial_posterior(p: Params, model_cfg: dict, x: Tensor, b: Tensor):
+    k = model_cfg["latent_dim"]
+    enc_kind = model_cfg["encoder_net"]
+    enc_cfg = model_cfg.get("encoder_net_config") or {}
+    penc_kind = model_cfg.get("partial_encoder_net", enc_kind)
+    penc_cfg = model_cfg.get("partial_encoder_net_config", enc_cfg) or {}
+    post_kind = model_cfg["posterior_dist"]
+    kind = model_cfg.get("partial_posterior_dist", post_kind)
+    cfg = dict(model_cfg.get("partial_posterior_dist_config", model_cfg.get("posterior_dist_config", {})) or {})
+    pfeats = _net(p, penc_kind, penc_cfg, "partial_encoder_net", torch.cat([x * b, b], -1))
+    return kind, cfg, pfeats, k
+
+
+def _rep(t: Tensor, S: int) -> Tensor:
+    """rows b*S + s (sample-minor), the layout of the HIP evaluation kernels"""
+    return t.repeat_interleave(S, dim=0)
+
+
+def _sample_partial_posterior(p, kind, cfg, pfeats, k, noise, S):
+    """-> z [B*S, k] and a closure giving log q(z | x_o) of such rows"""
+    if kind == "AutoregressiveGMM":
+        nc, rb = cfg.get("num_components", 10), cfg.get("residual_blocks", 2)
+        ctx = _rep(pfeats.reshape(pfeats.shape[0], -1), S)
+        z = autoregressive_gmm_sample(p, "partial_posterior_dist", ctx, noise["gumbel"].reshape(-1, k, nc),
+                                      noise["eps"].reshape(-1, k), k, nc, rb)
+        return z, lambda zz: autoregressive_gmm_log_prob(p, "partial_posterior_dist", ctx, zz, k, nc, rb)
+    if kind == "TriLGaussian":
+        loc, tril = tril_gaussian_params(p, "partial_posterior_dist", pfeats, k)
+    else:
+        loc, scale = diagonal_gaussian_params(p, "partial_posterior_dist", pfeats, k)
+        tril = torch.diag_embed(scale)
+    loc, tril = _rep(loc, S), _rep(tril, S)
+    z = loc + torch.einsum("bij,bj->bi", tril, noise["eps"].reshape(-1, k))
+    return z, lambda zz: mvn_tril_log_prob(zz, loc, tril)
+
+
+def _decoder(p: Params, model_cfg: dict, z: Tensor):
+    dec = _net(p, model_cfg["decoder_net"], model_cfg.get("decoder_net_config") or {}, "decoder_net", z)
+    if model_cfg["decoder_dist"] == "Bernoulli":
+        return "Bernoulli", dec
+    return "IdentityGaussian", linear(dec.reshape(dec.shape[0], -1), p["decoder_dist/linear/w"], p["decoder_dist/linear/b"])
+
+
+def pm_vae_impute(p: Params, model_cfg: dict, x_o: Tensor, b: Tensor, noise: Dict[str, Tensor]) -> Tensor:
+    """PosteriorMatchingVAE.impute (vae.py:146-169) -> [S, B, ...].  noise["eps"] [B,S,k] (+ "gumbel" [B,S,k,nc])."""
+    S = noise["eps"].shape[1]
+    x_o = x_o * b
+    kind, cfg, pfeats, k = _partial_posterior(p, model_cfg, x_o, b)
+    z, _ = _sample_partial_posterior(p, kind, cfg, pfeats, k, noise, S)
+    dkind, out = _decoder(p, model_cfg, z)
+    mean = torch.sigmoid(out) if dkind == "Bernoulli" else out                     # decoder(u).mean()
+    mean = mean.reshape((x_o.shape[0], S) + tuple(x_o.shape[1:])).transpose(0, 1)
+    return torch.where(b[None] > 0, x_o[None], mean)
+
+
+def pm_vae_is_log_prob(p: Params, model_cfg: dict, x: Tensor, b: Tensor, noise: Dict[str, Tensor]):
+    """PosteriorMatchingVAE.is_log_prob (vae.py:171-226) -> (log p(x) [B], log p(x_u | x_o) [B]).
+    noise: "eps_posterior" [B,S,k] for q(z|x); "eps" (+"gumbel") for q(z|x_o)."""
+    k = model_cfg["latent_dim"]
+    B, S = x.shape[0], noise["eps"].shape[1]
+    feats = _net(p, model_cfg["encoder_net"], model_cfg.get("encoder_net_config") or {}, "encoder_net", x)
+    if model_cfg["posterior_dist"] == "TriLGaussian":
+        loc, tril = tril_gaussian_params(p, "posterior_dist", feats, k)
+    else:
+        loc, scale = diagonal_gaussian_params(p, "posterior_dist", feats, k)
+        tril = torch.diag_embed(scale)
+    loc, tril = _rep(loc, S), _rep(tril, S)
+    z = loc + torch.einsum("bij,bj->bi", tril, noise["eps_posterior"].reshape(-1, k))
+    kind, cfg, pfeats, _ = _partial_posterior(p, model_cfg, x, b)
+    z_xo, log_q_xo = _sample_partial_posterior(p, kind, cfg, pfeats, k, noise, S)
+
+    def dec_ll(zz, w):
+        dkind, out = _decoder(p, model_cfg, zz)
+        xr = _rep(x, S)
+        if dkind == "Bernoulli":
+            lls = bernoulli_log_prob(out.reshape(xr.shape), xr)
+        else:
+            lls = normal_log_prob(xr, out.reshape(xr.shape), torch.exp(p["decoder_dist/log_scale"]))
+        if w is not None:
+            lls = lls * _rep(w, S)
+        return lls.reshape(lls.shape[0], -1).sum(-1)
+
+    def prior_lp(zz):
+        return -0.5 * (zz * zz).sum(-1) - 0.5 * k * math.log(2 * math.pi)
+
+    def lme(v):
+        v = v.reshape(B, S)
+        return torch.logsumexp(v, 1) - math.log(S)
+
+    log_p_x = lme(dec_ll(z, None) + prior_lp(z) - mvn_tril_log_prob(z, loc, tril))
+    log_p_xo = lme(dec_ll(z_xo, b) + prior_lp(z_xo) - log_q_xo(z_xo))
+    return log_p_x, log_p_x - log_p_xo
+
+
+def nrmse_score(imputations, true_data, observed_mask):
+    """eval_pm_vae_uci.py:60-66 (numpy): per-feature RMSE over the missing entries / feature std, mean over features."""
+    import numpy as np
+
+    error = (imputations - true_data) ** 2
+    mse = np.sum(error, axis=-2) / np.count_nonzero(1.0 - observed_mask, axis=-2)
+    return np.mean(np.sqrt(mse) / np.std(true_data, axis=-2), axis=-1)
+
+
 def cyclical_annealing_beta(step: int, low: float, high: float, period: int, delay: int = 0) -> float:
     """cyclical_annealing_schedule (utils.py:124-136)."""
     count = step - delay

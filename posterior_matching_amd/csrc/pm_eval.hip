@@ -1,0 +1,186 @@
+// Evaluation paths of the PM-VAE: imputation and importance-sampled likelihoods.
+//   PosteriorMatchingVAE.impute       reference vae.py:146-169
+//   PosteriorMatchingVAE.is_log_prob  reference vae.py:171-226
+//   _AutoregressiveDistribution._sample_n  reference distributions.py:168-190 (one latent dimension per network pass)
+// S samples per example live on the row axis, sample-minor: row b*S + s.  Everything here is HBM-bound row work.
+#include "pm_common.h"
+
+namespace {
+
+constexpr float kLog2Pi = 1.8378770664093453f;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = pm_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// dst[(b*S + s), :] = src[b, :]
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            long long total, long long n, int S) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const long long row = e / n, j = e - row * n;
+        dst[e] = src[(row / S) * n + j];
+    }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ in, float* __restrict__ out, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) out[e] = pm_sigmoid(in[e]);
+}
+
+// ll[b*S + s] = sum_j w[b, j] * log Bernoulli(x[b, j]; logits[b*S + s, j]);  w NULL: 1;  Dw in {D, 1 per pixel group}:
+// w index = j / (D / Dw)  (mask with one channel per pixel against C-channel data)
+__global__ __launch_bounds__(256) void bernoulli_ll_rep_kernel(const float* __restrict__ logits, const float* __restrict__ x,
+                                                                 const float* __restrict__ w, float* __restrict__ ll,
+                                                                 int S, int D, int Dw) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row / S;
+    const size_t lb = (size_t)row * D, xb = (size_t)b * D, wb = (size_t)b * Dw;
+    const int grp = D / Dw;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < D; j += 256) {
+        const float l = logits[lb + j], t = x[xb + j];
+        const float v = t * (-pm_softplus(-l)) + (1.f - t) * (-pm_softplus(l));
+        s += w ? w[wb + j / grp] * v : v;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) ll[row] = s;
+}
+
+__global__ __launch_bounds__(256) void normal_ll_rep_kernel(const float* __restrict__ loc, const float* __restrict__ x,
+                                                              const float* __restrict__ log_scale,
+                                                              const float* __restrict__ w, float* __restrict__ ll, int S,
+                                                              int D, int Dw, float scale_eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row / S;
+    const size_t lb = (size_t)row * D, xb = (size_t)b * D, wb = (size_t)b * Dw;
+    const int grp = D / Dw;
+    const float sigma = expf(log_scale[0]) + scale_eps;
+    const float inv = 1.f / sigma, ls = logf(sigma);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < D; j += 256) {
+        const float u = (x[xb + j] - loc[lb + j]) * inv;
+        const float v = -0.5f * u * u - ls - 0.5f * kLog2Pi;
+        s += w ? w[wb + j / grp] * v : v;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) ll[row] = s;
+}
+
+// lp[r] = log N(z[r]; 0, I)
+__global__ __launch_bounds__(256) void std_normal_logprob_kernel(const float* __restrict__ z, float* __restrict__ lp,
+                                                                   long long R, int k) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const float v = z[r * k + j];
+        s += v * v;
+    }
+    lp[r] = -0.5f * s - 0.5f * kLog2Pi * (float)k;
+}
+
+// out[b] = log mean_s exp(a[b,s] + bb[b,s] - c[b,s])   (tfp.math.reduce_logmeanexp over the sample axis)
+__global__ __launch_bounds__(64) void logmeanexp3_kernel(const float* __restrict__ a, const float* __restrict__ bb,
+                                                           const float* __restrict__ c, float* __restrict__ out, int S) {
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * S;
+    float m = -INFINITY;
+    for (int s = threadIdx.x; s < S; s += 64) {
+        float v = a[base + s];
+        if (bb) v += bb[base + s];
+        if (c) v -= c[base + s];
+        m = fmaxf(m, v);
+    }
+    m = pm_wave_max(m);
+    float acc = 0.f;
+    for (int s = threadIdx.x; s < S; s += 64) {
+        float v = a[base + s];
+        if (bb) v += bb[base + s];
+        if (c) v -= c[base + s];
+        acc += (m == -INFINITY) ? 0.f : expf(v - m);
+    }
+    acc = pm_wave_sum(acc);
+    if (threadIdx.x == 0) out[b] = (m == -INFINITY) ? -INFINITY : m + logf(acc) - logf((float)S);
+}
+
+// One step of the autoregressive sampler: head rows [i*R, (i+1)*R) hold (logits | means | raw scales) of latent
+// dimension i given z[:, :i];  z[r, i] = mean[c] + (softplus(raw[c]) + 1e-5) * eps[r, i],  c = argmax(logits + gumbel[r, i, :])
+__global__ __launch_bounds__(256) void gmm_sample_step_kernel(const float* __restrict__ head, const float* __restrict__ gumbel,
+                                                                const float* __restrict__ eps, float* __restrict__ z,
+                                                                long long R, int k, int nc, int i) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float* h = head + ((size_t)i * R + r) * 3 * nc;
+    const float* g = gumbel + ((size_t)r * k + i) * nc;
+    int best = 0;
+    float bv = h[0] + g[0];
+    for (int c = 1; c < nc; ++c) {
+        const float v = h[c] + g[c];
+        if (v > bv) {
+            bv = v;
+            best = c;
+        }
+    }
+    z[r * k + i] = h[nc + best] + (pm_softplus(h[2 * nc + best]) + 1e-5f) * eps[r * k + i];
+}
+
+}  // namespace
+
+extern "C" int pm_repeat_rows(pm_stream_t stream, const float* src, float* dst, long long B, int S, long long n) {
+    if (!src || !dst || B <= 0 || S <= 0 || n <= 0) return PM_EINVAL;
+    const long long total = B * S * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, total, n, S);
+    return pm_check_launch("pm_repeat_rows");
+}
+
+extern "C" int pm_sigmoid(pm_stream_t stream, const float* in, float* out, long long n) {
+    if (!in || !out || n <= 0) return PM_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    return pm_check_launch("pm_sigmoid");
+}
+
+extern "C" int pm_bernoulli_ll_rep_fwd(pm_stream_t stream, const float* logits, const float* x, const float* w, float* ll,
+                                       int B, int S, int D, int Dw) {
+    if (!logits || !x || !ll || B <= 0 || S <= 0 || D <= 0 || Dw <= 0 || D % Dw != 0) return PM_EINVAL;
+    hipLaunchKernelGGL(bernoulli_ll_rep_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, logits, x, w, ll, S, D, Dw);
+    return pm_check_launch("pm_bernoulli_ll_rep_fwd");
+}
+
+extern "C" int pm_normal_ll_rep_fwd(pm_stream_t stream, const float* loc, const float* x, const float* log_scale,
+                                    const float* w, float* ll, int B, int S, int D, int Dw, float scale_eps) {
+    if (!loc || !x || !log_scale || !ll || B <= 0 || S <= 0 || D <= 0 || Dw <= 0 || D % Dw != 0) return PM_EINVAL;
+    hipLaunchKernelGGL(normal_ll_rep_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, loc, x, log_scale, w, ll, S,
+                       D, Dw, scale_eps);
+    return pm_check_launch("pm_normal_ll_rep_fwd");
+}
+
+extern "C" int pm_std_normal_logprob(pm_stream_t stream, const float* z, float* lp, long long R, int k) {
+    if (!z || !lp || R <= 0 || k <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(std_normal_logprob_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
+                       lp, R, k);
+    return pm_check_launch("pm_std_normal_logprob");
+}
+
+extern "C" int pm_logmeanexp3(pm_stream_t stream, const float* a, const float* b, const float* c, float* out, int B,
+                              int S) {
+    if (!a || !out || B <= 0 || S <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(logmeanexp3_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a, b, c, out, S);
+    return pm_check_launch("pm_logmeanexp3");
+}
+
+extern "C" int pm_gmm_sample_step(pm_stream_t stream, const float* head, const float* gumbel, const float* eps, float* z,
+                                  long long R, int k, int nc, int i) {
+    if (!head || !gumbel || !eps || !z || R <= 0 || k <= 0 || nc <= 0 || i < 0 || i >= k) return PM_EINVAL;
+    hipLaunchKernelGGL(gmm_sample_step_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head,
+                       gumbel, eps, z, R, k, nc, i);
+    return pm_check_launch("pm_gmm_sample_step");
+}

@@ -39,6 +39,17 @@ class Bernoulli(Module):
         ops.bernoulli_ll_bwd(self._feat.t, self._x, g, dpre, self._feat.grad_act)
         return dpre
 
+    # -- evaluation paths (vae.py:146-226): rows of `feat` are (example, sample) pairs, sample-minor
+    def mean(self, feat: Feat) -> torch.Tensor:
+        out = self.buf("mean", feat.t.shape)
+        ops.sigmoid(feat.t, out)
+        return out
+
+    def log_prob_rep(self, feat: Feat, x: torch.Tensor, w: Optional[torch.Tensor], S: int, tag: str) -> torch.Tensor:
+        ll = self.buf(f"ll_rep_{tag}", (x.shape[0] * S,))
+        ops.bernoulli_ll_rep_fwd(feat.t, x, w, ll, S)
+        return ll
+
 
 class _LinearHead(Module):
     """Flatten + hk.Linear(out) on a network's features (distributions.py:42-48,73-79,102-108)."""
@@ -98,6 +109,15 @@ class IdentityGaussian(_LinearHead):
         ops.normal_ll_bwd(self._loc, self._x, self.P("log_scale"), g, dloc, self.G("log_scale"))
         return self._linear_bwd(dloc)
 
+    def mean(self, feat: Feat) -> torch.Tensor:
+        return self._linear_fwd(feat)
+
+    def log_prob_rep(self, feat: Feat, x: torch.Tensor, w: Optional[torch.Tensor], S: int, tag: str) -> torch.Tensor:
+        loc = self._linear_fwd(feat)
+        ll = self.buf(f"ll_rep_{tag}", (x.shape[0] * S,))
+        ops.normal_ll_rep_fwd(loc, x, self.P("log_scale"), w, ll, S)
+        return ll
+
 
 class TriLGaussian(_LinearHead):
     """reference distributions.py:87-113: Linear(k + k(k+1)/2) -> loc, FillScaleTriL."""
@@ -140,6 +160,22 @@ class TriLGaussian(_LinearHead):
         ops.tril_logprob_bwd(self._prm, self._z, g, dprm, dz)
         return self._linear_bwd(dprm)
 
+    # -- evaluation paths (vae.py:146-226): S samples per example, rows b*S + s
+    def sample_n(self, feat: Feat, eps: torch.Tensor, S: int, tag: str):
+        """eps [B*S, k] -> (z [B*S, k], repeated head parameters for log_prob_n)"""
+        prm = self._linear_fwd(feat)
+        R, k = eps.shape
+        rep = self.buf(f"params_rep_{tag}", (R, prm.shape[1]))
+        ops.repeat_rows(prm, rep, S)
+        z, kl = self.buf(f"z_n_{tag}", (R, k)), self.buf(f"kl_n_{tag}", (R,))
+        ops.tril_sample_kl_fwd(rep, eps, z, kl)
+        return z, rep
+
+    def log_prob_n(self, rep: torch.Tensor, z: torch.Tensor, tag: str) -> torch.Tensor:
+        lp = self.buf(f"lp_n_{tag}", (z.shape[0],))
+        ops.tril_logprob_fwd(rep, z, lp)
+        return lp
+
 
 class DiagonalGaussian(_LinearHead):
     """reference distributions.py:58-84: Linear(2k) -> loc, scale = softplus(raw) + 1e-5, MultivariateNormalDiag.
@@ -179,6 +215,22 @@ class DiagonalGaussian(_LinearHead):
         dprm = self.buf("dparams", self._prm.shape)
         ops.diag_gaussian_logprob_bwd(self._prm, self._z, g, dprm, dz)
         return self._linear_bwd(dprm)
+
+    # -- evaluation paths (vae.py:146-226): S samples per example, rows b*S + s
+    def sample_n(self, feat: Feat, eps: torch.Tensor, S: int, tag: str):
+        """eps [B*S, k] -> (z [B*S, k], repeated head parameters for log_prob_n)"""
+        prm = self._linear_fwd(feat)
+        R, k = eps.shape
+        rep = self.buf(f"params_rep_{tag}", (R, prm.shape[1]))
+        ops.repeat_rows(prm, rep, S)
+        z, kl = self.buf(f"z_n_{tag}", (R, k)), self.buf(f"kl_n_{tag}", (R,))
+        ops.diag_gaussian_sample_kl_fwd(rep, eps, z, kl)
+        return z, rep
+
+    def log_prob_n(self, rep: torch.Tensor, z: torch.Tensor, tag: str) -> torch.Tensor:
+        lp = self.buf(f"lp_n_{tag}", (z.shape[0],))
+        ops.diag_gaussian_logprob_fwd(rep, z, lp)
+        return lp
 
 
 class AutoregressiveGMM(Module):
@@ -255,6 +307,37 @@ class AutoregressiveGMM(Module):
                             ctx_act=self._feat.grad_act)
         return dctx.view(self._feat.t.shape)
 
+
+def _argmm_sample_n(self, feat: Feat, noise, S: int, tag: str):
+    """_AutoregressiveDistribution._sample_n (reference distributions.py:168-190): latent dimension i is drawn from
+    the network evaluated on z[:, :i].  Every step re-runs the stacked teacher-forced pass and reads step i's rows
+    (evaluation path: k network passes per sample, as in the reference's fori_loop).
+    noise = (gumbel [B*S, k, nc], eps [B*S, k]) -> (z [B*S, k], repeated context Feat for log_prob_n)"""
+    gumbel, eps = noise
+    R, k = eps.shape
+    nc = self._num_components
+    ctx = feat.t.reshape(feat.t.shape[0], -1)
+    if feat.in_act != ACT_NONE:
+        raise NotImplementedError("AutoregressiveGMM expects a materialised context")
+    rep = self.buf(f"ctx_rep_{tag}", (R, ctx.shape[1]))
+    ops.repeat_rows(ctx, rep, S)
+    z = self.buf(f"z_n_{tag}", (R, k))
+    ops.fill_zero(z)
+    rfeat = Feat(rep, feat.in_act, feat.grad_act)
+    for i in range(k):
+        self.log_prob(rfeat, z)                       # leaves the stacked head [k*R, 3nc] in self._head
+        ops.gmm_sample_step(self._head, gumbel, eps, z, nc, i)
+    return z, rfeat
+
+
+def _argmm_log_prob_n(self, rfeat: Feat, z: torch.Tensor, tag: str) -> torch.Tensor:
+    lp = self.buf(f"lp_n_{tag}", (z.shape[0],))
+    lp.copy_(self.log_prob(rfeat, z))
+    return lp
+
+
+AutoregressiveGMM.sample_n = _argmm_sample_n
+AutoregressiveGMM.log_prob_n = _argmm_log_prob_n
 
 _DISTRIBUTIONS = {
     "Bernoulli": Bernoulli,

@@ -128,6 +128,92 @@ class PosteriorMatchingVAE(Module):
         self._z = z
         return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll}
 
+    # ------------------------------------------------------------------------------------------
+    # evaluation paths.  S samples per example are laid out sample-minor on the row axis.
+    def _eval_noise(self, B: int, S: int, noise, seed, need_posterior: bool):
+        """noise: {"eps" [B,S,k], "gumbel" [B,S,k,nc] (AutoregressiveGMM only), "eps_posterior" [B,S,k]} - drawn on the
+        device from Philox streams keyed by `seed` when not given (the reference draws from hk.next_rng_key())."""
+        k, dev = self.latent_dim, self.store.device
+        noise = dict(noise or {})
+        seed = self._seed if seed is None else seed
+        step = getattr(self, "_eval_step", None)
+        if step is None:
+            step = self._eval_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        drew = False
+        if "eps" not in noise:
+            noise["eps"] = torch.empty((B, S, k), device=dev)
+            ops.normal_fill(noise["eps"], seed, step, stream_id=11)
+            drew = True
+        if isinstance(self.partial_posterior_dist, AutoregressiveGMM) and "gumbel" not in noise:
+            noise["gumbel"] = torch.empty((B, S, k, self.partial_posterior_dist._num_components), device=dev)
+            ops.gumbel_fill(noise["gumbel"], seed, step, stream_id=12)
+            drew = True
+        if need_posterior and "eps_posterior" not in noise:
+            noise["eps_posterior"] = torch.empty((B, S, k), device=dev)
+            ops.normal_fill(noise["eps_posterior"], seed, step, stream_id=13)
+            drew = True
+        if drew:
+            ops.counter_increment(step)
+        return {n: t.reshape((B * S,) + tuple(t.shape[2:])).contiguous() for n, t in noise.items()}
+
+    def _partial_posterior_samples(self, x_o: torch.Tensor, b: torch.Tensor, nz, S: int):
+        xob = self.ws.get("x_o_b", tuple(x_o.shape[:-1]) + (x_o.shape[-1] + b.shape[-1],))
+        ops.mask_concat(x_o, b, xob)                      # x_o * b, b  (vae.py:158-159: x_o *= b)
+        pfeat = self.partial_encoder_net(Feat(xob), is_training=False)
+        pp = self.partial_posterior_dist
+        if isinstance(pp, AutoregressiveGMM):
+            return pp.sample_n(pfeat, (nz["gumbel"], nz["eps"]), S, "pp")
+        return pp.sample_n(pfeat, nz["eps"], S, "pp")
+
+    def impute(self, x_o: torch.Tensor, b: torch.Tensor, num_samples: int = 100, noise=None,
+               seed: Optional[int] = None) -> torch.Tensor:
+        """reference vae.py:146-169: imputations [num_samples, *x_o.shape]: observed values where b == 1, the decoder
+        mean of a partial-posterior sample elsewhere."""
+        if self.store is None:
+            self.init(x_o.shape[1:], x_o.device)
+        B, S = x_o.shape[0], int(num_samples)
+        nz = self._eval_noise(B, S, noise, seed, need_posterior=False)
+        z, _ = self._partial_posterior_samples(x_o, b, nz, S)
+        dec = self.decoder_net(Feat(z), is_training=False)
+        mean = self.decoder_dist.mean(dec)
+        imp = self.ws.get("imputations", (B, S) + tuple(x_o.shape[1:]))
+        imp.view(-1).copy_(mean.reshape(-1))
+        ops.impute_blend(x_o, b, imp, lo=1.0, hi=0.0)       # lo > hi: no clipping
+        return imp.transpose(0, 1)
+
+    def is_log_prob(self, x: torch.Tensor, b: torch.Tensor, num_samples: int = 100, noise=None,
+                    seed: Optional[int] = None):
+        """reference vae.py:171-226: importance-sampled (log p(x), log p(x_u | x_o)), each [B]."""
+        if self.store is None:
+            self.init(x.shape[1:], x.device)
+        B, S = x.shape[0], int(num_samples)
+        nz = self._eval_noise(B, S, noise, seed, need_posterior=True)
+        post, pp, dd = self.posterior_dist, self.partial_posterior_dist, self.decoder_dist
+        # q(z | x): samples, log q, log p(z), log p(x | z)
+        feat = self.encoder_net(Feat(x), is_training=False)
+        z, rep = post.sample_n(feat, nz["eps_posterior"], S, "post")
+        log_q = post.log_prob_n(rep, z, "post")
+        log_pz = self.ws.get("is_log_pz", (B * S,))
+        ops.std_normal_logprob(z, log_pz)
+        dec = self.decoder_net(Feat(z), is_training=False)
+        log_px = dd.log_prob_rep(dec, x, None, S, "x")
+        log_p_x = self.ws.get("is_log_p_x", (B,))
+        ops.logmeanexp3(log_px, log_pz, log_q, log_p_x, S)
+        # q(z | x_o): the same with the observed dimensions only
+        z_o, rep_o = self._partial_posterior_samples(x, b, nz, S)
+        log_q_o = pp.log_prob_n(rep_o, z_o, "pp")
+        log_pz_o = self.ws.get("is_log_pz_o", (B * S,))
+        ops.std_normal_logprob(z_o, log_pz_o)
+        dec_o = self.decoder_net(Feat(z_o), is_training=False)
+        log_pxo = dd.log_prob_rep(dec_o, x, b, S, "xo")
+        log_p_xo = self.ws.get("is_log_p_xo", (B,))
+        ops.logmeanexp3(log_pxo, log_pz_o, log_q_o, log_p_xo, S)
+        neg = self.ws.get("is_neg_log_p_xo", (B, 1))
+        ops.scale_shift(log_p_xo.view(B, 1), -1.0, 0.0, neg)
+        out = self.ws.get("is_log_p_xu_xo", (B, 1))
+        ops.add_cols(log_p_x.view(B, 1), neg, 0, out)       # log p(x_u | x_o) = log p(x) - log p(x_o)
+        return log_p_x, out.view(B)
+
     def _side_stream(self, device) -> "torch.cuda.Stream":
         if not self.concurrent:
             return torch.cuda.current_stream(device)

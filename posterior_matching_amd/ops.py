@@ -688,6 +688,43 @@ def imputation_psnr(imp, x, psnr, scale: float = 1.0) -> None:
     _call("pm_imputation_psnr", _ptr(imp), _ptr(x), _ptr(psnr), B, S, x.numel() // B, scale)
 
 
+# ---- PM-VAE evaluation paths (csrc/pm_eval.hip) ------------------------------------------------------------
+def repeat_rows(src, dst, S: int) -> None:
+    """dst[b*S + s, :] = src[b, :]"""
+    B = src.shape[0]
+    _call("pm_repeat_rows", _ptr(src), _ptr(dst), B, S, src.numel() // B)
+
+
+def sigmoid(inp, out) -> None:
+    _call("pm_sigmoid", _ptr(inp), _ptr(out), inp.numel())
+
+
+def bernoulli_ll_rep_fwd(logits, x, w, ll, S: int) -> None:
+    B = x.shape[0]
+    D = x.numel() // B
+    _call("pm_bernoulli_ll_rep_fwd", _ptr(logits), _ptr(x), _ptr(w), _ptr(ll), B, S, D, (w.numel() // B) if w is not None else D)
+
+
+def normal_ll_rep_fwd(loc, x, log_scale, w, ll, S: int, scale_eps: float = 0.0) -> None:
+    B = x.shape[0]
+    D = x.numel() // B
+    _call("pm_normal_ll_rep_fwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(w), _ptr(ll), B, S, D,
+          (w.numel() // B) if w is not None else D, float(scale_eps))
+
+
+def std_normal_logprob(z, lp) -> None:
+    _call("pm_std_normal_logprob", _ptr(z), _ptr(lp), z.shape[0], z.shape[1])
+
+
+def logmeanexp3(a, b, c, out, S: int) -> None:
+    _call("pm_logmeanexp3", _ptr(a), _ptr(b), _ptr(c), _ptr(out), out.numel(), S)
+
+
+def gmm_sample_step(head, gumbel, eps, z, nc: int, i: int) -> None:
+    R, k = z.shape
+    _call("pm_gmm_sample_step", _ptr(head), _ptr(gumbel), _ptr(eps), _ptr(z), R, k, nc, i)
+
+
 def image_mask_mixture(mask, comps, seed: int, step_dev=None, stream_id: int = 0, desc_out=None) -> None:
     """mask [B,H,W,1] f32; comps: ctypes array of _lib.MaskComponent (host memory, copied into the launch)"""
     B, H, W = mask.shape[0], mask.shape[1], mask.shape[2]

@@ -554,6 +554,14 @@ def test_train_script_end_to_end(tmp_path):
     sys.path.insert(0, root)
     state = pickle.load(open(os.path.join(run, "train_state.pkl"), "rb"))
     assert state.step == 30 and len(state.params) == 37
+    # eval_pm_vae_uci.py on that run: imputation NRMSE + arbitrary-conditional log-likelihood (device-side masks)
+    out = subprocess.run([sys.executable, os.path.join(root, "eval_pm_vae_uci.py"), "--run_dir", run, "--dataset", "gas",
+                          "--num_instances", "128", "--batch_size", "32", "--num_samples", "16", "--num_trials", "2"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    nrmse = np.load(os.path.join(run, "uci_results", "nrmse.npy"))
+    ac = np.load(os.path.join(run, "uci_results", "ac_lls.npy"))
+    assert nrmse.shape == (2,) and ac.shape == (2,) and np.isfinite(nrmse).all() and np.isfinite(ac).all()
 
 
 # ----------------------------------------------------------------------------------------------

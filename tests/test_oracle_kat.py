@@ -502,3 +502,32 @@ def test_mask_oracle_semantics():
     assert u.sum(1).max() <= 7 and u.sum(1).min() == 0                          # q = choice(8) is 0..7
     b = MO.bernoulli_mask((200, 50), 0.3, seed=4)
     assert abs(b.mean() - 0.3) < 0.02
+
+
+def test_is_log_prob_and_impute_oracle_properties():
+    """vae.py:146-226 on the oracle: with every feature observed log p(x_u | x_o) = log p(x) - log p(x_o) uses the full
+    decoder likelihood on both sides; with nothing observed log p(x_o) is the logmeanexp of p(z)/q(z) ~ 0 and imputations
+    are pure decoder means; observed entries always pass through."""
+    import torch
+
+    from oracle import pm_vae_oracle as O
+    from tests.ref_configs import pm_vae_gas
+
+    cfg = pm_vae_gas()
+    p = O.init_params(cfg["model"], (8,), seed=2)
+    gen = torch.Generator().manual_seed(0)
+    B, S, k = 5, 64, cfg["model"]["latent_dim"]
+    x = torch.randn((B, 8), generator=gen, dtype=torch.float64)
+    noise = {"eps": torch.randn((B, S, k), generator=gen, dtype=torch.float64),
+             "eps_posterior": torch.randn((B, S, k), generator=gen, dtype=torch.float64)}
+    ones, zeros = torch.ones_like(x), torch.zeros_like(x)
+    imp = O.pm_vae_impute(p, cfg["model"], x, ones, noise)
+    assert imp.shape == (S, B, 8) and torch.equal(imp, x[None].expand(S, B, 8))
+    imp0 = O.pm_vae_impute(p, cfg["model"], x, zeros, noise)
+    assert (imp0.std(0) > 0).all()                          # nothing observed: every entry is a decoder mean of a sample
+    lx, lxu = O.pm_vae_is_log_prob(p, cfg["model"], x, zeros, noise)
+    assert torch.isfinite(lx).all()
+    # nothing observed: p(x_o) = E_q[p(z)/q(z)] -> log p(x_u | x_o) ~ log p(x) up to the estimator's noise
+    assert (lxu - lx).abs().max() < 5.0
+    score = O.nrmse_score(imp0.mean(0).numpy()[None], x.numpy()[None], zeros.numpy()[None])
+    assert score.shape == (1,)
