@@ -298,7 +298,7 @@ class AutoregressiveGMM(Module):
         hf = self._hfeat
         self.wgrad(self.g_head, hf.t, dhead, self.G("gmm/linear/w"), self.G("gmm/linear/b"), in_act=hf.in_act,
                         **self._group_kw(B))
-        dh = self.buf("dh_last", (k * B, hu))
+        dh = self.mlp.out_grad_buffer(k * B)          # the MLP's grouped weight-gradient launch reads it in place
         ops.layer_dgrad(self.g_head, dhead, self.P("gmm/linear/w"), dh, aux=hf.t, aux_act=hf.grad_act,
                         wsplit=self.store.split_view(self._ws_head[1]), **self._group_kw(B))
         dinp = self.mlp.backward(dh, need_input_grad=True)

@@ -180,43 +180,80 @@ class ResidualMLP(Module):
     def _wsd(self, name):
         return self.store.split_view(self._ws[name][1])
 
+    # The 2*N hidden linears (hu -> hu) all see [rows, hu] operands and their weights / biases are adjacent in the flat
+    # parameter buffer, so their weight gradients run as ONE grouped launch at the end of backward (4 launches of 256
+    # workgroups -> 1 launch of 1024: the per-launch floor is paid once and the chip holds 4 waves per SIMD).  For that
+    # the layer inputs and the output gradients live in two strided buffers:
+    #   xs[2k] = h_k, xs[2k+1] = u_k          (inputs of block_k/linear_0, block_k/linear_1; relu applied on load)
+    #   dys[2k] = du_k, dys[2k+1] = dh_{k+1}  (gradients w.r.t. the outputs of the same two layers)
+    def _grouped(self) -> bool:
+        if self._residual_blocks == 0:
+            return False
+        if getattr(self, "_grouped_ok", None) is None:
+            hu, off = self._hidden_units, self.store.offsets
+            names = [f"{self.prefix}/block_{k}/linear_{j}" for k in range(self._residual_blocks) for j in range(2)]
+            w0, b0 = off[names[0] + "/w"][0], off[names[0] + "/b"][0]
+            self._grouped_ok = all(off[n + "/w"][0] == w0 + i * hu * hu and off[n + "/b"][0] == b0 + i * hu
+                                   for i, n in enumerate(names))
+        return self._grouped_ok
+
+    def out_grad_buffer(self, rows: int) -> torch.Tensor:
+        """where the caller should write the gradient w.r.t. this network's output so that backward() needs no copy"""
+        nb, hu = self._residual_blocks, self._hidden_units
+        if nb == 0:
+            return self.buf("dh_out", (rows, hu))
+        return self.buf("dys_all", (2 * nb, rows, hu))[2 * nb - 1]
+
     def __call__(self, x: Feat, is_training: bool = False) -> Feat:
-        rows, hu = x.t.shape[0], self._hidden_units
+        rows, hu, nb = x.t.shape[0], self._hidden_units, self._residual_blocks
         self._x = x
-        h = self.buf("h_0", (rows, hu))
+        xs = self.buf("xs_all", (2 * nb + 1, rows, hu))
+        h = xs[0]
         ops.layer_forward(self.g_in, x.t, self.P("linear_0/w"), self.P("linear_0/b"), h, in_act=x.in_act,
                           wsplit=self._wsf("linear_0"))
         self._h, self._u = [h], []
-        for k in range(self._residual_blocks):
-            u = self.buf(f"u_{k}", (rows, hu))
+        for k in range(nb):
+            u = xs[2 * k + 1]
             ops.layer_forward(self.g_hid, h, self.P(f"block_{k}/linear_0/w"), self.P(f"block_{k}/linear_0/b"), u,
                               in_act=ACT_RELU, wsplit=self._wsf(f"block_{k}/linear_0"))
-            hn = self.buf(f"h_{k + 1}", (rows, hu))
+            hn = xs[2 * k + 2]
             ops.layer_forward(self.g_hid, u, self.P(f"block_{k}/linear_1/w"), self.P(f"block_{k}/linear_1/b"), hn,
                               in_act=ACT_RELU, res=h, wsplit=self._wsf(f"block_{k}/linear_1"))
             self._u.append(u)
             self._h.append(hn)
             h = hn
+        self._xs = xs
         if self._activate_final:
             return Feat(h, ACT_RELU, ACT_RELU)
         return Feat(h, ACT_NONE, ACT_NONE)
 
     def backward(self, dh: torch.Tensor, need_input_grad: bool = False) -> Optional[torch.Tensor]:
         """dh: gradient w.r.t. the stored pre-activation h of the last block."""
-        rows, hu = dh.shape[0], self._hidden_units
-        for k in reversed(range(self._residual_blocks)):
+        rows, hu, nb = dh.shape[0], self._hidden_units, self._residual_blocks
+        grouped = self._grouped()
+        if nb > 0:
+            dys = self.buf("dys_all", (2 * nb, rows, hu))
+            if grouped and dh.data_ptr() != dys[2 * nb - 1].data_ptr():
+                ops.copy_cols(dh.reshape(rows, hu), dys[2 * nb - 1], 0)   # callers that did not use out_grad_buffer()
+                dh = dys[2 * nb - 1]
+        for k in reversed(range(nb)):
             h, u = self._h[k], self._u[k]
-            self.wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),
-                            in_act=ACT_RELU)
-            du = self.buf(f"du_{k}", (rows, hu))
+            if not grouped:
+                self.wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),
+                           in_act=ACT_RELU)
+            du = dys[2 * k]
             ops.layer_dgrad(self.g_hid, dh, self.P(f"block_{k}/linear_1/w"), du, aux=u, aux_act=ACT_RELU,
                             wsplit=self._wsd(f"block_{k}/linear_1"))
-            self.wgrad(self.g_hid, h, du, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"),
-                            in_act=ACT_RELU)
-            dprev = self.buf(f"dh_{k}", (rows, hu))
+            if not grouped:
+                self.wgrad(self.g_hid, h, du, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"),
+                           in_act=ACT_RELU)
+            dprev = dys[2 * k - 1] if k > 0 else self.buf("dh_0", (rows, hu))
             ops.layer_dgrad(self.g_hid, du, self.P(f"block_{k}/linear_0/w"), dprev, aux=h, aux_act=ACT_RELU, res=dh,
                             wsplit=self._wsd(f"block_{k}/linear_0"))
             dh = dprev
+        if grouped:
+            self.wgrad(self.g_hid, self._xs, dys, self.G("block_0/linear_0/w"), self.G("block_0/linear_0/b"),
+                       in_act=ACT_RELU, B=rows, groups=2 * nb, in_gs=rows * hu, out_gs=rows * hu, w_gs=hu * hu, bias_gs=hu)
         self.wgrad(self.g_in, self._x.t, dh, self.G("linear_0/w"), self.G("linear_0/b"), in_act=self._x.in_act)
         if need_input_grad:
             dx = self.buf("dx", (rows, self.g_in.CI))

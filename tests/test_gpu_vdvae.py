@@ -356,7 +356,7 @@ def test_train_and_eval_vdvae_scripts_end_to_end(tmp_path):
         return out.stdout
 
     run("train_pm_vdvae.py", "--config", os.path.join(root, "configs", "pm_vdvae_mnist.py"), "--config.steps=6",
-        "--config.validation_freq=3", "--config.seed=2", "--config.model.width=32", "--config.model.latent_dim=4",
+        "--device_masks", "--config.validation_freq=3", "--config.seed=2", "--config.model.width=32", "--config.model.latent_dim=4",
         "--config.data.train_batch_size=4", "--config.data.val_batch_size=4",
         "--config.model.encoder_blocks=28x1,28d2,14x1,14d2,7x1,7d2,3x1,3d2,1x1",
         "--config.model.decoder_blocks=1x1,3m1,3x1,7m3,7x1,14m7,14x1,28m14,28x1")

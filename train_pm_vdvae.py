@@ -58,6 +58,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
     ap.add_argument("--data", default=None, help="optional .npy with raw-pixel training examples")
+    ap.add_argument("--device_masks", action="store_true",
+                    help="draw a fresh mask for every training batch on the GPU (pm_image_mask_mixture & co.) "
+                         "instead of cycling host-generated masks")
     args, rest = ap.parse_known_args()
     config = load_config_file(args.config)
     apply_overrides(config, [r[len("--config."):] for r in rest if r.startswith("--config.")])
