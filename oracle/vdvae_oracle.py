@@ -359,6 +359,107 @@ def vdvae_impute(p: Params, cfg: dict, x: Tensor, b: Tensor, eps: Sequence[Seque
     return torch.stack(outs, dim=1)
 
 
+def _diag_log_prob(z: Tensor, loc: Tensor, raw: Tensor) -> Tensor:
+    """tfd.Independent(MultivariateNormalDiag(loc, softplus(raw) + 1e-5)).log_prob(z): sum over latent dims and positions"""
+    scale = softplus(raw) + 1e-5
+    lp = -0.5 * ((z - loc) / scale) ** 2 - torch.log(scale) - 0.5 * math.log(2 * math.pi)
+    return lp.reshape(z.shape[0], -1).sum(1)
+
+
+def _tril_log_prob(z: Tensor, loc: Tensor, tril: Tensor) -> Tensor:
+    """tfd.Independent(MultivariateNormalTriL(loc, tril)).log_prob(z) summed over positions"""
+    k = z.shape[-1]
+    d = torch.linalg.solve_triangular(tril, (z - loc).unsqueeze(-1), upper=False).squeeze(-1)
+    lp = -0.5 * (d ** 2).sum(-1) - torch.log(torch.diagonal(tril, dim1=-2, dim2=-1)).sum(-1) - 0.5 * k * math.log(2 * math.pi)
+    return lp.reshape(z.shape[0], -1).sum(1)
+
+
+def vdvae_is_log_probs(p: Params, cfg: dict, x: Tensor, b: Tensor, eps: Sequence[Sequence[Tensor]],
+                       eps_masked: Sequence[Sequence[Tensor]]):
+    """PosteriorMatchingVDVAE.is_log_probs (vdvae.py:96-146) with PosteriorMatchingDecoder.forward_lls (:844-855),
+    PosteriorMatchingDecoderBlock.forward_lls (:725-754) and .sample_lls (:609-660).  Two decoder states are carried:
+    x (driven by the full posterior q(z | x)) and masked_x (driven by the masked posterior q(z | x_o)); the prior
+    block is evaluated on each.  eps[s][i] / eps_masked[s][i]: the N(0,1) draws of sample s, decoder block i, behind
+    posterior.sample / masked_posterior.sample.  -> (log p(x) [B], log p(x_u | x_o) [B])."""
+    Z, size = cfg.get("latent_dim", 16), cfg["image_shape"][0]
+    nm = cfg.get("num_mixtures", 10)
+    xn = x / 127.5 - 1.0
+    acts = encoder(p, "encoder", xn, cfg)
+    macts = encoder(p, "masked_encoder", torch.cat([xn * b, b], -1), cfg)
+    blocks = parse_layer_string(cfg["decoder_blocks"])
+    resolutions = sorted({r for r, _ in blocks})
+    pxs, pxos = [], []
+    for es, ems in zip(eps, eps_masked):
+        xs = {r: p[f"decoder/x_bias_{r}"] for r in resolutions if r <= cfg.get("no_bias_above", 64)}
+        mxs = dict(xs)
+        pz = qzx = mpz = mqzx = 0.0
+        for i, (res, mixin) in enumerate(blocks):
+            a, ma = acts[res], macts[res]
+            W = a.shape[-1]
+            n = f"decoder/block_{i}"
+            use3 = res > 2
+
+            def start(state):
+                v = state[res] if res in state else torch.zeros_like(a)
+                if v.shape[0] != a.shape[0]:
+                    v = v.expand(a.shape[0], -1, -1, -1)
+                if mixin is not None:
+                    v = v + resize_nearest(state[mixin][..., :W], (res, res))
+                return v
+
+            xx, mx = start(xs), start(mxs)
+            pp = block(p, f"{n}/posterior", torch.cat([xx, a], -1), use3, False)
+            mp = block(p, f"{n}/masked_posterior", torch.cat([mx, ma], -1), use3, False)
+            pr = block(p, f"{n}/prior", xx, use3, False)
+            mpr = block(p, f"{n}/prior", mx, use3, False)
+            xx = xx + pr[..., 2 * Z:]
+            mx = mx + mpr[..., 2 * Z:]
+            z = pp[..., :Z] + (softplus(pp[..., Z:]) + 1e-5) * es[i]
+            m_tril = fill_scale_tril(mp[..., Z:])
+            mz = mp[..., :Z] + (m_tril @ ems[i].unsqueeze(-1)).squeeze(-1)
+            pz = pz + _diag_log_prob(z, pr[..., :Z], pr[..., Z:2 * Z])
+            qzx = qzx + _diag_log_prob(z, pp[..., :Z], pp[..., Z:])
+            mpz = mpz + _diag_log_prob(mz, mpr[..., :Z], mpr[..., Z:2 * Z])
+            mqzx = mqzx + _tril_log_prob(mz, mp[..., :Z], m_tril)
+            xx = xx + conv1x1(p, f"{n}/z_proj", z)
+            mx = mx + conv1x1(p, f"{n}/z_proj", mz)
+            xs[res] = block(p, f"{n}/resnet", xx, use3, True)
+            mxs[res] = block(p, f"{n}/resnet", mx, use3, True)
+        prm = conv1x1(p, "decoder/out_net", xs[size] * p["decoder/gain"] + p["decoder/bias"])
+        mprm = conv1x1(p, "decoder/out_net", mxs[size] * p["decoder/gain"] + p["decoder/bias"])
+        pxz = logistic_mixture_log_prob(prm, x, nm)
+        pxoz = (logistic_mixture_log_prob(mprm, x, nm, independent=False).unsqueeze(-1) * b).reshape(x.shape[0], -1).sum(1)
+        pxs.append(pxz + pz - qzx)
+        pxos.append(pxoz + mpz - mqzx)
+    S = len(pxs)
+    px = torch.logsumexp(torch.stack(pxs, 0), 0) - math.log(S)
+    pxo = torch.logsumexp(torch.stack(pxos, 0), 0) - math.log(S)
+    return px, px - pxo
+
+
+def vdvae_sample(p: Params, cfg: dict, eps: Sequence[Tensor]) -> Tensor:
+    """PosteriorMatchingVDVAE.sample (vdvae.py:148-159): forward_prior (:835-842, :705-723, :593-607) then the decoder
+    distribution's mean.  eps[i] [N,res,res,Z]: the draw behind prior.sample of decoder block i."""
+    Z, size = cfg.get("latent_dim", 16), cfg["image_shape"][0]
+    blocks = parse_layer_string(cfg["decoder_blocks"])
+    resolutions = sorted({r for r, _ in blocks})
+    N = eps[0].shape[0]
+    W = cfg.get("width", 128)
+    xs = {r: p[f"decoder/x_bias_{r}"].expand(N, -1, -1, -1) for r in resolutions if r <= cfg.get("no_bias_above", 64)}
+    for i, (res, mixin) in enumerate(blocks):
+        n = f"decoder/block_{i}"
+        xx = xs[res] if res in xs else torch.zeros((N, res, res, W), dtype=eps[0].dtype)
+        if mixin is not None:
+            xx = xx + resize_nearest(xs[mixin][..., :W], (res, res))
+        pr = block(p, f"{n}/prior", xx, res > 2, False)
+        xx = xx + pr[..., 2 * Z:]
+        z = pr[..., :Z] + (softplus(pr[..., Z:2 * Z]) + 1e-5) * eps[i]
+        xx = xx + conv1x1(p, f"{n}/z_proj", z)
+        xs[res] = block(p, f"{n}/resnet", xx, res > 2, True)
+    prm = conv1x1(p, "decoder/out_net", xs[size] * p["decoder/gain"] + p["decoder/bias"])
+    return logistic_mixture_mean(prm, cfg.get("num_mixtures", 10))
+
+
 def imputation_psnr(imputations: Tensor, x: Tensor) -> Tensor:
     err = ((imputations.mean(1) / 255.0 - x / 255.0) ** 2).reshape(x.shape[0], -1).mean(1)
     return -10.0 * torch.log10(err)

@@ -138,8 +138,10 @@ SIGNATURES = {
     "pm_bernoulli_ll_rep_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "pm_normal_ll_rep_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F],
     "pm_std_normal_logprob": [_P, _P, _P, _LL, _I],
-    "pm_logmeanexp3": [_P, _P, _P, _P, _P, _I, _I],
+    "pm_logmeanexp3": [_P, _P, _P, _P, _P, _I, _I, _I],
     "pm_gmm_sample_step": [_P, _P, _P, _P, _P, _LL, _I, _I, _I],
+    "pm_diag_logprob_acc": [_P, _P, _I, _P, _P, _LL, _I, _I, _F],
+    "pm_segment_wsum": [_P, _P, _P, _P, _I, _I, _F, _I],
     "pm_image_mask_mixture": [_P, _P, _I, _I, _I, C.POINTER(MaskComponent), _I, C.c_ulonglong, _P, _I, _P],
     "pm_bernoulli_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
     "pm_uniform_mask": [_P, _P, _I, _I, _I, _I, C.c_ulonglong, _P, _I],

@@ -86,22 +86,23 @@ __global__ __launch_bounds__(256) void std_normal_logprob_kernel(const float* __
 
 // out[b] = log mean_s exp(a[b,s] + bb[b,s] - c[b,s])   (tfp.math.reduce_logmeanexp over the sample axis)
 __global__ __launch_bounds__(64) void logmeanexp3_kernel(const float* __restrict__ a, const float* __restrict__ bb,
-                                                           const float* __restrict__ c, float* __restrict__ out, int S) {
+                                                           const float* __restrict__ c, float* __restrict__ out, int S,
+                                                           long long sb, long long ss) {
     const int b = blockIdx.x;
-    const size_t base = (size_t)b * S;
+    const size_t base = (size_t)b * sb;
     float m = -INFINITY;
     for (int s = threadIdx.x; s < S; s += 64) {
-        float v = a[base + s];
-        if (bb) v += bb[base + s];
-        if (c) v -= c[base + s];
+        float v = a[base + s * ss];
+        if (bb) v += bb[base + s * ss];
+        if (c) v -= c[base + s * ss];
         m = fmaxf(m, v);
     }
     m = pm_wave_max(m);
     float acc = 0.f;
     for (int s = threadIdx.x; s < S; s += 64) {
-        float v = a[base + s];
-        if (bb) v += bb[base + s];
-        if (c) v -= c[base + s];
+        float v = a[base + s * ss];
+        if (bb) v += bb[base + s * ss];
+        if (c) v -= c[base + s * ss];
         acc += (m == -INFINITY) ? 0.f : expf(v - m);
     }
     acc = pm_wave_sum(acc);
@@ -129,7 +130,56 @@ __global__ __launch_bounds__(256) void gmm_sample_step_kernel(const float* __res
     z[r * k + i] = h[nc + best] + (pm_softplus(h[2 * nc + best]) + 1e-5f) * eps[r * k + i];
 }
 
+// out[r / P] += sign * sum_j log N(z[r, j]; loc[r, j], softplus(raw[r, j]) + 1e-5): params rows of stride ld = (loc | raw | ...)
+__global__ __launch_bounds__(256) void diag_logprob_acc_kernel(const float* __restrict__ params, int ld,
+                                                                const float* __restrict__ z, float* __restrict__ out,
+                                                                long long R, int Z, int P, float sign) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float t = 0.f;
+    long long r = 0;
+    if (i < R * Z) {
+        r = i / Z;
+        const int j = (int)(i - r * Z);
+        const float loc = params[r * ld + j], sc = pm_softplus(params[r * ld + Z + j]) + 1e-5f;
+        const float u = (z[i] - loc) / sc;
+        t = sign * (-0.5f * u * u - logf(sc) - 0.5f * kLog2Pi);
+    }
+    if (Z == 16) {       // the 16 lanes of a row reduce by shuffle, then one atomic per row
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (i < R * Z && (threadIdx.x & 15) == 0) atomicAdd(out + r / P, t);
+    } else if (i < R * Z) {
+        atomicAdd(out + r / P, t);
+    }
+}
+
+// out[b] (+)= sign * sum_p v[b*P + p] * (w ? w[b*P + p] : 1)
+__global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restrict__ v, const float* __restrict__ w,
+                                                            float* __restrict__ out, int P, float sign, int accumulate) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * P;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) s += w ? v[base + p] * w[base + p] : v[base + p];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.f) + sign * s;
+}
+
 }  // namespace
+
+extern "C" int pm_diag_logprob_acc(pm_stream_t stream, const float* params, int ld, const float* z, float* out,
+                                   long long rows, int Z, int P, float sign) {
+    if (!params || !z || !out || rows <= 0 || Z <= 0 || P <= 0 || ld < 2 * Z) return PM_EINVAL;
+    hipLaunchKernelGGL(diag_logprob_acc_kernel, dim3((unsigned)((rows * Z + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       params, ld, z, out, rows, Z, P, sign);
+    return pm_check_launch("pm_diag_logprob_acc");
+}
+
+extern "C" int pm_segment_wsum(pm_stream_t stream, const float* v, const float* w, float* out, int B, int P, float sign,
+                               int accumulate) {
+    if (!v || !out || B <= 0 || P <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(segment_wsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, v, w, out, P, sign, accumulate);
+    return pm_check_launch("pm_segment_wsum");
+}
 
 extern "C" int pm_repeat_rows(pm_stream_t stream, const float* src, float* dst, long long B, int S, long long n) {
     if (!src || !dst || B <= 0 || S <= 0 || n <= 0) return PM_EINVAL;
@@ -171,9 +221,10 @@ extern "C" int pm_std_normal_logprob(pm_stream_t stream, const float* z, float* 
 }
 
 extern "C" int pm_logmeanexp3(pm_stream_t stream, const float* a, const float* b, const float* c, float* out, int B,
-                              int S) {
+                              int S, int sample_major) {
     if (!a || !out || B <= 0 || S <= 0) return PM_EINVAL;
-    hipLaunchKernelGGL(logmeanexp3_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a, b, c, out, S);
+    hipLaunchKernelGGL(logmeanexp3_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a, b, c, out, S,
+                       sample_major ? 1LL : (long long)S, sample_major ? (long long)B : 1LL);
     return pm_check_launch("pm_logmeanexp3");
 }
 

@@ -270,6 +270,69 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.gelu_fwd(x2, None, x2g)
         return self.resnet.forward(x2g, res=x2)
 
+    def forward_prior(self, x_in: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        """forward_prior / sample_prior (reference :705-723, :593-607): z = prior_loc + prior_scale * eps."""
+        B, r, W, Z = x_in.shape[0], self.base, self.width, self.Z
+        sh = lambda c: (B, r, r, c)   # noqa: E731
+        ap = self.buf("ap", sh(W))
+        ops.gelu_fwd(x_in, None, ap)
+        pr = self.prior.forward(ap)
+        x1 = self.buf("x1", sh(W))
+        ops.add_cols(x_in, pr, 2 * Z, x1)
+        # the prior's (loc | raw scale) columns as a [rows, 2Z] posterior-shaped operand of the sampling kernel
+        pq = self.buf("prior_as_post", sh(2 * Z))
+        zeros = self.buf("zeros_2z", sh(2 * Z))
+        ops.fill_zero(zeros)
+        ops.add_cols(zeros, pr, 0, pq)
+        z, scratch = self.buf("z", sh(Z)), self.buf("kl_scratch", (B,))
+        ops.fill_zero(scratch)
+        ops.diag_sample_kl_fwd(pq, pr, eps, z, scratch, r * r)
+        x2 = self.buf("x2", sh(W))
+        ops.layer_forward(self.z_proj.g, z, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
+                          wsplit=self.store.split_view(self.z_proj.ws_f))
+        x2g = self.buf("x2g", sh(W))
+        ops.gelu_fwd(x2, None, x2g)
+        return self.resnet.forward(x2g, res=x2)
+
+    def forward_lls(self, x_all: torch.Tensor, acts: torch.Tensor, macts: torch.Tensor, eps: torch.Tensor,
+                    eps_m: torch.Tensor, stats: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """forward_lls / sample_lls (reference :725-754, :609-660).  x_all [2B, r, r, W] stacks the two decoder states
+        the reference carries - rows [0, B): x (full posterior), rows [B, 2B): masked_x (masked posterior) - so the
+        shared prior / z_proj / resnet Blocks run once on 2B rows.  stats[name] [B] accumulate pz, qzx, masked_pz,
+        masked_qzx over the blocks."""
+        B2, r, W, Z = x_all.shape[0], self.base, self.width, self.Z
+        B, P = B2 // 2, r * r
+        sh = lambda n, c: (n, r, r, c)   # noqa: E731
+        x, mx = x_all[:B], x_all[B:]
+        a = self.buf("a", sh(B, 2 * W))
+        ops.gelu_fwd(x, acts, a)
+        pp = self.posterior.forward(a)
+        am = self.buf("am", sh(B, 2 * W))
+        ops.gelu_fwd(mx, macts, am)
+        mp = self.masked_posterior.forward(am)
+        ap = self.buf("ap_lls", sh(B2, W))
+        ops.gelu_fwd(x_all, None, ap)
+        pr = self.prior.forward(ap)                         # rows [0,B): prior(x), rows [B,2B): prior(masked_x)
+        x1 = self.buf("x1_lls", sh(B2, W))
+        ops.add_cols(x_all, pr, 2 * Z, x1)
+        z_all = self.buf("z_lls", sh(B2, Z))
+        z, mz = z_all[:B], z_all[B:]
+        scratch, scratch_p = self.buf("kl_scratch", (B,)), self.buf("tril_scratch", (B * P,))
+        ops.fill_zero(scratch)
+        ops.diag_sample_kl_fwd(pp, pr[:B], eps, z, scratch, P)
+        ops.tril_sample_kl_fwd(mp.view(B * P, -1), eps_m.view(B * P, Z), mz.view(B * P, Z), scratch_p)
+        ops.diag_logprob_acc(pr[:B], z, stats["pz"], P)
+        ops.diag_logprob_acc(pp, z, stats["qzx"], P)
+        ops.diag_logprob_acc(pr[B:], mz, stats["masked_pz"], P)
+        ops.tril_logprob_fwd(mp.view(B * P, -1), mz.view(B * P, Z), scratch_p)
+        ops.segment_wsum(scratch_p, None, stats["masked_qzx"], accumulate=True)
+        x2 = self.buf("x2_lls", sh(B2, W))
+        ops.layer_forward(self.z_proj.g, z_all, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
+                          wsplit=self.store.split_view(self.z_proj.ws_f))
+        x2g = self.buf("x2g_lls", sh(B2, W))
+        ops.gelu_fwd(x2, None, x2g)
+        return self.resnet.forward(x2g, res=x2)
+
     def backward(self, dx3: torch.Tensor, dacts: torch.Tensor, dmacts: torch.Tensor, g_kl: float, g_pm: float,
                  streams=None) -> torch.Tensor:
         """dx3: gradient w.r.t. this block's output.  Accumulates into dacts / dmacts (the encoder
@@ -483,6 +546,98 @@ class PosteriorMatchingVDVAE(Module):
             out[:, s].copy_(mean)
         ops.impute_blend(x, b, out, 1.0, 0.0)               # jnp.where(b == 1, x, mean): no clipping
         return out
+
+    def sample(self, num_samples: int, seed: int = 0, eps: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        """reference vdvae.py:148-159: unconditional samples, [num_samples, H, W, C] (decoder mean of a prior draw).
+        eps[i] [N,res,res,Z]: explicit prior noise (parity mode); otherwise device Philox keyed by seed."""
+        if self.store is None:
+            self.init(self._device)
+        c = self.config
+        N, nm = int(num_samples), c["num_mixtures"]
+        H, W_, C = c["image_shape"]
+        dev = self.store.device
+        xs: Dict[int, torch.Tensor] = {}
+        for i, blk in enumerate(self.dec_blocks):
+            r = blk.base
+            x_in = xs[r] if r in xs else self._start_state(xs, r, N)
+            if blk.mixin is not None:
+                ops.resize_nearest_add(xs[blk.mixin], x_in)
+            if eps is None:
+                e = self.ws.get(f"vdvae/sample_eps_{i}", (N, r, r, c["latent_dim"]))
+                ops.normal_fill(e, seed, None, stream_id=i)
+            else:
+                e = eps[i]
+            xs[r] = blk.forward_prior(x_in, e)
+        px_z = self.ws.get("decoder/px_z", tuple(xs[H].shape))
+        ops.affine_fwd(xs[H], self.store.p["decoder/gain"], self.store.p["decoder/bias"], px_z)
+        params = self.ws.get("decoder/dmol_params", (N, H, W_, 3 * nm))
+        ops.layer_forward(self.out_net.g, px_z, self.store.p[self.out_net.w], self.store.p[self.out_net.b], params,
+                          wsplit=self.store.split_view(self.out_net.ws_f))
+        out = torch.empty((N, H, W_, C), device=dev)
+        ops.dmol_mean(params, out, nm)
+        return out
+
+    def is_log_probs(self, x: torch.Tensor, b: torch.Tensor, num_samples: int = 100, seed: int = 0,
+                     eps: Optional[Sequence[Sequence[torch.Tensor]]] = None,
+                     eps_masked: Optional[Sequence[Sequence[torch.Tensor]]] = None):
+        """reference vdvae.py:96-146: importance-sampled (log p(x), log p(x_u | x_o)), each [B].  One decoder pass per
+        sample over the stacked states (see PosteriorMatchingDecoderBlock.forward_lls); eps[s][i] / eps_masked[s][i] are
+        the explicit draws of sample s, block i (parity mode), otherwise device Philox keyed by (seed, s)."""
+        if self.store is None:
+            self.init(x.device)
+        c = self.config
+        B, H, W_, C = x.shape
+        S, nm, Z = int(num_samples), c["num_mixtures"], c["latent_dim"]
+        xn = self.ws.get("vdvae/xn", tuple(x.shape))
+        ops.scale_shift(x, 1.0 / 127.5, -1.0, xn)
+        xob = self.ws.get("vdvae/x_o_b", (B, H, W_, 2))
+        ops.mask_concat(xn, b, xob)
+        acts = self.encoder(xn)
+        macts = self.masked_encoder(xob)
+        names = ("pz", "qzx", "masked_pz", "masked_qzx")
+        stats = {n: self.ws.get(f"vdvae/is_{n}", (B,)) for n in names}
+        comb = self.ws.get("vdvae/is_comb", (2, S, B))       # [0]: pz - qzx, [1]: masked_pz - masked_qzx, per sample
+        lls = self.ws.get("vdvae/is_lls", (2, S, B))         # [0]: log p(x | z), [1]: observed-pixel log p(x_o | z)
+        pix = self.ws.get("vdvae/is_pix_ll", (B * H * W_,))
+        noise = [[self.ws.get(f"vdvae/is_eps_{k}_{i}", (B, blk.base, blk.base, Z)) for i, blk in enumerate(self.dec_blocks)]
+                 for k in range(2)] if eps is None else None
+        for s in range(S):
+            for n in names:
+                ops.fill_zero(stats[n])
+            xs: Dict[int, torch.Tensor] = {}
+            for i, blk in enumerate(self.dec_blocks):
+                r = blk.base
+                x_in = xs[r] if r in xs else self._start_state(xs, r, 2 * B)
+                if blk.mixin is not None:
+                    ops.resize_nearest_add(xs[blk.mixin], x_in)
+                if eps is None:
+                    ops.normal_fill(noise[0][i], seed + 7919 * s, None, stream_id=2 * i)
+                    ops.normal_fill(noise[1][i], seed + 7919 * s, None, stream_id=2 * i + 1)
+                    e, em = noise[0][i], noise[1][i]
+                else:
+                    e, em = eps[s][i], eps_masked[s][i]
+                xs[r] = blk.forward_lls(x_in, acts[r], macts[r], e, em, stats)
+            px_z = self.ws.get("decoder/px_z", tuple(xs[H].shape))
+            ops.affine_fwd(xs[H], self.store.p["decoder/gain"], self.store.p["decoder/bias"], px_z)
+            params = self.ws.get("decoder/dmol_params", (2 * B, H, W_, 3 * nm))
+            ops.layer_forward(self.out_net.g, px_z, self.store.p[self.out_net.w], self.store.p[self.out_net.b], params,
+                              wsplit=self.store.split_view(self.out_net.ws_f))
+            ops.dmol_ll_fwd(params[:B], x, lls[0, s], nm, H * W_)
+            ops.dmol_ll_fwd(params[B:], x, pix, nm, 1)                               # log_prob(x, independent=False)
+            ops.segment_wsum(pix, b, lls[1, s])                                      # sum over the observed pixels
+            # px = pxz_ll + pz - qzx ; pxo = pxoz_ll + masked_pz - masked_qzx   (:134-140)
+            ops.scale_shift(stats["qzx"], -1.0, 0.0, comb[0, s])
+            ops.axpy1(stats["pz"], comb[0, s])
+            ops.scale_shift(stats["masked_qzx"], -1.0, 0.0, comb[1, s])
+            ops.axpy1(stats["masked_pz"], comb[1, s])
+        px, pxo = self.ws.get("vdvae/is_log_px", (B,)), self.ws.get("vdvae/is_log_pxo", (B,))
+        ops.logmeanexp3(lls[0], comb[0], None, px, S, sample_major=True)            # reduce_logmeanexp over the samples
+        ops.logmeanexp3(lls[1], comb[1], None, pxo, S, sample_major=True)
+        neg = self.ws.get("vdvae/is_neg", (B, 1))
+        ops.scale_shift(pxo.view(B, 1), -1.0, 0.0, neg)
+        out = self.ws.get("vdvae/is_pxu_xo", (B, 1))
+        ops.add_cols(px.view(B, 1), neg, 0, out)
+        return px, out.view(B)
 
     def reconstruction(self) -> torch.Tensor:
         """decoder_dist.mean() of the last call (reference :93)"""

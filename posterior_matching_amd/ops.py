@@ -716,13 +716,25 @@ def std_normal_logprob(z, lp) -> None:
     _call("pm_std_normal_logprob", _ptr(z), _ptr(lp), z.shape[0], z.shape[1])
 
 
-def logmeanexp3(a, b, c, out, S: int) -> None:
-    _call("pm_logmeanexp3", _ptr(a), _ptr(b), _ptr(c), _ptr(out), out.numel(), S)
+def logmeanexp3(a, b, c, out, S: int, sample_major: bool = False) -> None:
+    """out[b] = log mean_s exp(a + b - c); operands [B, S], or [S, B] with sample_major"""
+    _call("pm_logmeanexp3", _ptr(a), _ptr(b), _ptr(c), _ptr(out), out.numel(), S, int(sample_major))
 
 
 def gmm_sample_step(head, gumbel, eps, z, nc: int, i: int) -> None:
     R, k = z.shape
     _call("pm_gmm_sample_step", _ptr(head), _ptr(gumbel), _ptr(eps), _ptr(z), R, k, nc, i)
+
+
+def diag_logprob_acc(params, z, out, P: int, sign: float = 1.0) -> None:
+    """out[b] += sign * sum over the P positions of example b of log N(z; params[..., :Z], softplus(params[..., Z:2Z]) + 1e-5)"""
+    Z = z.shape[-1]
+    _call("pm_diag_logprob_acc", _ptr(params), params.shape[-1], _ptr(z), _ptr(out), z.numel() // Z, Z, P, float(sign))
+
+
+def segment_wsum(v, w, out, sign: float = 1.0, accumulate: bool = False) -> None:
+    B = out.numel()
+    _call("pm_segment_wsum", _ptr(v), _ptr(w), _ptr(out), B, v.numel() // B, float(sign), int(accumulate))
 
 
 def image_mask_mixture(mask, comps, seed: int, step_dev=None, stream_id: int = 0, desc_out=None) -> None:

@@ -339,6 +339,44 @@ def test_vdvae_impute_and_psnr_match_oracle():
     assert torch.equal(a, c) and a.min() >= 0 and a.max() <= 255
 
 
+def test_vdvae_is_log_probs_and_sample_match_oracle():
+    """PosteriorMatchingVDVAE.is_log_probs (reference vdvae.py:96-146, forward_lls / sample_lls :609-660,725-754) and
+    .sample (:148-159, forward_prior) with explicit noise.  The estimator sums O(100)-magnitude log terms over every
+    latent site before exponentiating: the yardstick is the float32-CPU oracle's own distance from float64."""
+    B, S = 3, 4
+    m, p64, x, b, _ = _setup(TINY, B, seed=14)
+    rng = np.random.default_rng(5)
+    eps = [[torch.tensor(rng.normal(size=s)) for s in m.eps_shapes(B)] for _ in range(S)]
+    eps_m = [[torch.tensor(rng.normal(size=s)) for s in m.eps_shapes(B)] for _ in range(S)]
+    want_px, want_pxu = DO.vdvae_is_log_probs(p64, TINY["model"], x, b, eps, eps_m)
+    p32 = {n: t.float() for n, t in p64.items()}
+    f32_px, f32_pxu = DO.vdvae_is_log_probs(p32, TINY["model"], x.float(), b.float(), [[e.float() for e in es] for es in eps],
+                                            [[e.float() for e in es] for es in eps_m])
+    got_px, got_pxu = m.is_log_probs(f32d(x), f32d(b), num_samples=S, eps=[[f32d(e) for e in es] for es in eps],
+                                     eps_masked=[[f32d(e) for e in es] for es in eps_m])
+    torch.cuda.synchronize()
+    scale = max(1.0, want_px.abs().max().item())
+    tol_px = max(1e-4 * scale, 20 * (f32_px.double() - want_px).abs().max().item())
+    tol_pxu = max(1e-4 * scale, 20 * (f32_pxu.double() - want_pxu).abs().max().item())
+    assert (got_px.cpu().double() - want_px).abs().max().item() < tol_px
+    assert (got_pxu.cpu().double() - want_pxu).abs().max().item() < tol_pxu
+    # device-noise path: finite and reproducible for a seed
+    a1 = [t.clone() for t in m.is_log_probs(f32d(x), f32d(b), num_samples=3, seed=9)]
+    a2 = m.is_log_probs(f32d(x), f32d(b), num_samples=3, seed=9)
+    # same noise for a seed; the per-example sums are float atomics, so the order of additions may differ between calls
+    assert all(torch.isfinite(t).all() for t in a1)
+    assert torch.allclose(a1[0], a2[0], atol=5e-3) and torch.allclose(a1[1], a2[1], atol=5e-3)
+    # unconditional samples
+    N = 5
+    eps_p = [torch.tensor(rng.normal(size=s)) for s in m.eps_shapes(N)]
+    want = DO.vdvae_sample(p64, TINY["model"], eps_p)
+    got = m.sample(N, eps=[f32d(e) for e in eps_p])
+    diff = (got.cpu().double() - want).abs()
+    assert got.shape == (N, 7, 7, 1) and (diff > 0).float().mean().item() < 0.02 and diff.max().item() <= 1.0
+    s1, s2 = m.sample(4, seed=2), m.sample(4, seed=2)
+    assert torch.equal(s1, s2) and s1.min() >= 0 and s1.max() <= 255
+
+
 def test_train_and_eval_vdvae_scripts_end_to_end(tmp_path):
     """train_pm_vdvae.py for a few steps on a small network, then eval_pm_vdvae_imputation.py on its checkpoint."""
     import json
@@ -374,3 +412,10 @@ def test_train_and_eval_vdvae_scripts_end_to_end(tmp_path):
     out = run("eval_pm_vdvae_imputation.py", "--run_dir", rd, "--num_instances", "8", "--batch_size", "4", "--num_samples", "2")
     res = json.loads(out.strip().splitlines()[-1])
     assert res["num_instances"] == 8 and np.isfinite(res["mean_psnr"]) and 0.0 < res["mean_psnr"] < 60.0
+    out = run("eval_pm_vdvae_likelihood.py", "--run_dir", rd, "--num_instances", "8", "--batch_size", "4", "--num_samples", "3",
+              "--num_trials", "2")
+    assert "BPD:" in out and "AC LL:" in out
+    lk = os.path.join(rd, "likelihood_results")
+    x_lls, bpd = np.load(os.path.join(lk, "x_lls.npy")), np.load(os.path.join(lk, "bpd.npy"))
+    assert x_lls.shape == (2, 8) and np.isfinite(x_lls).all() and (bpd > 0).all()
+    assert np.load(os.path.join(lk, "xo_lls.npy")).shape == (2, 8)
