@@ -58,6 +58,7 @@ struct WgradArgs {
     long long in_gs, w_gs, out_gs, bias_gs;
     int chunks_per_split;
     int step_b, step_p, step_q;  // 128 rows = step_b images + step_p rows + step_q pixels
+    int ntiles, nsplits, xcd_map;  // bf16 kernel: (k-block, n-block) tiles x m-splits, see the block-id remap there
 };
 
 constexpr int BK = 32;
@@ -1652,9 +1653,23 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
     const int wave = tid >> 6;
     const int i = lane & 31;
     const int h = lane >> 5;
+    // Block id -> (tile, m-split).  All tiles of one m-split read the SAME rows of both operands (every n-block re-reads
+    // the gathered rows, every k-block the dense rows, every tap re-gathers them), and blocks b, b + 8 share an XCD's
+    // L2 (round-robin placement: a speed assumption only).  When the splits divide evenly over the 8 XCDs a split's
+    // tiles are kept on one XCD: the grouped 8192x256x256 launch (1024 workgroups, fabric-bound) fetches 16 MB per
+    // group instead of 48 MB.  Uneven splits are left alone (20 splits: 75 vs 50 workgroups per XCD cost 40 %).
+    int tile, split;
+    if (p.xcd_map) {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        tile = r % p.ntiles;
+        split = xcd + 8 * (r / p.ntiles);
+    } else {
+        tile = blockIdx.x % p.ntiles;
+        split = blockIdx.x / p.ntiles;
+    }
     const int nkb = (g.K + CB - 1) / CB;
-    const int kkb = blockIdx.x % nkb;
-    const int nb = blockIdx.x / nkb;
+    const int kkb = tile % nkb;
+    const int nb = tile / nkb;
     const int kk0 = kkb * CB;
     const int n0 = nb * NB;
     const int grp = blockIdx.z;
@@ -1667,7 +1682,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
     const int kx_u = tap_u - ky_u * g.KW;
 
     const int total_chunks = (g.M + BMC - 1) / BMC;
-    const int c_begin = blockIdx.y * p.chunks_per_split;
+    const int c_begin = split * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > total_chunks) c_end = total_chunks;
 
@@ -1815,6 +1830,147 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
             int n = n0 + b * 32 + i;
             if (n < g.N) atomicAdd(db + n, accb[b][0]);
         }
+    }
+}
+
+// The 64 x 64-tile case again, organised for OCCUPANCY.  Measured on the kernel above (SQ counters, 1024 workgroups):
+// 0.9 waves per SIMD, 41 % of the wave cycles issuing VALU (f32 -> hi/lo splits, row bookkeeping), 5 % MFMA - its 74 KB
+// of LDS (two 128-row tiles, then a 64 KB cross-wave reduction) leave one workgroup per CU, so load latency, split,
+// LDS round trip and MFMAs run one after the other.  Here every wave owns ONE 32 x 32 block of the tile and walks all
+// rows of a 64-row chunk: no cross-wave reduction (accumulators 16 registers instead of 64, flushed straight from the
+// C layout as two 128-byte segments per atomic instruction), 37 KB of LDS -> four workgroups per CU whose phases overlap.
+template <int DD>
+__global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p) {
+    constexpr int CB = 64, NB = 64, BMC = 64;
+    constexpr int GS = CB + 8, DS = NB + 8;
+    __shared__ __attribute__((aligned(16))) short smem_s[2 * BMC * (GS + DS)];
+    short* Gh = smem_s;
+    short* Gl = Gh + BMC * GS;
+    short* Dh = Gl + BMC * GS;
+    short* Dl = Dh + BMC * DS;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1, wn = wave & 1;      // this wave's 32 x 32 block of the 64 x 64 tile
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int tile = blockIdx.x % p.ntiles;
+    const int split = blockIdx.x / p.ntiles;
+    const int nkb = (g.K + CB - 1) / CB;
+    const int kkb = tile % nkb;
+    const int nb = tile / nkb;
+    const int kk0 = kkb * CB;
+    const int n0 = nb * NB;
+    const int grp = blockIdx.z;
+    const float* gin = p.gathered + (size_t)grp * p.in_gs;
+    const float* din = p.dense + (size_t)grp * p.out_gs;
+    const bool do_bias = (p.db != nullptr) && (kkb == 0) && (wc == 0);
+    const int tap_u = kk0 / g.C;
+    const int c_u = kk0 - tap_u * g.C;
+    const int ky_u = tap_u / g.KW;
+    const int kx_u = tap_u - ky_u * g.KW;
+
+    const int total_chunks = (g.M + BMC - 1) / BMC;
+    const int c_begin = split * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    LoaderV4<BMC, CB, DD> lg;
+    lg.init(tid);
+    constexpr int DSLOTS = NB / 4;
+    constexpr int DRPP = 256 / DSLOTS;
+    constexpr int DNP = BMC / DRPP;
+    const int dslot = tid % DSLOTS;
+    const int dr0 = tid / DSLOTS;
+    const int dn = n0 + dslot * 4;
+    const bool dn_ok = dn < g.N;
+    f32x4 dreg[DNP];
+    unsigned dmask = 0u;
+    auto load_d = [&](int m0) {
+        dmask = 0u;
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            int m = m0 + dr0 + j * DRPP;
+            const bool ok = m < g.M && dn_ok;
+            const size_t o = ok ? (size_t)m * g.N + dn : 0;
+            dmask |= (ok ? 1u : 0u) << j;
+            dreg[j] = *reinterpret_cast<const f32x4*>(din + o);
+        }
+    };
+    auto store_d = [&]() {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            const bool ok = (dmask >> j) & 1u;
+            f32x4 v = dreg[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            u32x2 h2, l2;
+            split4(v, h2, l2);
+            *reinterpret_cast<u32x2*>(Dh + (dr0 + j * DRPP) * DS + dslot * 4) = h2;
+            *reinterpret_cast<u32x2*>(Dl + (dr0 + j * DRPP) * DS + dslot * 4) = l2;
+        }
+    };
+
+    f32x16 acc, accb;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = accb[e] = 0.f;
+    const int gq = lane >> 4;
+    const int q = (lane & 15) >> 2;
+    const int pq = lane & 3;
+    const int tr_row = 8 * (gq >> 1) + q;
+    const int tr_col = 16 * (gq & 1) + 4 * pq;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    if (c_begin < c_end) {
+        lg.set_rows(g, c_begin * BMC);
+        lg.load_tap(g, gin, ky_u, kx_u, c_u, true);
+        load_d(c_begin * BMC);
+    }
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        lg.store_split(g, Gh, Gl, GS);
+        store_d();
+        __syncthreads();
+        if (ch + 1 < c_end) {
+            lg.advance_rows(g, (ch + 1) * BMC, p.step_b, p.step_p, p.step_q);
+            lg.load_tap(g, gin, ky_u, kx_u, c_u, true);
+            load_d((ch + 1) * BMC);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BMC / 16; ++ks) {
+            const int row = 16 * ks + tr_row;
+            const bf16x8 ah = tr_frag(Gh + row * GS + 32 * wc + tr_col, GS);
+            const bf16x8 al = tr_frag(Gl + row * GS + 32 * wc + tr_col, GS);
+            const bf16x8 bh = tr_frag(Dh + row * DS + 32 * wn + tr_col, DS);
+            const bf16x8 bl = tr_frag(Dl + row * DS + 32 * wn + tr_col, DS);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            if (do_bias) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bh, accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bl, accb, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // flush straight from the C/D layout: col = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * h (k index)
+    float* dw = p.dw + (size_t)grp * p.w_gs;
+    const int n = n0 + 32 * wn + i;
+    if (n < g.N) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int kk = kk0 + 32 * wc + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (kk >= g.K) continue;
+            const int tap = kk / g.C;
+            const int c = kk - tap * g.C;
+            const int wtap = (tap / g.KW) * g.kws + tap % g.KW;
+            atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[e]);
+        }
+        if (do_bias && h == 0) atomicAdd(p.db + (size_t)grp * p.bias_gs + n, accb[0]);
     }
 }
 
@@ -2257,7 +2413,13 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
     const int G = d->groups;
     const int npad = (a.g.N + 31) / 32 * 32;
     const long long plane = (long long)a.g.KH * a.g.KW * ((a.g.C + BK - 1) / BK) * BK * npad;
-    const int rn = a.g.N > 32 ? 2 : 1;
+    int rn = a.g.N > 32 ? 2 : 1;
+    {   // 64-column workgroups need 80 KB of LDS (one per CU); when their grid would leave most CUs with a single
+        // workgroup anyway, 32-column workgroups (40 KB, twice as many) hide each other's latencies: measured
+        // 14x14x64 -> 7x7x64 forward 55 -> 44 us, its data gradient 73 -> 56 us, 8192x256x256 data gradient 29 -> 25 us
+        const long long wgs64 = (long long)((a.g.M + 127) / 128) * ((a.g.N + 63) / 64) * d->groups;
+        if (rn == 2 && wgs64 < 512) rn = 1;
+    }
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
     PatchPlan pp;
     static const bool patch_off = getenv("PM_NO_PATCH") != nullptr;      // A/B switch for measurements
@@ -2358,9 +2520,24 @@ extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d,
     a.step_b = 128 / hw;
     a.step_p = (128 - a.step_b * hw) / a.g.OW;
     a.step_q = 128 - a.step_b * hw - a.step_p * a.g.OW;
-    dim3 grid(p.nkb * p.nnb, p.splits, d->groups);
+    static const bool xcd_off = getenv("PM_WG_NOXCD") != nullptr;       // A/B switches for measurements
+    static const bool sub_off = getenv("PM_WG_NOSUB") != nullptr;
+    a.ntiles = p.nkb * p.nnb;
+    a.nsplits = p.splits;
+    a.xcd_map = (!xcd_off && p.splits % 8 == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int dd = d->d;
+    if (!sub_off && p.rc == 2 && p.rn == 2) {     // 64 x 64 tiles: the occupancy-oriented form, 64-row chunks
+        a.chunks_per_split = 2 * p.chunks_per_split;
+        a.step_b = 64 / hw;
+        a.step_p = (64 - a.step_b * hw) / a.g.OW;
+        a.step_q = 64 - a.step_b * hw - a.step_p * a.g.OW;
+        dim3 grid2(a.ntiles * p.splits, 1, d->groups);
+        if (dd == 1) hipLaunchKernelGGL((gather_wgrad_bf16_sub_kernel<1>), grid2, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gather_wgrad_bf16_sub_kernel<2>), grid2, dim3(256), 0, s, a);
+        return pm_check_launch("pm_gather_wgrad_bf16(sub)");
+    }
+    dim3 grid(a.ntiles * p.splits, 1, d->groups);
 #define PM_WB(RCv, RNv)                                                                                            \
     do {                                                                                                            \
         if (dd == 1) hipLaunchKernelGGL((gather_wgrad_bf16_kernel<RCv, RNv, 1>), grid, dim3(256), 0, s, a);         \

@@ -270,10 +270,18 @@ __global__ __launch_bounds__(32 * NS) void thin_wgrad_lane_kernel(ThinArgs t, co
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(row);
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + 4);
                     const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    // Scalar v_fmac through inline asm ON PURPOSE.  Written as fmaf() the compiler emits packed
+                    // v_pk_fma_f32 pairs, and that build returned run-to-run different sums - one 16-lane group of
+                    // one accumulator off by about one item's contribution - but only while an MFMA-heavy kernel
+                    // (patch_conv_bf16 / gather_wgrad_bf16_sub) ran beside it on another stream; alone, or beside
+                    // light kernels, it was bit-stable, and inputs and outputs were never touched by the neighbour
+                    // (tools/debug_thin_wgrad2.py bisects it: not the dense loads, not LDS, not the atomics).
+                    // Root cause not established (ROCm 7.2 hazard handling of packed FP32?); this form is stable.
 #pragma unroll
                     for (int jx = 0; jx < KS; ++jx)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[c][jy][jx] = fmaf(xv[j + jx], d[j], acc[c][jy][jx]);
+                        for (int j = 0; j < 4; ++j)
+                            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[c][jy][jx]) : "v"(xv[j + jx]), "v"(d[j]));
                 }
         }
     }

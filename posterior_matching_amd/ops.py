@@ -6,6 +6,7 @@ libpmhip.so.  All calls enqueue on torch's current stream and never synchronise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -347,8 +348,9 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None
     tag = work = None
     if _timer is not None:
         dense = desc.KH == desc.KW == desc.IH == desc.IW == desc.OH == desc.OW == 1 and desc.d == 1
-        tag = (f"direct_gemm_bf16_kernel<{2 if desc.N > 32 else 1}, {desc.d}, {desc.in_act}, "
-               f"{'true' if dense else 'false'}>")   # template args
+        wgs64 = -(-desc.B * desc.OH * desc.OW // 128) * -(-desc.N // 64) * desc.groups
+        rn = 2 if desc.N > 32 and wgs64 >= 512 else 1        # pm_gather_gemm_bf16: 32-column workgroups on short grids
+        tag = f"direct_gemm_bf16_kernel<{rn}, {desc.d}, {desc.in_act}, {'true' if dense else 'false'}>"   # template args
         if _patch_form(desc):
             tag = f"patch_conv_bf16_kernel<{2 if desc.N > 32 else 1}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
@@ -362,7 +364,7 @@ USE_BF16_WGRAD = True   # weight gradients on the bf16 matrix cores when the sha
 def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, db_gathered=None) -> None:
     """db_gathered: bias gradient taken over the GATHERED operand (transposed convs); only the thin lane form
     fuses it - callers must check the return value (True = db_gathered was accumulated)."""
-    if _lane_form(desc):
+    if _lane_form(desc) and not os.environ.get("PM_NO_LANE_WGRAD"):
         tag = work = None
         if _timer is not None:
             tag = f"thin_wgrad_lane_kernel<{desc.C}, {desc.KH}, 32>"
@@ -374,7 +376,9 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, 
             and gathered.data_ptr() % 16 == 0 and dense.data_ptr() % 16 == 0):
         tag = work = None
         if _timer is not None:
-            tag = f"gather_wgrad_bf16_kernel<{2 if desc.C % 64 == 0 and desc.KH * desc.KW * desc.C >= 64 else 1}, {2 if desc.N > 32 else 1}, {desc.d}>"
+            rc, rn = 2 if desc.C % 64 == 0 and desc.KH * desc.KW * desc.C >= 64 else 1, 2 if desc.N > 32 else 1
+            tag = (f"gather_wgrad_bf16_sub_kernel<{desc.d}>" if rc == 2 and rn == 2 else
+                   f"gather_wgrad_bf16_kernel<{rc}, {rn}, {desc.d}>")
             if (_patch_form(desc) and desc.C == 32 and desc.N <= 64 and desc.KH * desc.KW in (9, 25)):
                 tag = f"patch_wgrad_bf16_kernel<{2 if desc.N > 32 else 1}, {7 if desc.KH * desc.KW == 25 else 3}>"
             work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}

@@ -35,6 +35,7 @@ CASES = [
     ("enc5 dgrad", LayerGeom.conv(7, 7, 64, 128, 7, 1, "VALID"), "dgrad"),
     ("enc5 wgrad", LayerGeom.conv(7, 7, 64, 128, 7, 1, "VALID"), "wgrad"),
     ("mlp dgrad 8192x256x256", LayerGeom.dense(256, 256), "dgrad8192"),
+    ("mlp grouped wgrad 4x8192x256x256", LayerGeom.dense(256, 256), "gwgrad8192"),
     ("thin enc0 fwd 28x28 1->32 k5", LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME"), "fwd"),
     ("thin penc0 fwd 28x28 2->32 k5", LayerGeom.conv(28, 28, 2, 32, 5, 1, "SAME"), "fwd"),
     ("thin dec6 fwd 28x28 32->1 k5", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "fwd"),
@@ -78,6 +79,12 @@ def main():
                 ws = st.split_view(hd) if os.environ.get("PM_BF16", "1") == "1" else None
                 y.normal_()
                 fn = lambda: ops.layer_dgrad(g, y, w, x, aux=x.clone(), aux_act=ACT_LEAKY, wsplit=ws)
+            elif what.startswith("gwgrad"):
+                G = 4
+                xg, yg = torch.randn((G, B, g.CI), device=d), torch.randn((G, B, g.CO), device=d)
+                dwg, dbg = torch.zeros((G,) + tuple(w.shape), device=d), torch.zeros((G, g.CO), device=d)
+                fn = lambda: ops.layer_wgrad(g, xg, yg, dwg, dbg, B=B, groups=G, in_gs=B * g.CI, out_gs=B * g.CO,
+                                             w_gs=g.CI * g.CO, bias_gs=g.CO)
             else:
                 y.normal_()
                 fn = lambda: ops.layer_wgrad(g, x, y, dw, db)
