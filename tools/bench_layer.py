@@ -29,6 +29,7 @@ CASES = [
     ("mlp wgrad 8192x256x256", LayerGeom.dense(256, 256), "wgrad8192"),
     ("enc4 fwd 14->7 s2 64->64", LayerGeom.conv(14, 14, 64, 64, 5, 2, "SAME"), "fwd"),
     ("enc2 wgrad 28->14 s2 32->32", LayerGeom.conv(28, 28, 32, 32, 5, 2, "SAME"), "wgrad"),
+    ("dec3 wgrad 14x14 64->32 k5", LayerGeom.conv_t(14, 14, 64, 32, 5, 1, "SAME"), "wgrad"),
     ("enc4 wgrad 14->7 s2 64->64", LayerGeom.conv(14, 14, 64, 64, 5, 2, "SAME"), "wgrad"),
     ("enc4 dgrad 7->14 d2 64->64", LayerGeom.conv(14, 14, 64, 64, 5, 2, "SAME"), "dgrad"),
     ("enc5 fwd 7x7x64->128 k7", LayerGeom.conv(7, 7, 64, 128, 7, 1, "VALID"), "fwd"),
