@@ -2418,7 +2418,8 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
         // workgroup anyway, 32-column workgroups (40 KB, twice as many) hide each other's latencies: measured
         // 14x14x64 -> 7x7x64 forward 55 -> 44 us, its data gradient 73 -> 56 us, 8192x256x256 data gradient 29 -> 25 us
         const long long wgs64 = (long long)((a.g.M + 127) / 128) * ((a.g.N + 63) / 64) * d->groups;
-        if (rn == 2 && wgs64 < 512) rn = 1;
+        static const long long rn2_min = getenv("PM_RN2_MIN_WGS") ? atoll(getenv("PM_RN2_MIN_WGS")) : 512;   // A/B knob
+        if (rn == 2 && wgs64 < rn2_min) rn = 1;
     }
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
     PatchPlan pp;
