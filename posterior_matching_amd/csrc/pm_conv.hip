@@ -1335,6 +1335,292 @@ bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
     return true;
 }
 
+// ------------- zero-dilated (d = 2) problems, patch-staged with the four residue classes fused -------------
+// Stride-2 transposed convolutions (forward) and the data gradients of stride-2 convolutions:  src * 2 = dst + tap * cs + off.
+// An output position of residue class (ry, rx) = (dst_y & 1, dst_x & 1) only meets the taps with
+// (ry + ky * cs + off) even (likewise in x), at source row i + (ry + ky * cs + off) / 2 with i = dst_y >> 1: four small
+// stride-1 convolutions over the SAME source neighbourhood.  A workgroup therefore owns a tile of class coordinates (i, j)
+// (8 x 16 of one image, or 8 x 8 of two images when the class grid is at most 8 wide), stages that neighbourhood ONCE
+// (f32 -> hi / lo bf16, zeros outside the image; 14 - 58 KB of LDS), and walks the four classes one after the other:
+// per class the valid taps only, every A fragment a 16-byte LDS read, weights through the usual double-buffered stages.
+// The direct form re-gathers its rows from L2 once per tap and runs at 36 - 46 TFLOP/s on these layers.
+struct KStepD2 {
+    int aoff;   // patch offset (bf16 elements) of this step's source shift and channel chunk
+    int woff;   // offset of this step's [Npad][32] hi block inside the split weights
+};
+
+template <int RN>
+__global__ __launch_bounds__(256) void patch_d2_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
+                                                             long long plane, int tw_log2, int ni) {
+    constexpr int NB = 32 * RN;
+    constexpr int STEP_E = 2 * NB * BROW;
+    constexpr int BTILE = PDGS * STEP_E;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    __bf16* Bs = reinterpret_cast<__bf16*>(dsm);                        // 2 stages = BTILE floats
+    int* meta = reinterpret_cast<int*>(dsm + BTILE);                    // [0..4]: first step of each class, [5..8]: shifts
+    KStepD2* kd = reinterpret_cast<KStepD2*>(meta + 16);
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int n0 = blockIdx.y * NB;
+    const int TW = 1 << tw_log2;
+    const int TH = 128 / (TW * ni);
+    const int cch = g.C / BK;
+    const int CHg = g.OH >> 1, CWg = g.OW >> 1;                         // class grid (OH, OW even)
+    const int PS = g.C + 8;
+
+    // shifts delta(r, t) = (r + t * cs + off) / 2 of the valid taps: range over both residues, per axis
+    auto shift = [&](int r, int t, int off, int& dl) {
+        const int v = r + t * g.cs + off;
+        dl = v >> 1;                                                    // arithmetic shift: exact when v is even
+        return (v & 1) == 0;
+    };
+    int dymin = 1 << 20, dymax = -(1 << 20), dxmin = 1 << 20, dxmax = -(1 << 20);
+    for (int r = 0; r < 2; ++r) {
+        for (int t = 0; t < g.KH; ++t) {
+            int dl;
+            if (shift(r, t, g.off, dl)) { dymin = dl < dymin ? dl : dymin; dymax = dl > dymax ? dl : dymax; }
+        }
+        for (int t = 0; t < g.KW; ++t) {
+            int dl;
+            if (shift(r, t, g.offx, dl)) { dxmin = dl < dxmin ? dl : dxmin; dxmax = dl > dxmax ? dl : dxmax; }
+        }
+    }
+    const int PH = TH + dymax - dymin, PW = TW + dxmax - dxmin;
+    const int nsteps_max = g.KH * g.KW * cch;
+    __bf16* Ph = reinterpret_cast<__bf16*>(kd + ((nsteps_max + PDGS + 1) & ~1));   // 16-byte aligned
+    __bf16* Pl = Ph + (size_t)ni * PH * PW * PS;
+
+    // tile -> images and class-grid origin
+    const int tiles_x = (CWg + TW - 1) >> tw_log2;
+    const int tiles_y = (CHg + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int b0 = (t / tiles_y) * ni;
+    const int i0 = tyi * TH, j0 = txi << tw_log2;
+
+    // step table: class c = ry * 2 + rx, its taps in (ky, kx) order, channel chunks innermost
+    if (tid < 4) {
+        const int ry = tid >> 1, rx = tid & 1;
+        int before = 0;
+        for (int c = 0; c < tid; ++c) {
+            int ny = 0, nx = 0, dl;
+            for (int tt = 0; tt < g.KH; ++tt) ny += shift(c >> 1, tt, g.off, dl) ? 1 : 0;
+            for (int tt = 0; tt < g.KW; ++tt) nx += shift(c & 1, tt, g.offx, dl) ? 1 : 0;
+            before += ny * nx * cch;
+        }
+        int s = before;
+        for (int ky = 0; ky < g.KH; ++ky) {
+            int dy;
+            if (!shift(ry, ky, g.off, dy)) continue;
+            for (int kx = 0; kx < g.KW; ++kx) {
+                int dx;
+                if (!shift(rx, kx, g.offx, dx)) continue;
+                for (int cc = 0; cc < cch; ++cc) {
+                    kd[s].aoff = ((dy - dymin) * PW + (dx - dxmin)) * PS + cc * BK;
+                    kd[s].woff = ((ky * g.KW + kx) * cch + cc) * npad * BK;
+                    ++s;
+                }
+            }
+        }
+        meta[tid] = before;
+        if (tid == 3) {
+            meta[4] = s;
+            for (int e = 0; e < PDGS; ++e) kd[s + e] = KStepD2{0, 0};
+        }
+    }
+    {   // the source neighbourhood of the tile, per image: f32 -> hi / lo bf16, zero outside the image
+        const int c4n = g.C >> 2;
+        const int per_img = PH * PW * c4n;
+        const int total = ni * per_img;
+        constexpr int PB = 8;
+        for (int e0 = tid; e0 < total; e0 += 256 * PB) {
+            f32x4 v[PB];
+            int dst[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int e = e0 + 256 * j;
+                const int ee = e < total ? e : total - 1;
+                const int im = ee / per_img, r = ee - im * per_img;
+                const int pos = r / c4n, c4 = r - pos * c4n;
+                const int py = pos / PW, px = pos - py * PW;
+                const int gy = i0 + dymin + py, gx = j0 + dxmin + px;
+                const bool ok = e < total && b0 + im < g.B && (unsigned)gy < (unsigned)g.IH && (unsigned)gx < (unsigned)g.IW;
+                const size_t so = ok ? (((size_t)(b0 + im) * g.IH + gy) * g.IW + gx) * g.C + 4 * c4 : 0;
+                v[j] = *reinterpret_cast<const f32x4*>(p.in + so);
+                if (!ok) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dst[j] = e < total ? (im * PH * PW + pos) * PS + 4 * c4 : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                if (dst[j] < 0) continue;
+                u32x2 h2, l2;
+                split4(v[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + dst[j]) = h2;
+                *reinterpret_cast<u32x2*>(Pl + dst[j]) = l2;
+            }
+        }
+    }
+
+    constexpr int PIECES = 2 * NB * 4;
+    constexpr int PPT = (PIECES + 255) / 256;
+    u32x4 breg[PDGS][PPT];
+    auto load_b = [&](int s0) {
+#pragma unroll
+        for (int st = 0; st < PDGS; ++st) {
+            const int wo = kd[s0 + st].woff;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                const int nrow = n0 + row < npad ? n0 + row : 0;
+                breg[st][j] = *reinterpret_cast<const u32x4*>(wsplit + (size_t)pl * plane + wo + nrow * BK + qtr * 8);
+            }
+        }
+    };
+    auto store_b = [&](__bf16* dstp) {
+#pragma unroll
+        for (int st = 0; st < PDGS; ++st)
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                *reinterpret_cast<u32x4*>(dstp + st * STEP_E + (pl * NB + row) * BROW + qtr * 8) = breg[st][j];
+            }
+    };
+
+    // this lane's class coordinate and its A-fragment base inside the patch
+    const int ml = wave * 32 + i;
+    const int im = ml / (TH * TW);
+    const int rem = ml - im * TH * TW;
+    const int ty = rem >> tw_log2, tx = rem & (TW - 1);
+    const int abase = ((im * PH + ty) * PW + tx) * PS + 8 * h;
+    const int ci = i0 + ty, cj = j0 + tx;
+    const bool row_ok = ci < CHg && cj < CWg && b0 + im < g.B;
+
+    const float* bias = p.bias;
+    const float* aux = p.aux;
+    const float* res = p.res;
+    float* out = p.out;
+    __syncthreads();                 // step table + patch visible
+
+    // short grids (7 x 7 class grids at B = 256: 128 tiles) spread the four classes over blockIdx.z instead
+    const int cls_begin = gridDim.z == 4 ? (int)blockIdx.z : 0;
+    const int cls_end = gridDim.z == 4 ? cls_begin + 1 : 4;
+    for (int cls = cls_begin; cls < cls_end; ++cls) {
+        const int sb = meta[cls], se = meta[cls + 1];
+        f32x16 acc[RN];
+#pragma unroll
+        for (int r = 0; r < RN; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+        if (sb < se) {
+            load_b(sb);
+            store_b(Bs);
+        }
+        __syncthreads();
+        bf16x8 ah[2][2], al[2][2];
+        auto read_a = [&](int s, int set) {
+            const int o = abase + kd[s].aoff;
+            ah[set][0] = *reinterpret_cast<const bf16x8*>(Ph + o);
+            ah[set][1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
+            al[set][0] = *reinterpret_cast<const bf16x8*>(Pl + o);
+            al[set][1] = *reinterpret_cast<const bf16x8*>(Pl + o + 16);
+        };
+        auto mma = [&](const __bf16* bstep, int set) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r = 0; r < RN; ++r) {
+                    const __bf16* brow = bstep + (r * 32 + i) * BROW + 16 * kk + 8 * h;
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(brow);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(brow + NB * BROW);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][kk], bh, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][kk], bl, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][kk], bh, acc[r], 0, 0, 0);
+                }
+        };
+        if (sb < se) read_a(sb, 0);
+        int stage = 0;
+        for (int s0 = sb; s0 < se; s0 += PDGS) {
+            const __bf16* bcur = Bs + stage * BTILE;
+            const bool more = s0 + PDGS < se;
+            if (more) load_b(s0 + PDGS);
+#pragma unroll
+            for (int st = 0; st < PDGS; ++st) {
+                if (s0 + st < se) {
+                    if (s0 + st + 1 < se) read_a(s0 + st + 1, (st + 1) & 1);
+                    mma(bcur + st * STEP_E, st & 1);
+                }
+            }
+            if (more) store_b(Bs + (stage ^ 1) * BTILE);
+            __syncthreads();
+            stage ^= 1;
+        }
+        // epilogue of this class: output position (2 ci + ry, 2 cj + rx)
+        const int ry = cls >> 1, rx = cls & 1;
+        const int rowoff = row_ok ? (((b0 + im) * g.OH + 2 * ci + ry) * g.OW + 2 * cj + rx) * g.N : -1;
+        int ro[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ro[e] = __shfl(rowoff, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
+#pragma unroll
+        for (int r = 0; r < RN; ++r) {
+            const int n = n0 + r * 32 + i;
+            if (n >= g.N) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (ro[e] < 0) continue;
+                const size_t o = (size_t)ro[e] + n;
+                out[o] = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
+            }
+        }
+        __syncthreads();             // stage buffers are rewritten by the next class
+    }
+}
+
+struct PatchD2Plan { int tw_log2, ni; size_t lds; dim3 grid; };
+bool plan_patch_d2(const Geom& g, int groups, int rn, PatchD2Plan& pp) {
+    if (groups != 1 || g.a != 1 || g.d != 2 || g.C % BK != 0 || g.in_act != PM_ACT_NONE) return false;
+    if ((g.cs != 1 && g.cs != -1) || (g.OH & 1) || (g.OW & 1) || g.KH > 8 || g.KW > 8 || g.KH * g.KW < 4) return false;
+    const int CHg = g.OH / 2, CWg = g.OW / 2;
+    if (CHg > g.IH + 4 || CWg > g.IW + 4) return false;
+    // Class grids at most 8 wide (two images per tile, optionally one class per workgroup) are implemented and
+    // parity-tested but measured SLOWER than the direct form (7x7 -> 14x14, 64 -> 64 at B = 256: 110 / 76 us against 57 us:
+    // 128 tiles cannot fill the chip, and a class per workgroup re-stages the patch four times): only wider grids qualify.
+    static const bool small_on = getenv("PM_PATCH_D2_SMALL") != nullptr;
+    if (CWg > 8) { pp.tw_log2 = 4; pp.ni = 1; }
+    else if (CHg <= 8 && small_on) { pp.tw_log2 = 3; pp.ni = 2; }
+    else return false;
+    const int TW = 1 << pp.tw_log2, TH = 128 / (TW * pp.ni);
+    const int tiles_x = (CWg + TW - 1) / TW, tiles_y = (CHg + TH - 1) / TH;
+    if ((long long)tiles_x * TW * tiles_y * TH * 2 > 3LL * CHg * CWg) return false;     // > 50 % padded slots
+    // shift range: at most (K + 1) / 2 distinct shifts per axis
+    const int spanh = (g.KH + 1) / 2 + 1, spanw = (g.KW + 1) / 2 + 1;
+    const int NB = 32 * rn;
+    const size_t bt = (size_t)PDGS * 2 * NB * BROW * 2 * 2;
+    const int nsteps = g.KH * g.KW * (g.C / BK);
+    if (nsteps > 2048) return false;
+    const size_t kdb = 64 + (size_t)((nsteps + PDGS + 1) & ~1) * sizeof(KStepD2);
+    const size_t patch = (size_t)pp.ni * (TH + spanh) * (TW + spanw) * (g.C + 8) * 2 * 2;
+    pp.lds = bt + kdb + patch;
+    if (pp.lds > 150 * 1024) return false;
+    const int nimg_tiles = (g.B + pp.ni - 1) / pp.ni;
+    pp.grid = dim3((unsigned)(nimg_tiles * tiles_y * tiles_x), (g.N + NB - 1) / NB, 1);
+    if ((long long)pp.grid.x * pp.grid.y < 384) pp.grid.z = 4;       // one residue class per workgroup
+    return true;
+}
+
 template <int RN, int DD>
 void launch_direct_bf16(hipStream_t s, const GemmArgs& a, dim3 grid, const __bf16* ws, int npad, long long plane) {
     const Geom& g = a.g;
@@ -2437,6 +2723,23 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
         if (rn == 1) hipLaunchKernelGGL(patch_conv_bf16_kernel<1>, pp.grid, dim3(256), pp.lds, s, a, ws, npad, plane, pp.tw_log2);
         else hipLaunchKernelGGL(patch_conv_bf16_kernel<2>, pp.grid, dim3(256), pp.lds, s, a, ws, npad, plane, pp.tw_log2);
         return pm_check_launch("pm_gather_gemm_bf16(patch)");
+    }
+    PatchD2Plan pd;
+    static const bool d2_off = getenv("PM_NO_PATCH_D2") != nullptr;      // A/B switch for measurements
+    const int rn_d2 = a.g.N > 32 ? 2 : 1;
+    if (!d2_off && plan_patch_d2(a.g, G, rn_d2, pd)) {   // zero-dilated problems: four residue classes off one staged patch
+        a.ksplit = 1;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_d2_bf16_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_d2_bf16_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        if (rn_d2 == 1) hipLaunchKernelGGL(patch_d2_bf16_kernel<1>, pd.grid, dim3(256), pd.lds, s, a, ws, npad, plane, pd.tw_log2, pd.ni);
+        else hipLaunchKernelGGL(patch_d2_bf16_kernel<2>, pd.grid, dim3(256), pd.lds, s, a, ws, npad, plane, pd.tw_log2, pd.ni);
+        return pm_check_launch("pm_gather_gemm_bf16(patch_d2)");
     }
     const GemmPlan p = plan_gemm(a.g, G, true);
     a.ksplit = p.ksplit;

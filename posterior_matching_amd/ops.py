@@ -344,6 +344,31 @@ def _patch_form(d: GatherDesc) -> bool:
     return lds <= 150 * 1024
 
 
+def _patch_d2_form(d: GatherDesc) -> bool:
+    """mirrors plan_patch_d2 (csrc/pm_conv.hip): zero-dilated problems whose four residue classes share one staged patch"""
+    if d.groups != 1 or d.a != 1 or d.d != 2 or d.C % 32 != 0 or d.in_act != ACT_NONE or d.cs not in (1, -1):
+        return False
+    if d.OH % 2 or d.OW % 2 or d.KH > 8 or d.KW > 8 or d.KH * d.KW < 4:
+        return False
+    ch, cw = d.OH // 2, d.OW // 2
+    if ch > d.IH + 4 or cw > d.IW + 4:
+        return False
+    if cw > 8:
+        tw, ni = 16, 1
+    elif ch <= 8 and os.environ.get("PM_PATCH_D2_SMALL"):
+        tw, ni = 8, 2
+    else:
+        return False
+    th = 128 // (tw * ni)
+    if -(-cw // tw) * tw * -(-ch // th) * th * 2 > 3 * ch * cw:
+        return False
+    nb = 64 if d.N > 32 else 32
+    nsteps = d.KH * d.KW * (d.C // 32)
+    lds = (2 * 2 * nb * 40 * 2 * 2 + 64 + ((nsteps + 3) & ~1) * 8
+           + ni * (th + (d.KH + 1) // 2 + 1) * (tw + (d.KW + 1) // 2 + 1) * (d.C + 8) * 4)
+    return nsteps <= 2048 and lds <= 150 * 1024
+
+
 def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None:
     tag = work = None
     if _timer is not None:
@@ -353,6 +378,8 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None
         tag = f"direct_gemm_bf16_kernel<{rn}, {desc.d}, {desc.in_act}, {'true' if dense else 'false'}>"   # template args
         if _patch_form(desc):
             tag = f"patch_conv_bf16_kernel<{2 if desc.N > 32 else 1}>"
+        elif _patch_d2_form(desc):
+            tag = f"patch_d2_bf16_kernel<{2 if desc.N > 32 else 1}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
     _call("pm_gather_gemm_bf16", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
           _ptr(out), tag=tag, work=work)
