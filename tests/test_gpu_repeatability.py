@@ -1,0 +1,76 @@
+"""Run-to-run repeatability of the gradients at the reference network sizes, with every companion stream active.
+
+Sums are accumulated with float atomics, so bit equality is not expected; anything above ordering noise is a hazard
+between kernels that run side by side.  (This is the check that exposed the packed-FP32 instability of the thin
+weight-gradient kernel)  Tolerance: 2e-6 of the tensor's own largest entry, the level an
+f32 sum of a few thousand same-sign terms moves when its order changes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+
+
+def _compare(runs):
+    ref = runs[0]
+    for other in runs[1:]:
+        for n in ref:
+            scale = max(ref[n].abs().max().item(), 1e-30)
+            err = (ref[n] - other[n]).abs().max().item() / scale
+            assert err < TOL, (n, err)
+
+
+def test_pm_vae_gradients_repeat():
+    from tests.test_gpu_parity import _inputs, _product_model
+
+    cfg, xs, x, b, eps = _inputs("mnist", 256, 9)
+    m = _product_model(cfg, xs)
+    xd, bd, ed = x.float().cuda(), b.float().cuda(), eps.float().cuda()
+    m(xd, bd, True, eps=ed)
+    g = [torch.full((256,), v, device="cuda") for v in (-1 / 256, 1 / 256, -1 / 256)]
+    runs = []
+    for _ in range(4):
+        m.zero_grad()
+        m.backward(*g)
+        torch.cuda.synchronize()
+        runs.append({n: t.clone() for n, t in m.grads_dict().items()})
+    _compare(runs)
+
+
+def test_vdvae_gradients_repeat():
+    from tests.ref_configs import pm_vdvae_mnist
+    from tests.test_gpu_vdvae import _setup, f32d
+
+    m, _, x, b, eps = _setup(pm_vdvae_mnist(), 8, seed=8, bf16x3=True)
+    runs = []
+    for _ in range(3):
+        m(f32d(x), f32d(b), [f32d(e) for e in eps])
+        m.zero_grad()
+        m.backward()
+        torch.cuda.synchronize()
+        runs.append({n: t.clone() for n, t in m.grads_dict().items()})
+    _compare(runs)
+
+
+def test_pm_vqvae_gradients_repeat():
+    from posterior_matching_amd import ops
+    from tests.ref_configs import pm_vqvae_mnist, vqvae_mnist
+    from tests.test_gpu_pixelcnn import _batch, _stage2, f32d
+
+    cfg, vq_cfg = pm_vqvae_mnist(), vqvae_mnist()["model"]
+    B, xs = 32, (28, 28, 1)
+    ts, _, _, _ = _stage2(cfg, vq_cfg, xs, B, seed=6, bf16x3=True)
+    x, b = _batch(np.random.default_rng(2), B, xs)
+    ts.set_batch(f32d(x), f32d(b))
+    runs = []
+    for _ in range(3):
+        with torch.cuda.stream(ts.stream):
+            ll = ts.forward(False)
+            ops.neg_mean_loss(ll, 1.0 / B, ts.metrics, ts.g_ll)
+            ops.fill_zero(ts.store.flat_g)
+            ts.penc.backward(ts.pcnn.backward(ts.g_ll))
+        ts.synchronize()
+        runs.append({n: t.clone() for n, t in ts.store.to_dict("g").items()})
+    _compare(runs)
