@@ -123,3 +123,35 @@ def test_dataset_device_masks_feed_a_train_step():
         ts.set_batch(batch["image"], batch["mask"])
         ts.step()
     assert np.isfinite(ts.read_metrics()["loss"])
+
+
+def test_device_masks_match_golden_fixture():
+    """the committed bit streams (tests/golden/masks_tiny.npz) straight from the kernels, without the oracle in the loop"""
+    import os
+
+    from posterior_matching_amd import ops
+    from posterior_matching_amd.masking import get_mask_generator
+    from tests.golden.make_golden_masks import CASES
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "masks_tiny.npz"))
+    for key, (name, B, H, seed) in CASES.items():
+        gen = get_mask_generator(name, device=dev(), seed=seed)
+        for step in range(6):
+            desc = torch.zeros((B, 6), dtype=torch.int32, device=dev())
+            out = torch.empty((B, H, H, 1), device=dev())
+            gen.fill(out, desc_out=desc)
+            gen._advance()
+            if step in (0, 5):
+                assert np.array_equal(np.packbits(out.cpu().numpy().astype(np.uint8).reshape(-1)), gold[f"{key}_step{step}_mask"])
+                assert np.array_equal(desc.cpu().numpy(), gold[f"{key}_step{step}_desc"])
+    step2 = torch.full((1,), 2, dtype=torch.int32, device=dev())
+    m = torch.empty((9, 43), device=dev())
+    ops.bernoulli_mask(m, 0.3, 3, step2)
+    assert np.array_equal(np.packbits(m.cpu().numpy().astype(np.uint8).reshape(-1)), gold["bernoulli_p03"])
+    step1 = torch.full((1,), 1, dtype=torch.int32, device=dev())
+    u = torch.empty((16, 21), device=dev())
+    ops.uniform_mask(u, 0, 21, 4, step1)
+    assert np.array_equal(np.packbits(u.cpu().numpy().astype(np.uint8).reshape(-1)), gold["uniform_d21"])
+    u2 = torch.empty((8, 300), device=dev())
+    ops.uniform_mask(u2, 75, 150, 5, None)
+    assert np.array_equal(np.packbits(u2.cpu().numpy().astype(np.uint8).reshape(-1)), gold["uniform_bounds"])

@@ -531,3 +531,18 @@ def test_is_log_prob_and_impute_oracle_properties():
     assert (lxu - lx).abs().max() < 5.0
     score = O.nrmse_score(imp0.mean(0).numpy()[None], x.numpy()[None], zeros.numpy()[None])
     assert score.shape == (1,)
+
+
+def test_mask_oracle_matches_golden_fixture():
+    """tests/golden/masks_tiny.npz (self-generated, make_golden_masks.py): a regression pin of the oracle's bit streams"""
+    import os
+
+    import numpy as np
+
+    from tests.golden.make_golden_masks import build
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "masks_tiny.npz"))
+    now = build()
+    assert sorted(gold.files) == sorted(now)
+    for k in gold.files:
+        assert np.array_equal(gold[k], now[k]), k
