@@ -28,3 +28,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_rngs():
+    """Every test starts from the same global RNG state: a few tests draw shape-only inputs from the global generators,
+    and their values must not depend on which tests ran before (one finite-difference check flipped a nearest-code
+    choice once in a fresh checkout)."""
+    import numpy as np
+    import torch
+
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    yield
