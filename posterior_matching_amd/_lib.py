@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpmhip.so")
+LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "lib", "libpmhip.so")   # PM_LIB_PATH: A/B builds
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 AUX_AFTER_RES = 16  # PM_AUX_AFTER_RES (include/pmhip.h)
@@ -133,6 +133,7 @@ SIGNATURES = {
     "pm_impute_blend": [_P, _P, _P, _P, _LL, _I, _LL, _I, _I, _F, _F],
     "pm_imputation_psnr": [_P, _P, _P, _P, _LL, _I, _LL, _F],
     "pm_gumbel_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
+    "pm_mlp_pair_bf16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _F],
     "pm_repeat_rows": [_P, _P, _P, _LL, _I, _LL],
     "pm_sigmoid": [_P, _P, _P, _LL],
     "pm_bernoulli_ll_rep_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I],

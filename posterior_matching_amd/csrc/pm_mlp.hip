@@ -1,0 +1,181 @@
+// Two dense layers of a ResidualMLP block in ONE launch (reference networks.py:111-135), forward or data gradient:
+//   forward :  u  = relu(h) W1 + b1                 hn    = relu(u) W2 + b2 + h
+//   backward:  du = (dh W2^T) * relu'(u)            dprev = (du W1^T) * relu'(h) + dh
+// i.e.  out1 = epi1(act_in(X) B1),  out2 = epi2(act_mid(out1) B2)  with both results stored (u / du are needed later).
+// A workgroup owns 64 rows: X is staged once as hi / lo bf16 in LDS, every wave owns 64 of the H = 256 output columns
+// (two 32-row x two 32-column accumulator tiles), the B fragments come straight from the pre-split, K-contiguous
+// weights in L2 (16 bytes per lane, prefetched one k-step ahead) and out1 goes back into the same LDS buffer as the
+// second product's A operand.  Same bf16x3 arithmetic as pm_gather_gemm_bf16 (three bf16 MFMA products, f32 accumulate).
+// Two launches of 256 / 512 workgroups and a round trip through HBM become one launch of R / 64 workgroups.
+#include "pm_common.h"
+
+namespace {
+
+typedef __bf16 m_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 m_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float m_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned m_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int H = 256;          // hidden width (columns of every operand)
+constexpr int LDA = H + 8;      // bf16 per LDS row: 528 bytes = 33 x 16 (conflict-free 16-byte reads down a column)
+#ifndef PM_MLP_ROWS
+#define PM_MLP_ROWS 64
+#endif
+constexpr int ROWS = PM_MLP_ROWS;
+constexpr int MS = ROWS / 32;   // 32-row accumulator tiles per wave
+
+__device__ __forceinline__ void m_split4(const f32x4& x, m_u32x2& hi, m_u32x2& lo) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float a0 = x[2 * j], a1 = x[2 * j + 1];
+        const unsigned hh = __builtin_bit_cast(unsigned, __builtin_convertvector(m_f32x2{a0, a1}, m_bf16x2));
+        const float f0 = __builtin_bit_cast(float, hh << 16);
+        const float f1 = __builtin_bit_cast(float, hh & 0xffff0000u);
+        hi[j] = hh;
+        lo[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(m_f32x2{a0 - f0, a1 - f1}, m_bf16x2));
+    }
+}
+
+struct PairArgs {
+    const float* x;          // [R, H]  first operand (also the residual of the second product)
+    const __bf16* w1;        // split weights of the first product: [2 planes][H/32][H][32]
+    const __bf16* w2;
+    const float* b1;         // may be NULL
+    const float* b2;
+    const float* aux1;       // act'(aux1) multiplies out1 (may be NULL)
+    const float* aux2;
+    float* out1;
+    float* out2;
+    int R;
+    int in_act, mid_act, aux_act1, aux_act2;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void mlp_pair_bf16_kernel(PairArgs p) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[ROWS * LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[ROWS * LDA];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * ROWS;
+    constexpr long long PLANE = (long long)H * H;
+
+    // stage act_in(X) as hi / lo planes: 64 x 256 floats, 16 float4 per thread, coalesced rows
+    for (int e = tid; e < ROWS * (H / 4); e += 256) {
+        const int row = e / (H / 4), c4 = e - row * (H / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < p.R) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(r0 + row) * H + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = pm_act(v[k], p.in_act, p.slope);
+        m_u32x2 h2, l2;
+        m_split4(v, h2, l2);
+        *reinterpret_cast<m_u32x2*>(Ah + row * LDA + 4 * c4) = h2;
+        *reinterpret_cast<m_u32x2*>(Al + row * LDA + 4 * c4) = l2;
+    }
+    __syncthreads();
+
+    const int ncol0 = 64 * wave;     // this wave's 64 output columns
+    for (int phase = 0; phase < 2; ++phase) {
+        const __bf16* w = phase == 0 ? p.w1 : p.w2;
+        f32x16 acc[MS][2];
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
+        // B fragments of k-step s: [kk][t][plane]
+        m_bf16x8 bcur[2][2][2], bnxt[2][2][2];
+        auto load_b = [&](int s, m_bf16x8 (&b)[2][2][2]) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const size_t o = ((size_t)s * H + ncol0 + 32 * t + i) * 32 + 16 * kk + 8 * h;
+                    b[kk][t][0] = *reinterpret_cast<const m_bf16x8*>(w + o);
+                    b[kk][t][1] = *reinterpret_cast<const m_bf16x8*>(w + PLANE + o);
+                }
+        };
+        load_b(0, bcur);
+#pragma unroll 1
+        for (int s = 0; s < H / 32; ++s) {
+            if (s + 1 < H / 32) load_b(s + 1, bnxt);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                m_bf16x8 ah[MS], al[MS];
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    const int o = (32 * m + i) * LDA + 32 * s + 16 * kk + 8 * h;
+                    ah[m] = *reinterpret_cast<const m_bf16x8*>(Ah + o);
+                    al[m] = *reinterpret_cast<const m_bf16x8*>(Al + o);
+                }
+#pragma unroll
+                for (int m = 0; m < MS; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bcur[kk][t][0], acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bcur[kk][t][1], acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bcur[kk][t][0], acc[m][t], 0, 0, 0);
+                    }
+            }
+            if (s + 1 < H / 32) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        bcur[kk][t][0] = bnxt[kk][t][0];
+                        bcur[kk][t][1] = bnxt[kk][t][1];
+                    }
+            }
+        }
+        // epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
+        const float* bias = phase == 0 ? p.b1 : p.b2;
+        const float* aux = phase == 0 ? p.aux1 : p.aux2;
+        const int aux_act = phase == 0 ? p.aux_act1 : p.aux_act2;
+        const float* res = phase == 0 ? nullptr : p.x;
+        float* out = phase == 0 ? p.out1 : p.out2;
+        if (phase == 0) __syncthreads();          // every wave is done reading X before act_mid(out1) overwrites it
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int n = ncol0 + 32 * t + i;
+                const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = 32 * m + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int row = r0 + rl;
+                    float v = 0.f;
+                    if (row < p.R) {
+                        const size_t o = (size_t)row * H + n;
+                        v = pm_epilogue(acc[m][t][e] + bv, aux, res, o, aux_act, PM_ACT_NONE, p.slope);
+                        out[o] = v;
+                    }
+                    if (phase == 0) {
+                        const float a = pm_act(v, p.mid_act, p.slope);
+                        const __bf16 hi = (__bf16)a;
+                        Ah[rl * LDA + n] = hi;
+                        Al[rl * LDA + n] = (__bf16)(a - (float)hi);
+                    }
+                }
+            }
+        if (phase == 0) __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int pm_mlp_pair_bf16(pm_stream_t stream, const float* x, const void* w1_split, const void* w2_split, const float* b1,
+                                const float* b2, const float* aux1, const float* aux2, float* out1, float* out2, long long R,
+                                int hidden, int in_act, int mid_act, int aux_act1, int aux_act2, float slope) {
+    if (!x || !w1_split || !w2_split || !out1 || !out2 || R <= 0 || R > (1LL << 30) || hidden != H) return PM_EINVAL;
+    if ((reinterpret_cast<size_t>(x) & 15) || (reinterpret_cast<size_t>(w1_split) & 15) ||
+        (reinterpret_cast<size_t>(w2_split) & 15))
+        return PM_EINVAL;
+    PairArgs p;
+    p.x = x; p.w1 = reinterpret_cast<const __bf16*>(w1_split); p.w2 = reinterpret_cast<const __bf16*>(w2_split);
+    p.b1 = b1; p.b2 = b2; p.aux1 = aux1; p.aux2 = aux2; p.out1 = out1; p.out2 = out2; p.R = (int)R;
+    p.in_act = in_act; p.mid_act = mid_act; p.aux_act1 = aux_act1; p.aux_act2 = aux_act2; p.slope = slope;
+    hipLaunchKernelGGL(mlp_pair_bf16_kernel, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), 0, (hipStream_t)stream, p);
+    return pm_check_launch("pm_mlp_pair_bf16");
+}

@@ -197,6 +197,15 @@ class ResidualMLP(Module):
                                    for i, n in enumerate(names))
         return self._grouped_ok
 
+    def _pair_fused(self) -> bool:
+        """hidden width 256 on the bf16x3 path: a block's two layers run as one launch (pm_mlp_pair_bf16)"""
+        import os
+
+        if os.environ.get("PM_NO_MLP_PAIR") or self._hidden_units != 256 or self._residual_blocks == 0:
+            return False
+        return all(self._wsf(f"block_{k}/linear_{j}") is not None and self._wsd(f"block_{k}/linear_{j}") is not None
+                   for k in range(self._residual_blocks) for j in range(2))
+
     def out_grad_buffer(self, rows: int) -> torch.Tensor:
         """where the caller should write the gradient w.r.t. this network's output so that backward() needs no copy"""
         nb, hu = self._residual_blocks, self._hidden_units
@@ -212,11 +221,20 @@ class ResidualMLP(Module):
         ops.layer_forward(self.g_in, x.t, self.P("linear_0/w"), self.P("linear_0/b"), h, in_act=x.in_act,
                           wsplit=self._wsf("linear_0"))
         self._h, self._u = [h], []
+        fused = self._pair_fused()
         for k in range(nb):
             u = xs[2 * k + 1]
+            hn = xs[2 * k + 2]
+            if fused:      # both layers of the block in one launch (csrc/pm_mlp.hip)
+                ops.mlp_pair_bf16(h, self._wsf(f"block_{k}/linear_0"), self._wsf(f"block_{k}/linear_1"),
+                                  self.P(f"block_{k}/linear_0/b"), self.P(f"block_{k}/linear_1/b"), None, None, u, hn,
+                                  ACT_RELU, ACT_RELU, ACT_NONE, ACT_NONE)
+                self._u.append(u)
+                self._h.append(hn)
+                h = hn
+                continue
             ops.layer_forward(self.g_hid, h, self.P(f"block_{k}/linear_0/w"), self.P(f"block_{k}/linear_0/b"), u,
                               in_act=ACT_RELU, wsplit=self._wsf(f"block_{k}/linear_0"))
-            hn = xs[2 * k + 2]
             ops.layer_forward(self.g_hid, u, self.P(f"block_{k}/linear_1/w"), self.P(f"block_{k}/linear_1/b"), hn,
                               in_act=ACT_RELU, res=h, wsplit=self._wsf(f"block_{k}/linear_1"))
             self._u.append(u)
@@ -242,12 +260,17 @@ class ResidualMLP(Module):
                 self.wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),
                            in_act=ACT_RELU)
             du = dys[2 * k]
+            dprev = dys[2 * k - 1] if k > 0 else self.buf("dh_0", (rows, hu))
+            if grouped and self._pair_fused():      # both data gradients of the block in one launch
+                ops.mlp_pair_bf16(dh, self._wsd(f"block_{k}/linear_1"), self._wsd(f"block_{k}/linear_0"), None, None, u, h,
+                                  du, dprev, ACT_NONE, ACT_NONE, ACT_RELU, ACT_RELU)
+                dh = dprev
+                continue
             ops.layer_dgrad(self.g_hid, dh, self.P(f"block_{k}/linear_1/w"), du, aux=u, aux_act=ACT_RELU,
                             wsplit=self._wsd(f"block_{k}/linear_1"))
             if not grouped:
                 self.wgrad(self.g_hid, h, du, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"),
                            in_act=ACT_RELU)
-            dprev = dys[2 * k - 1] if k > 0 else self.buf("dh_0", (rows, hu))
             ops.layer_dgrad(self.g_hid, du, self.P(f"block_{k}/linear_0/w"), dprev, aux=h, aux_act=ACT_RELU, res=dh,
                             wsplit=self._wsd(f"block_{k}/linear_0"))
             dh = dprev

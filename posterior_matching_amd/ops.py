@@ -719,6 +719,15 @@ def imputation_psnr(imp, x, psnr, scale: float = 1.0) -> None:
     _call("pm_imputation_psnr", _ptr(imp), _ptr(x), _ptr(psnr), B, S, x.numel() // B, scale)
 
 
+def mlp_pair_bf16(x, w1_split, w2_split, b1, b2, aux1, aux2, out1, out2, in_act, mid_act, aux_act1, aux_act2) -> None:
+    """csrc/pm_mlp.hip: two 256 -> 256 dense layers of a ResidualMLP block in one launch (see include/pmhip.h)"""
+    R, hid = x.shape[0], x.shape[1]
+    work = {"flops": 4.0 * R * hid * hid, "bytes": _nbytes(x, aux1, aux2, out1, out2), "detail": f"B{R} 2x({hid}->{hid})"}
+    _call("pm_mlp_pair_bf16", _ptr(x), w1_split.data_ptr(), w2_split.data_ptr(), _ptr(b1), _ptr(b2), _ptr(aux1), _ptr(aux2),
+          _ptr(out1), _ptr(out2), R, hid, in_act, mid_act, aux_act1, aux_act2, LEAKY_SLOPE, tag="mlp_pair_bf16_kernel",
+          work=work)
+
+
 # ---- PM-VAE evaluation paths (csrc/pm_eval.hip) ------------------------------------------------------------
 def repeat_rows(src, dst, S: int) -> None:
     """dst[b*S + s, :] = src[b, :]"""

@@ -2,15 +2,16 @@
 
 Sums are accumulated with float atomics, so bit equality is not expected; anything above ordering noise is a hazard
 between kernels that run side by side.  (This is the check that exposed the packed-FP32 instability of the thin
-weight-gradient kernel)  Tolerance: 2e-6 of the tensor's own largest entry, the level an
-f32 sum of a few thousand same-sign terms moves when its order changes."""
+weight-gradient kernel)  Tolerance: 1e-5 of the tensor's own largest entry - well above the level an
+f32 sum of a few thousand terms moves when its order changes (bias gradients with cancelling terms reach 2-3e-6); the
+hazard this test exists for produced 1e-4 ... 1e-2."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-6
+TOL = 1e-5
 
 
 def _compare(runs):
