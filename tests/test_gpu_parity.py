@@ -66,7 +66,10 @@ def test_layer_fwd_dgrad_wgrad(kind, B, H, ci, co, k, s, padding):
     from posterior_matching_amd import ops
     from posterior_matching_amd.ops import ACT_LEAKY, LayerGeom
 
-    gen = torch.Generator().manual_seed(hash((kind, B, H, ci, co, k, s)) % 2 ** 31)
+    import zlib
+
+    # a stable per-case seed: hash() of a tuple holding a str changes with PYTHONHASHSEED from run to run
+    gen = torch.Generator().manual_seed(zlib.crc32(repr((kind, B, H, ci, co, k, s, padding)).encode()) % 2 ** 31)
     if kind == "conv":
         geom = LayerGeom.conv(H, H, ci, co, k, s, padding)
     elif kind == "convT":
