@@ -4,6 +4,7 @@ float32 kernels vs a float64 oracle: tolerances are stated per test and sit well
 1e-3 relative bar of BASELINE.json's north_star.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -69,7 +70,8 @@ def test_layer_fwd_dgrad_wgrad(kind, B, H, ci, co, k, s, padding):
     import zlib
 
     # a stable per-case seed: hash() of a tuple holding a str changes with PYTHONHASHSEED from run to run
-    gen = torch.Generator().manual_seed(zlib.crc32(repr((kind, B, H, ci, co, k, s, padding)).encode()) % 2 ** 31)
+    seed = zlib.crc32(repr((kind, B, H, ci, co, k, s, padding)).encode()) + int(os.environ.get("PM_TEST_SEED_OFFSET", "0"))
+    gen = torch.Generator().manual_seed(seed % 2 ** 31)
     if kind == "conv":
         geom = LayerGeom.conv(H, H, ci, co, k, s, padding)
     elif kind == "convT":
@@ -121,11 +123,14 @@ def test_layer_fwd_dgrad_wgrad(kind, B, H, ci, co, k, s, padding):
     dwd, dbd = torch.zeros_like(wd), torch.zeros_like(bd)
     ops.layer_wgrad(geom, xd, dpre, dwd, dbd, bf16=False)          # f32 MFMA
     assert rel_err(dwd, wr.grad) < 2e-6
-    assert rel_err(dbd, br.grad) < 1e-5
+    # a bias gradient is a sum over every position: when the terms cancel (single-channel outputs) the f32 rounding is
+    # small against the terms, not against the result -> the yardstick is sum |dpre| per channel
+    db_scale = (dy * torch.where(pre >= 0, 1.0, 0.01)).abs().sum((0, 1, 2)).max().item()
+    assert (dbd.cpu().double() - br.grad).abs().max().item() < 2e-6 * db_scale
     dwd.zero_(); dbd.zero_()
     ops.layer_wgrad(geom, xd, dpre, dwd, dbd, bf16=True)           # bf16x3 where the shape qualifies
     assert rel_err(dwd, wr.grad) < 3e-5
-    assert rel_err(dbd, br.grad) < 3e-5
+    assert (dbd.cpu().double() - br.grad).abs().max().item() < 3e-5 * db_scale
 
 
 def test_epilogue_aux_res_inact():
