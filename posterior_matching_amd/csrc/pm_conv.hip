@@ -47,6 +47,8 @@ struct GemmArgs {
     float* out;
     long long in_gs, w_gs, out_gs, bias_gs;
     int ksplit;
+    float* out2;   // optional second store: out2 = act2(out) (a layer's pre-activation AND its activation in one launch)
+    int act2;
 };
 
 struct WgradArgs {
@@ -565,7 +567,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, long l
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total_per_group; o += stride) {
         int n = (int)(o % g.N);
         float v = out[o] + (bias ? bias[n] : 0.f);
-        out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
+        v = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
+        out[o] = v;
+        if (p.out2) p.out2[(size_t)grp * p.out_gs + o] = pm_act(v, p.act2, g.slope);
     }
 }
 
@@ -1104,7 +1108,9 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
                 continue;
             }
             float v = acc[r][e] + bv;
-            out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
+            v = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
+            out[o] = v;
+            if (p.out2) p.out2[(size_t)grp * p.out_gs + o] = pm_act(v, p.act2, g.slope);
         }
     }
 }
@@ -1309,7 +1315,9 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
         for (int e = 0; e < 16; ++e) {
             if (ro[e] < 0) continue;
             size_t o = (size_t)ro[e] + n;
-            out[o] = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
+            const float v = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
+            out[o] = v;
+            if (p.out2) p.out2[o] = pm_act(v, p.act2, g.slope);
         }
     }
 }
@@ -1582,7 +1590,9 @@ __global__ __launch_bounds__(256) void patch_d2_bf16_kernel(GemmArgs p, const __
             for (int e = 0; e < 16; ++e) {
                 if (ro[e] < 0) continue;
                 const size_t o = (size_t)ro[e] + n;
-                out[o] = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
+                const float v = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
+                out[o] = v;
+                if (p.out2) p.out2[o] = pm_act(v, p.act2, g.slope);
             }
         }
         __syncthreads();             // stage buffers are rewritten by the next class
@@ -2607,6 +2617,7 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
     GemmArgs a;
     if (!fill_geom(d, a.g, true) || !in || !w || !out) return PM_EINVAL;
     a.in = in; a.w = w; a.bias = bias; a.aux = aux; a.res = res; a.out = out;
+    a.out2 = nullptr; a.act2 = PM_ACT_NONE;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     const bool vec4 = (d->C % 4 == 0) && aligned16(in) && (d->in_gs % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
@@ -2684,9 +2695,10 @@ extern "C" int pm_query_wgrad_plan(const pm_gather_desc* d, int gathered_aligned
 }
 
 // ---- bf16x3 ("split bf16") direct path ----
-extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
-                                   const float* bias, const float* aux, const float* res, float* out) {
+static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
+                                 const float* bias, const float* aux, const float* res, float* out, float* out2, int act2) {
     GemmArgs a;
+    a.out2 = out2; a.act2 = act2;
     if (!fill_geom(d, a.g, true) || !in || !wsplit || !out) return PM_EINVAL;
     if (d->C % 8 != 0 || (d->groups != 1 && d->w_gs % 8 != 0)) return PM_EINVAL;   // C % 32 != 0: zero-padded weight chunks
     if (!aligned16(in) || !aligned16(wsplit) || (d->in_gs % 4) != 0) return PM_EINVAL;
@@ -2758,6 +2770,18 @@ extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, 
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks, G), dim3(256), 0, s, a, total);
     }
     return pm_check_launch("pm_gather_gemm_bf16");
+}
+
+extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
+                                   const float* bias, const float* aux, const float* res, float* out) {
+    return gather_gemm_bf16_impl(stream, d, in, wsplit, bias, aux, res, out, nullptr, PM_ACT_NONE);
+}
+
+extern "C" int pm_gather_gemm_bf16_dual(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
+                                        const float* bias, const float* aux, const float* res, float* out, float* out2,
+                                        int act2) {
+    if (!out2) return PM_EINVAL;
+    return gather_gemm_bf16_impl(stream, d, in, wsplit, bias, aux, res, out, out2, act2);
 }
 
 extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* out_bf16, const pm_split_job* jobs_dev,

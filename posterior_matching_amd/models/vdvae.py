@@ -68,8 +68,10 @@ class Block(Module):
         self.c4 = _Conv(store, f"{name}/c4", LayerGeom.conv(H, W, mid, cout, 1, 1, pad), 0 if zero_last else mid * out_init_div)
         self.H, self.W, self.cin, self.mid, self.cout = H, W, cin, mid, cout
 
-    def _f(self, L: _Conv, x, out, res=None):
-        ops.layer_forward(L.g, x, self.store.p[L.w], self.store.p[L.b], out, res=res, wsplit=self.store.split_view(L.ws_f))
+    def _f(self, L: _Conv, x, out, res=None, out2=None):
+        """out2: gelu(out) from the same launch (pm_gather_gemm_bf16_dual) - the next convolution's input"""
+        ops.layer_forward(L.g, x, self.store.p[L.w], self.store.p[L.b], out, res=res, wsplit=self.store.split_view(L.ws_f),
+                          out2=out2, act2=ops.ACT_GELU if out2 is not None else ops.ACT_NONE)
 
     def forward(self, xg: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, H, W = xg.shape[0], self.H, self.W
@@ -79,9 +81,8 @@ class Block(Module):
         x = xg
         for i, L in enumerate((self.c1, self.c2, self.c3)):
             h = self.buf(f"h{i + 1}", sh(self.mid))
-            self._f(L, x, h)
             g = self.buf(f"g{i + 1}", sh(self.mid))
-            ops.gelu_fwd(h, None, g)
+            self._f(L, x, h, out2=g)          # pre-activation (for gelu' in the backward pass) and gelu(h) in one launch
             self._h.append(h)
             self._g.append(g)
             x = g

@@ -369,7 +369,8 @@ def _patch_d2_form(d: GatherDesc) -> bool:
     return nsteps <= 2048 and lds <= 150 * 1024
 
 
-def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None:
+def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=None, act2=ACT_NONE) -> None:
+    """out2 (optional): a second store out2 = act2(out) from the same launch (pm_gather_gemm_bf16_dual)"""
     tag = work = None
     if _timer is not None:
         dense = desc.KH == desc.KW == desc.IH == desc.IW == desc.OH == desc.OW == 1 and desc.d == 1
@@ -381,6 +382,10 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out) -> None
         elif _patch_d2_form(desc):
             tag = f"patch_d2_bf16_kernel<{2 if desc.N > 32 else 1}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
+    if out2 is not None:
+        _call("pm_gather_gemm_bf16_dual", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
+              _ptr(out), _ptr(out2), act2, tag=tag, work=work)
+        return
     _call("pm_gather_gemm_bf16", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
           _ptr(out), tag=tag, work=work)
 
@@ -452,7 +457,7 @@ def thin_conv(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
 
 
 def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE, res=None, wsplit=None,
-                  tmp=None, **group_kw) -> None:
+                  tmp=None, out2=None, act2=ACT_NONE, **group_kw) -> None:
     """wsplit: this layer's pre-split bf16 weights for the forward direction (ParamStore.split_view);
     when given and the shape qualifies the layer runs on the bf16 matrix cores (bf16x3).
     tmp: [B, IH, IW, k*k] scratch for a wide -> 1-channel transposed conv (per-tap dot products)."""
@@ -464,9 +469,13 @@ def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE,
         work = {"flops": _algorithmic_flops(d), "bytes": _nbytes(x, res, out), "detail": _detail(d)}
         _call("pm_thin_to1_bf16", C.byref(d), _ptr(x), _ptr(w), _ptr(b), None, _ptr(res), _ptr(out),
               tag=f"thin_to1_bf16_kernel<{d.C // 32}>", work=work)
+        if out2 is not None:
+            gelu_fwd(out, None, out2)
         return
     if _thin_ok(d):
         thin_conv(d, x, w, b, None, res, out)
+        if out2 is not None:
+            gelu_fwd(out, None, out2)
         return
     if g.kind == "convT" and g.CO == 1 and g.s == 1 and tmp is not None and res is None and in_act == ACT_NONE:
         # out[p] = sum_tap (x[p + tap] . w[tap]):  T = x @ W' (one GEMM, N = taps) then a shifted sum
@@ -480,9 +489,12 @@ def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE,
     if wsplit is not None and bf16_supported(d):
         if d.groups > 1:
             d.w_gs = wsplit.numel() // d.groups
-        gather_gemm_bf16(d, x, wsplit, b, None, res, out)
+        gather_gemm_bf16(d, x, wsplit, b, None, res, out, out2=out2, act2=act2)
     else:
         gather_gemm(d, x, w, b, None, res, out)
+        if out2 is not None:
+            assert act2 == ACT_GELU, "the unfused second store only exists for gelu"
+            gelu_fwd(out, None, out2)
 
 
 def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, wsplit=None, **group_kw) -> None:
