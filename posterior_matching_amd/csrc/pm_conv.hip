@@ -1634,8 +1634,10 @@ bool plan_patch_d2(const Geom& g, int groups, int rn, PatchD2Plan& pp) {
 template <int RN, int DD>
 void launch_direct_bf16(hipStream_t s, const GemmArgs& a, dim3 grid, const __bf16* ws, int npad, long long plane) {
     const Geom& g = a.g;
-    const bool dense = DD == 1 && g.KH == 1 && g.KW == 1 && g.IH == 1 && g.IW == 1 && g.OH == 1 && g.OW == 1 &&
-                       g.a == 1 && g.off == 0 && g.offx == 0;
+    // plain matrix rows: hk.Linear, and every 1x1 stride-1 unpadded convolution (position m of the output IS position m
+    // of the input in NHWC order) - no taps, no coordinates, no tap lists: 6 us less per launch on the VDVAE's 1x1 layers
+    const bool dense = DD == 1 && g.KH == 1 && g.KW == 1 && g.IH == g.OH && g.IW == g.OW && g.a == 1 && g.off == 0 &&
+                       g.offx == 0 && g.PY == 1 && g.PX == 1;
 #define PM_LB(ACT)                                                                                                   \
     do {                                                                                                              \
         if (dense) hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, 1, ACT, true>), grid, dim3(256), 0, s, a, ws, npad, plane); \

@@ -373,7 +373,8 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=No
     """out2 (optional): a second store out2 = act2(out) from the same launch (pm_gather_gemm_bf16_dual)"""
     tag = work = None
     if _timer is not None:
-        dense = desc.KH == desc.KW == desc.IH == desc.IW == desc.OH == desc.OW == 1 and desc.d == 1
+        dense = (desc.KH == desc.KW == 1 and desc.IH == desc.OH and desc.IW == desc.OW and desc.d == 1 and desc.a == 1
+                 and desc.off == 0 and desc.off_x == 0)
         wgs64 = -(-desc.B * desc.OH * desc.OW // 128) * -(-desc.N // 64) * desc.groups
         rn = 2 if desc.N > 32 and wgs64 >= 512 else 1        # pm_gather_gemm_bf16: 32-column workgroups on short grids
         tag = f"direct_gemm_bf16_kernel<{rn}, {desc.d}, {desc.in_act}, {'true' if dense else 'false'}>"   # template args

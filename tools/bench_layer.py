@@ -37,6 +37,11 @@ CASES = [
     ("enc5 wgrad", LayerGeom.conv(7, 7, 64, 128, 7, 1, "VALID"), "wgrad"),
     ("mlp dgrad 8192x256x256", LayerGeom.dense(256, 256), "dgrad8192"),
     ("mlp grouped wgrad 4x8192x256x256", LayerGeom.dense(256, 256), "gwgrad8192"),
+    ("vd 1x1 192->48 14x14", LayerGeom.conv(14, 14, 192, 48, 1, 1, "SAME"), "fwd"),
+    ("vd 3x3 48->48 14x14", LayerGeom.conv(14, 14, 48, 48, 3, 1, "SAME"), "fwd"),
+    ("vd 1x1 48->192 14x14", LayerGeom.conv(14, 14, 48, 192, 1, 1, "SAME"), "fwd"),
+    ("vd dense 192->48", LayerGeom.dense(192, 48), "fwdrows"),
+    ("vd dense 48->192", LayerGeom.dense(48, 192), "fwdrows"),
     ("thin enc0 fwd 28x28 1->32 k5", LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME"), "fwd"),
     ("thin penc0 fwd 28x28 2->32 k5", LayerGeom.conv(28, 28, 2, 32, 5, 1, "SAME"), "fwd"),
     ("thin dec6 fwd 28x28 32->1 k5", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "fwd"),
@@ -54,7 +59,9 @@ def main():
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         for name, g, what in CASES:
-            B = 8192 if what.endswith("8192") else 256
+            B = 8192 if what.endswith("8192") else int(os.environ.get("PM_BENCH_B", "256"))
+            if what == "fwdrows":
+                B, what = B * 196, "fwd"
             x = torch.randn((B, g.IH, g.IW, g.CI), device=d)
             w = torch.randn(g.weight_shape, device=d) * 0.05
             b = torch.zeros(g.CO, device=d)
