@@ -202,6 +202,14 @@ class Workspace:
         if aux is not None and self.overlap_wgrad:
             ops.wait_stream(cur, aux)
 
+    def join_all_aux(self) -> None:
+        """the current stream waits for every companion stream that carried weight gradients (models whose backward
+        runs on several streams)"""
+        cur = torch.cuda.current_stream(self.device)
+        if self.overlap_wgrad:
+            for aux in self._aux_streams.values():
+                ops.wait_stream(cur, aux)
+
     def get(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         key = (name, tuple(int(s) for s in shape))
         buf = self._bufs.get(key)

@@ -697,7 +697,7 @@ class PosteriorMatchingVDVAE(Module):
         else:
             self.encoder.backward(dacts)
             self.masked_encoder.backward(dmacts)
-        self.ws.join_aux()
+        self.ws.join_all_aux()
 
     def zero_grad(self) -> None:
         ops.fill_zero(self.store.flat_g)
