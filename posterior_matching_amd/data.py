@@ -14,6 +14,8 @@ from .masking import get_mask_generator
 def data_shape(dataset: str):
     if "mnist" in dataset:
         return (28, 28, 1)
+    if dataset == "celeb_a":
+        return (64, 64, 3)                  # utils.py:76-85: centre crop [45:-45, 25:-25] resized to 64 x 64
     return {"gas": (8,), "power": (6,), "hepmass": (21,), "miniboone": (43,), "bsds": (63,)}[dataset]
 
 
@@ -42,6 +44,8 @@ class SyntheticDataset:
             if arrays is not None:
                 idx = rng.integers(0, arrays.shape[0], size=batch_size)
                 x = arrays[idx].astype(np.float32)
+            elif self.key == "image" and name == "celeb_a":
+                x = rng.uniform(size=(batch_size,) + shape).astype(np.float32)     # U[0, 1] RGB
             elif self.key == "image":
                 # MNIST-like: ~19 % of the pixels carry ink, values in [0, 1] (utils.py:50-54: x / 255)
                 x = (rng.uniform(size=(batch_size,) + shape) * (rng.uniform(size=(batch_size,) + shape) < 0.19)).astype(np.float32)
@@ -53,7 +57,8 @@ class SyntheticDataset:
                     x = x + rng.normal(scale=config["training_noise"], size=x.shape).astype(np.float32)
             batch = {self.key: torch.from_numpy(x).to(device)}
             if gen is not None:
-                batch["mask"] = torch.from_numpy(gen((batch_size,) + shape)).to(device)
+                mshape = (batch_size,) + shape
+                batch["mask"] = torch.from_numpy(np.ascontiguousarray(gen(mshape))).to(device)
             elif self._device_gen is not None:
                 mshape = (batch_size,) + (shape[:-1] + (1,) if self.key == "image" else shape)
                 batch["mask"] = torch.empty(mshape, dtype=torch.float32, device=device)

@@ -35,46 +35,250 @@ class BernoulliMaskGenerator(MaskGenerator):
         return self._rng.binomial(1, self.p, size=shape)
 
 
-class MNISTMaskGenerator(MaskGenerator):
-    """Per-example mixture, weights [2,1,1,1,1,2,2] (reference masking.py:235-249): pixel-Bernoulli(0.5);
-    top / left / bottom / right half missing; a random dim/2 square missing; a random rectangle
-    covering 30-100 % of the image missing.  Shape [B, H, W, 1]."""
+def _check_image_shape(shape):
+    if len(shape) != 4:
+        raise AssertionError(f"expected shape of size [batch_dim, height, width, channels], got {tuple(shape)}")
 
-    def __init__(self, dim: int = 28, **kw):
+
+def _child_seed(rng: np.random.Generator) -> int:
+    return int(rng.integers(0, 2 ** 63 - 1))
+
+
+class ImageBernoulliMaskGenerator(MaskGenerator):
+    """each PIXEL observed with probability p, one mask channel (reference masking.py:94-104)."""
+
+    def __init__(self, p: float = 0.2, **kw):
         super().__init__(**kw)
-        self.dim = dim
-        self.weights = np.array([2, 1, 1, 1, 1, 2, 2], np.float64) / 10.0
+        self.p = p
 
     def call(self, shape):
-        if len(shape) != 4:
-            raise AssertionError(f"expected shape of size [batch_dim, height, width, channels], got {shape}")
+        _check_image_shape(shape)
+        return self._rng.binomial(1, self.p, size=tuple(shape[:-1]) + (1,))
+
+
+class RectangleMaskGenerator(MaskGenerator):
+    """a random axis-aligned rectangle covering min_prop..max_prop of the image is missing; corner pairs are
+    redrawn until the area bound holds (reference masking.py:107-140)."""
+
+    def __init__(self, min_prop: float = 0.3, max_prop: float = 1.0, **kw):
+        super().__init__(**kw)
+        self.min_prop, self.max_prop = min_prop, max_prop
+
+    def call(self, shape):
+        _check_image_shape(shape)
         bsz, h, w, _ = shape
-        half = self.dim // 2
-        kinds = self._rng.choice(7, size=bsz, p=self.weights)
         out = np.ones((bsz, h, w, 1), np.float32)
-        for i, kind in enumerate(kinds):
-            m = out[i, :, :, 0]
-            if kind == 0:
-                m[...] = self._rng.binomial(1, 0.5, size=(h, w))
-            elif kind == 1:
-                m[0:self.dim, 0:half] = 0           # FixedRectangle(y1=0, x1=0, y2=dim, x2=half)
-            elif kind == 2:
-                m[0:half, 0:self.dim] = 0
-            elif kind == 3:
-                m[0:self.dim, half:self.dim] = 0
-            elif kind == 4:
-                m[half:self.dim, 0:self.dim] = 0
-            elif kind == 5:
-                x0, y0 = self._rng.integers(w - half), self._rng.integers(h - half)
-                m[y0:y0 + half, x0:x0 + half] = 0
-            else:
-                while True:
-                    x1, x2 = sorted(self._rng.integers(0, w, 2))
-                    y1, y2 = sorted(self._rng.integers(0, h, 2))
-                    if 0.3 * w * h <= (x2 - x1 + 1) * (y2 - y1 + 1) <= 1.0 * w * h:
-                        break
-                m[y1:y2 + 1, x1:x2 + 1] = 0
+        for i in range(bsz):
+            while True:
+                x1, x2 = np.sort(self._rng.integers(0, w, 2))
+                y1, y2 = np.sort(self._rng.integers(0, h, 2))
+                if self.min_prop * w * h <= (x2 - x1 + 1) * (y2 - y1 + 1) <= self.max_prop * w * h:
+                    break
+            out[i, y1:y2 + 1, x1:x2 + 1] = 0
         return out
+
+
+class FixedRectangleMaskGenerator(MaskGenerator):
+    """rows y1:y2, columns x1:x2 missing (reference masking.py:143-157)."""
+
+    def __init__(self, y1, x1, y2, x2, **kw):
+        super().__init__(**kw)
+        self.y1, self.x1, self.y2, self.x2 = y1, x1, y2, x2
+
+    def call(self, shape):
+        _check_image_shape(shape)
+        out = np.ones(tuple(shape[:-1]) + (1,), np.float32)
+        out[:, self.y1:self.y2, self.x1:self.x2] = 0
+        return out
+
+
+class SquareMaskGenerator(MaskGenerator):
+    """one random size x size square missing, the same square for every example of the call (reference
+    masking.py:160-174; the per-example mixtures call it with batch size 1)."""
+
+    def __init__(self, size, **kw):
+        super().__init__(**kw)
+        self.size = size
+
+    def call(self, shape):
+        _check_image_shape(shape)
+        _, h, w, _ = shape
+        out = np.ones(tuple(shape[:-1]) + (1,), np.float32)
+        x0, y0 = self._rng.integers(w - self.size), self._rng.integers(h - self.size)
+        out[:, y0:y0 + self.size, x0:x0 + self.size] = 0
+        return out
+
+
+def _bicubic_taps(out_coords: np.ndarray, in_size: int, scale: float):
+    """Pillow's resampling coefficients (Resample.c precompute_coeffs with the bicubic filter, a = -0.5, support 2)
+    for the given OUTPUT coordinates of an in_size -> in_size/scale upscale: -> (first tap index [n], weights [n, 5]
+    float64, zero-padded).  Upscaling leaves the filter unscaled, so at most 5 input samples meet an output pixel."""
+    centre = (out_coords.astype(np.float64) + 0.5) * scale
+    lo = np.maximum((centre - 2.0 + 0.5).astype(np.int64), 0)
+    hi = np.minimum((centre + 2.0 + 0.5).astype(np.int64), in_size)
+    j = np.arange(5)[None, :]
+    t = np.abs((j + lo[:, None]) - centre[:, None] + 0.5)
+    a = -0.5
+    near = ((a + 2.0) * t - (a + 3.0)) * t * t + 1.0
+    far = (((t - 5.0) * t + 8.0) * t - 4.0) * a
+    w = np.where(t < 1.0, near, np.where(t < 2.0, far, 0.0))
+    w = np.where(j < (hi - lo)[:, None], w, 0.0)
+    tot = np.zeros(len(centre))
+    for k in range(5):                       # Pillow sums the taps left to right in double precision
+        tot = tot + w[:, k]
+    return lo, w / np.where(tot != 0.0, tot, 1.0)[:, None]
+
+
+def bicubic_window(low: np.ndarray, y0: int, x0: int, height: int, width: int, out_size: int) -> np.ndarray:
+    """Rows y0:y0+height, columns x0:x0+width of PIL.Image.fromarray(low).resize((out_size, out_size), BICUBIC) for a
+    float32 `low`, computed WITHOUT materialising the out_size x out_size image: horizontal pass (float64 sums,
+    rounded to float32) over the few low-resolution rows the window touches, then the vertical pass - Pillow's order
+    of operations, so the result is bit-identical to the crop of the full resize (tests/test_host_cpu.py)."""
+    scale = low.shape[0] / out_size
+    ylo, yw = _bicubic_taps(np.arange(y0, y0 + height), low.shape[0], scale)
+    xlo, xw = _bicubic_taps(np.arange(x0, x0 + width), low.shape[1], low.shape[1] / out_size)
+    r0, r1 = int(ylo.min()), int(min(ylo.max() + 5, low.shape[0]))
+    rows = low[r0:r1].astype(np.float64)
+    hor = np.zeros((r1 - r0, width))
+    for k in range(5):
+        cols = np.minimum(xlo + k, low.shape[1] - 1)
+        hor = hor + rows[:, cols] * xw[None, :, k]
+    hor = hor.astype(np.float32).astype(np.float64)
+    out = np.zeros((height, width))
+    for k in range(5):
+        rr = np.minimum(ylo + k, low.shape[0] - 1) - r0
+        out = out + hor[rr, :] * yw[:, k, None]
+    return out.astype(np.float32)
+
+
+class RandomPatternMaskGenerator(MaskGenerator):
+    """Blob-shaped missing regions (reference masking.py:177-232): a resolution*max_size square of uniform noise is
+    upsampled bicubically to max_size x max_size and thresholded at `density`; every mask is a random window of it whose
+    covered fraction lies within density +- density_std; the noise is redrawn after update_freq * max_size^2 pixels
+    have been handed out.  The reference materialises the 10 000 x 10 000 pattern (400 MB) with PIL; here only the
+    requested window is interpolated (bicubic_window: the same arithmetic, bit-identical to a crop of PIL's resize)."""
+
+    def __init__(self, max_size=10000, resolution=0.06, density=0.25, update_freq=1, **kw):
+        super().__init__(**kw)
+        self.max_size, self.resolution, self.density, self.update_freq = max_size, resolution, density, update_freq
+        self._regenerate_cache()
+
+    def _regenerate_cache(self):
+        n = int(self.resolution * self.max_size)
+        self.low_pattern = self._rng.uniform(0.0, 1.0, size=(n, n)).astype(np.float32)
+        self.points_used = 0
+
+    def window(self, y0, x0, height, width):
+        """pattern[y0:y0+height, x0:x0+width] (1 = inside a blob)"""
+        return (bicubic_window(self.low_pattern, y0, x0, height, width, self.max_size) < self.density).astype(np.float32)
+
+    def call(self, shape, density_std=0.05):
+        _check_image_shape(shape)
+        bsz, h, w, _ = shape
+        out = np.empty((bsz, h, w, 1), np.float32)
+        for i in range(bsz):
+            while True:
+                x0 = int(self._rng.integers(0, self.max_size - w + 1))
+                y0 = int(self._rng.integers(0, self.max_size - h + 1))
+                res = self.window(y0, x0, h, w)
+                if self.density - density_std < res.mean() < self.density + density_std:
+                    break
+            out[i, :, :, 0] = 1.0 - res
+            self.points_used += w * h
+            if self.update_freq * self.max_size ** 2 < self.points_used:
+                self._regenerate_cache()
+        return out
+
+
+class MixtureMaskGenerator(MaskGenerator):
+    """one sub-generator per example (or per batch with batch_level), drawn with the given weights (reference
+    masking.py:24-47)."""
+
+    def __init__(self, generators, weights=None, batch_level=False, **kw):
+        super().__init__(**kw)
+        self.generators = list(generators)
+        w = np.ones(len(self.generators)) if weights is None else np.asarray(weights, np.float64)
+        assert len(w) == len(self.generators)
+        self.weights, self.batch_level = w / w.sum(), batch_level
+
+    def call(self, shape):
+        if self.batch_level:
+            return self.generators[int(self._rng.choice(len(self.generators), p=self.weights))](shape)
+        picks = self._rng.choice(len(self.generators), size=shape[0], p=self.weights)
+        return np.concatenate([self.generators[i]((1,) + tuple(shape[1:])) for i in picks], axis=0)
+
+
+def _half_plane_mixture(dim, pixel_p, rect_props, rng):
+    half = dim // 2
+    s = lambda: _child_seed(rng)   # noqa: E731
+    return [ImageBernoulliMaskGenerator(pixel_p, seed=s()),
+            FixedRectangleMaskGenerator(0, 0, dim, half), FixedRectangleMaskGenerator(0, 0, half, dim),
+            FixedRectangleMaskGenerator(0, half, dim, dim), FixedRectangleMaskGenerator(half, 0, dim, dim),
+            SquareMaskGenerator(half, seed=s()), RectangleMaskGenerator(*rect_props, seed=s())], [2, 1, 1, 1, 1, 2, 2]
+
+
+class MNISTMaskGenerator(MixtureMaskGenerator):
+    """Per-example mixture, weights [2,1,1,1,1,2,2] (reference masking.py:235-249): pixel-Bernoulli(0.5);
+    left / top / right / bottom half missing; a random dim/2 square missing; a random rectangle
+    covering 30-100 % of the image missing.  Shape [B, H, W, 1]."""
+
+    def __init__(self, dim: int = 28, seed=None, **kw):
+        gens, w = _half_plane_mixture(dim, 0.5, (0.3, 1.0), np.random.default_rng(seed))
+        super().__init__(gens, weights=w, seed=seed, **kw)
+        self.dim = dim
+
+    def call(self, shape):
+        _check_image_shape(shape)
+        return super().call(shape)
+
+
+class OmniglotMaskGenerator(MixtureMaskGenerator):
+    """reference masking.py:252-267"""
+
+    def __init__(self, seed=None, **kw):
+        gens, w = _half_plane_mixture(28, 0.5, (0.1, 0.6), np.random.default_rng(seed))
+        super().__init__(gens, weights=w, seed=seed, **kw)
+
+
+class Cifar10MaskGenerator(MixtureMaskGenerator):
+    """reference masking.py:270-286"""
+
+    def __init__(self, seed=None, **kw):
+        gens, w = _half_plane_mixture(32, 0.3, (0.1, 0.5), np.random.default_rng(seed))
+        super().__init__(gens, weights=w, seed=seed, **kw)
+
+
+_GCF_RECTS = [(26, 17, 58, 36), (26, 29, 58, 48), (26, 15, 37, 50), (26, 15, 37, 34), (26, 31, 37, 50), (43, 20, 62, 44)]
+_SIIDGM_RECTS = [(16, 16, 48, 48), (0, 0, 64, 32), (0, 0, 32, 64), (0, 32, 64, 64), (32, 0, 64, 64)]
+
+
+class GCFMaskGenerator(MixtureMaskGenerator):
+    """six fixed face-region rectangles of a 64 x 64 image, equal weights (reference masking.py:289-300)"""
+
+    def __init__(self, seed=None, **kw):
+        super().__init__([FixedRectangleMaskGenerator(*r) for r in _GCF_RECTS], seed=seed, **kw)
+
+
+class SIIDGMMaskGenerator(MixtureMaskGenerator):
+    """random pattern / pixel-Bernoulli(0.2) / centre square / four half planes of a 64 x 64 image, weights
+    [2,2,2,1,1,1,1] (reference masking.py:303-314)"""
+
+    def __init__(self, seed=None, max_size=10000, resolution=0.06, **kw):
+        rng = np.random.default_rng(seed)
+        gens = [RandomPatternMaskGenerator(max_size=max_size, resolution=resolution, seed=_child_seed(rng)),
+                ImageBernoulliMaskGenerator(0.2, seed=_child_seed(rng))]
+        gens += [FixedRectangleMaskGenerator(*r) for r in _SIIDGM_RECTS]
+        super().__init__(gens, weights=[2, 2, 2, 1, 1, 1, 1], seed=seed, **kw)
+
+
+class CelebAMaskGenerator(MixtureMaskGenerator):
+    """SIIDGM / GCF / random rectangle (30-100 %) with weights [1,1,2] (reference masking.py:317-325)"""
+
+    def __init__(self, seed=None, **kw):
+        rng = np.random.default_rng(seed)
+        gens = [SIIDGMMaskGenerator(seed=_child_seed(rng)), GCFMaskGenerator(seed=_child_seed(rng)),
+                RectangleMaskGenerator(seed=_child_seed(rng))]
+        super().__init__(gens, weights=[1, 1, 2], seed=seed, **kw)
 
 
 class UniformMaskGenerator(MaskGenerator):
@@ -193,7 +397,8 @@ class DeviceImageMixtureMaskGenerator(DeviceMaskGenerator):
 
 
 _GENERATORS = {"BernoulliMaskGenerator": BernoulliMaskGenerator, "UniformMaskGenerator": UniformMaskGenerator,
-               "MNISTMaskGenerator": MNISTMaskGenerator}
+               "MNISTMaskGenerator": MNISTMaskGenerator, "OmniglotMaskGenerator": OmniglotMaskGenerator,
+               "CelebAMaskGenerator": CelebAMaskGenerator}
 
 
 def get_mask_generator(mask_generator_name: str, device=None, **kwargs):

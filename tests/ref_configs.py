@@ -79,3 +79,29 @@ def pm_vdvae_mnist():
         "ema_rate": 0.999, "gradient_clip": 200.0, "lr": 0.00015,
         "steps": 500000, "validation_freq": 5000,
     }
+
+
+def vqvae_celeb_a():
+    """configs/vqvae_celeb_a.py:4-30 of the reference (stage-1 VQ-VAE on 64 x 64 RGB; 16 x 16 code grid, K = 512)."""
+    return {
+        "data": {"dataset": "celeb_a", "train_split": "train", "validation_split": "validation",
+                 "train_batch_size": 64, "val_batch_size": 64},
+        "model": {"embedding_dim": 64, "num_embeddings": 512, "hidden_units": 128, "residual_hidden_units": 32,
+                  "residual_blocks": 2, "decay": 0.99, "use_ema": True, "commitment_cost": 0.25,
+                  "output_channels": 3},
+        "steps": 100000, "validation_freq": 1000, "learning_rate": 3e-4,
+    }
+
+
+def pm_vqvae_celeb_a():
+    """configs/pm_vqvae_celeb_a.py:4-40 of the reference (stage 2: 12-resnet PixelCNN over the 16 x 16 codes; per-device
+    batch 32; BASELINE quotes global 128 on 8 GPUs = 16 per GPU)."""
+    return {
+        "data": {"dataset": "celeb_a", "train_split": "train", "validation_split": "validation",
+                 "train_batch_size": 32, "val_batch_size": 32, "mask_generator": "CelebAMaskGenerator"},
+        "vqvae_dir": "runs/vqvae-celeb_a-20220227-111869",
+        "pixel_cnn": {"image_shape": (16, 16), "num_resnet": 12, "num_hierarchies": 1, "num_filters": 128, "dropout": 0.5},
+        "conditional_dim": 512,
+        "steps": 150000, "validation_freq": 2000,
+        "lr_schedule": {"init_value": 3e-4, "decay_rate": 0.999995, "transition_steps": 1},
+    }

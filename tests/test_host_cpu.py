@@ -15,10 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_configs_match_reference_values():
     from posterior_matching_amd.config_dict import load_config_file
-    from tests.ref_configs import pm_vae_gas, pm_vae_mnist, pm_vdvae_mnist, pm_vqvae_mnist, vqvae_mnist
+    from tests.ref_configs import (pm_vae_gas, pm_vae_mnist, pm_vdvae_mnist, pm_vqvae_celeb_a, pm_vqvae_mnist,
+                                   vqvae_celeb_a, vqvae_mnist)
 
     for name, ref in (("pm_vae_mnist", pm_vae_mnist()), ("pm_vae_gas", pm_vae_gas()), ("vqvae_mnist", vqvae_mnist()),
-                      ("pm_vqvae_mnist", pm_vqvae_mnist()), ("pm_vdvae_mnist", pm_vdvae_mnist())):
+                      ("pm_vqvae_mnist", pm_vqvae_mnist()), ("pm_vdvae_mnist", pm_vdvae_mnist()),
+                      ("vqvae_celeb_a", vqvae_celeb_a()), ("pm_vqvae_celeb_a", pm_vqvae_celeb_a())):
         cfg = load_config_file(os.path.join(ROOT, "configs", name + ".py")).to_dict()
         assert cfg == ref, name
 
@@ -53,9 +55,72 @@ def test_mask_generators():
     g = get_mask_generator("BernoulliMaskGenerator", seed=1)((1000, 8))
     assert g.shape == (1000, 8) and abs(g.mean() - 0.5) < 0.03
     with pytest.raises(KeyError):
-        get_mask_generator("CelebAMaskGenerator")
+        get_mask_generator("NoSuchMaskGenerator")
     with pytest.raises(AssertionError):
         get_mask_generator("MNISTMaskGenerator")((3, 784))
+
+
+def test_celeba_mask_mixture_and_bicubic_window_matches_pillow():
+    """CelebAMaskGenerator (reference masking.py:177-232,289-325): the random-pattern component interpolates only the
+    requested window; that window must be bit-identical to a crop of Pillow's full BICUBIC resize (the third-party
+    routine the reference calls at masking.py:196-198) - the one external pin this generator has."""
+    from PIL import Image
+
+    from posterior_matching_amd.masking import (RandomPatternMaskGenerator, SIIDGMMaskGenerator, bicubic_window,
+                                                get_mask_generator)
+
+    rng = np.random.default_rng(0)
+    low = rng.uniform(size=(60, 60)).astype(np.float32)
+    full = np.array(Image.fromarray(low).resize((1000, 1000), Image.BICUBIC))
+    for y0, x0, h, w in [(0, 0, 64, 64), (936, 936, 64, 64), (500, 3, 64, 17), (7, 990, 30, 10), (123, 456, 1, 1)]:
+        assert np.array_equal(bicubic_window(low, y0, x0, h, w, 1000), full[y0:y0 + h, x0:x0 + w]), (y0, x0)
+    gen = RandomPatternMaskGenerator(max_size=2000, resolution=0.06, seed=3)
+    m = gen((50, 64, 64, 1))
+    cover = 1.0 - m.mean(axis=(1, 2, 3))
+    assert m.shape == (50, 64, 64, 1) and set(np.unique(m)) <= {0.0, 1.0} and (np.abs(cover - 0.25) < 0.05).all()
+    assert gen.points_used == 50 * 64 * 64
+    gen.update_freq, gen.points_used = 1e-2, 0                # 40 000 points: the cache is redrawn by the 10th mask
+    before = gen.low_pattern.copy()
+    gen((10, 64, 64, 1))
+    assert not np.array_equal(before, gen.low_pattern) and gen.points_used == 0
+    s = SIIDGMMaskGenerator(seed=1, max_size=2000)((300, 64, 64, 1))
+    assert s.shape == (300, 64, 64, 1) and 0.3 < s.mean() < 0.8
+    c = get_mask_generator("CelebAMaskGenerator", seed=0)((600, 64, 64, 1))
+    assert c.shape == (600, 64, 64, 1) and c.dtype == np.float32 and set(np.unique(c)) <= {0.0, 1.0}
+    frac = c.mean(axis=(1, 2, 3))
+    # half of the examples are area-bounded rectangles (>= 30 % missing); the six GCF boxes leave 0.80-0.90 observed
+    assert (frac <= 0.7 + 1e-6).mean() > 0.45 and frac.min() >= 0.0 and ((frac > 0.8) & (frac < 0.91)).mean() > 0.1
+    o = get_mask_generator("OmniglotMaskGenerator", seed=2)((64, 28, 28, 1))
+    assert o.shape == (64, 28, 28, 1)
+
+
+def test_reference_import_paths_resolve():
+    """every import path INTEGRATION.md shows goes through the `posterior_matching` shim package (reference
+    posterior_matching/models/*.py, masking.py, utils.py); building a model needs the GPU, importing must not."""
+    import importlib
+
+    want = {
+        "posterior_matching.models.vae": ["PosteriorMatchingVAE"],
+        "posterior_matching.models.networks": ["get_network", "ConvEncoder", "ConvDecoder", "ResidualMLP"],
+        "posterior_matching.models.distributions": ["get_distribution", "TriLGaussian", "AutoregressiveGMM", "Bernoulli",
+                                                    "IdentityGaussian", "DiagonalGaussian"],
+        "posterior_matching.models.vqvae": ["VQVAE", "VQVAEPartialEncoder", "vqvae_impute", "ConvResidualEncoder",
+                                            "ConvResidualDecoder"],
+        "posterior_matching.models.pixel_cnn": ["PixelCNN"],
+        "posterior_matching.models.vdvae": ["PosteriorMatchingVDVAE", "Encoder", "Block", "PosteriorMatchingDecoderBlock",
+                                            "parse_layer_string"],
+        "posterior_matching.masking": ["get_mask_generator", "MNISTMaskGenerator", "CelebAMaskGenerator",
+                                       "BernoulliMaskGenerator", "UniformMaskGenerator"],
+        "posterior_matching.utils": ["load_datasets", "cyclical_annealing_schedule", "make_run_dir",
+                                     "configure_environment", "TensorBoardCallback"],
+    }
+    for mod, names in want.items():
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for mod in set(re.findall(r"from (posterior_matching(?:_amd)?[\w.]*) import", text)):
+        importlib.import_module(mod)
 
 
 def test_library_exports_every_declared_symbol():
