@@ -285,7 +285,7 @@ class PMVQVAETrainStep(_PlannedStep):
         if getattr(pixel_cnn, "store", None) is None:          # not built yet (models.vqvae.build_partial_posterior)
             store, ws = ParamStore(), Workspace(dev)
             partial_encoder.ws = pixel_cnn.ws = ws
-            xb_shape = tuple(x_shape[:-1]) + (2 * x_shape[-1],)
+            xb_shape = tuple(x_shape[:-1]) + (x_shape[-1] + 1,)     # [x*b | b], b [B,H,W,1] (train_pm_vqvae.py:87-89)
             (cond_dim,) = partial_encoder.build(store, "partial_encoder", xb_shape)
             pixel_cnn.build(store, "pixel_cnn", cond_dim)
             store.allocate(dev, seed)

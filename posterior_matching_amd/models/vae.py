@@ -77,7 +77,8 @@ class PosteriorMatchingVAE(Module):
         device = torch.device(device or self._device or "cuda:0")
         store, ws = ParamStore(), Workspace(device)
         x_shape = tuple(int(s) for s in x_shape)
-        xb_shape = x_shape[:-1] + (2 * x_shape[-1],)
+        # [x*b | b] (vae.py:132-133): image masks are [B,H,W,1], feature masks have the features' shape (masking.py:344-348)
+        xb_shape = x_shape[:-1] + ((x_shape[-1] + 1,) if len(x_shape) == 3 else (2 * x_shape[-1],))
         mods = [self.encoder_net, self.posterior_dist, self.decoder_net, self.decoder_dist, self.partial_encoder_net,
                 self.partial_posterior_dist]
         for m in mods:

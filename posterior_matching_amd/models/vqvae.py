@@ -484,7 +484,7 @@ def build_partial_posterior(vqvae: VQVAE, conditional_dim: int, pixel_cnn_config
     pc_cfg["num_indices"] = vqvae.config["num_embeddings"]            # train_pm_vqvae.py:78
     pcnn = PixelCNN(**pc_cfg)
     penc.ws = pcnn.ws = ws
-    xb_shape = tuple(x_shape[:-1]) + (2 * x_shape[-1],)
+    xb_shape = tuple(x_shape[:-1]) + (x_shape[-1] + 1,)             # [x*b | b]: image masks have ONE channel (masking.py:346)
     (cond_dim,) = penc.build(store, "partial_encoder", xb_shape)
     pcnn.build(store, "pixel_cnn", cond_dim)
     store.allocate(dev, seed)
