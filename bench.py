@@ -21,6 +21,71 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
+# SURVEY.md 8(d) algorithmic figures per training example of configs/pm_vae_mnist.py
+F_ALG_EXECUTED = 563.8e6        # 6 x forward MACs with only the 30 consumed AR-GMM head columns per scan step computed
+F_ALG_AS_WRITTEN = 609.5e6      # the same with all 960 head columns, as the reference states the scan
+B_ALG_F32 = 2.25e6              # bytes per example: f32 activations written once + re-read once, weights, gradients, Adam
+
+
+def _short(name):
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    if ">(" in name:
+        return name.split(">(")[0] + ">"
+    return name.split("(")[0]
+
+
+def pmc_traffic_child(counter, timeout_s=240):
+    """One rocprofv3 PMC pass (its own run, one counter - MI355X_MICROARCH.md HBM section) over a short serial run of THIS
+    script in a child process; must be called before this process touches the GPU.  -> {kernel: (sum KB, launches)}"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="pm_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--serial", "--no-cpu-baseline", "--no-pmc", "--steps", "3", "--warmup", "2",
+               "--profile-steps", "0", "--no-f32-aux"]
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       check=True)
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None
+        tot, disp = {}, {}
+        with open(files[-1]) as fp:
+            for r in csv.DictReader(fp):
+                if r["Counter_Name"] != counter:
+                    continue
+                n = _short(r["Kernel_Name"])
+                tot[n] = tot.get(n, 0.0) + float(r["Counter_Value"])
+                disp.setdefault(n, set()).add(r["Dispatch_Id"])
+        return {n: (tot[n], len(disp[n])) for n in tot}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measured_traffic():
+    """HBM-side bytes per launch and kernel from two PMC passes of this run: 2 x FETCH_SIZE + WRITE_SIZE (counters in
+    KB; FETCH_SIZE tallies the 128-B requests of 16-B-per-lane loads at 64 B on gfx950: doubled, as the guide prescribes)"""
+    fetch = pmc_traffic_child("FETCH_SIZE")
+    if fetch is None:
+        return None
+    write = pmc_traffic_child("WRITE_SIZE")
+    if write is None:
+        return None
+    out = {}
+    for n, (kb, launches) in fetch.items():
+        wkb, wl = write.get(n, (0.0, 1))
+        out[n] = int((2.0 * kb / max(launches, 1) + wkb / max(wl, 1)) * 1024)
+    return out
 
 
 def cpu_baseline(cfg, xs, B, budget_s=12.0):
@@ -65,22 +130,43 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one stream (clean per-kernel durations for rocprofv3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 path with several ranks on ONE GPU)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic)")
+    ap.add_argument("--no-f32-aux", action="store_true", help="skip the strict-f32 throughput sample (aux.f32_images_per_sec)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the backward pass instead of "
+                                                              "reverse-order buckets overlapped with it")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    from posterior_matching_amd import ops, optim
-    from posterior_matching_amd.data import SyntheticDataset
-    from posterior_matching_amd.engine import PMVAETrainStep
-    from posterior_matching_amd.models import PosteriorMatchingVAE
-    from tests.ref_configs import pm_vae_mnist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+
+    # HBM-side traffic per kernel: two PMC passes over a short run of this same workload, each in a child process
+    # BEFORE this process initialises the GPU (counters cannot be read from inside the measured process)
+    traffic, traffic_src = None, None
+    if world == 1 and not args.no_pmc and args.profile_steps > 0:
+        traffic = measured_traffic()
+        traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes, 2*FETCH_SIZE + WRITE_SIZE per launch"
+    if traffic is None and world == 1 and args.profile_steps > 0:
+        for name in ("r02_final_pmc_traffic.json", "r01_final_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fp:
+                    traffic = {k: v.get("traffic_bytes") for k, v in json.load(fp).items()}
+                traffic_src = f"profiles/{name} (committed PMC passes of the same command; rocprofv3 not runnable here)"
+                break
+            except OSError:
+                pass
+
+    import torch
+    import torch.distributed as dist
+
+    from posterior_matching_amd import ops, optim
+    from posterior_matching_amd.config_dict import load_config_file
+    from posterior_matching_amd.data import SyntheticDataset, data_shape
+    from posterior_matching_amd.engine import PMVAETrainStep
+    from posterior_matching_amd.models import PosteriorMatchingVAE
+
     ndev = torch.cuda.device_count()
     local_rank = local_rank % max(ndev, 1)        # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
@@ -91,23 +177,34 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    cfg, xs, B = pm_vae_mnist(), (28, 28, 1), args.batch
+    cfg = load_config_file(os.path.join(ROOT, "configs", "pm_vae_mnist.py")).to_dict()   # the CLI's own config file
+    xs, B = data_shape(cfg["data"]["dataset"]), args.batch
+
+    def make_opt():
+        return optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg.get("weight_decay", 0.0)),
+                           optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
+
     model = PosteriorMatchingVAE.from_config(cfg["model"], device=dev, seed=1)    # same init on every rank
     model.init(xs)
     model.store.use_bf16 = not args.f32
     model.concurrent = not args.serial
     model.ws.overlap_wgrad = args.wgrad_streams
-    opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg.get("weight_decay", 0.0)),
-                      optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
-    ts = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=world, rank=rank, use_graph=args.graph)
+    opt = make_opt()
+    ts = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=world, rank=rank, use_graph=args.graph,
+                        **({"overlap_allreduce": not args.no_overlap} if world > 1 else {}))
     pool = SyntheticDataset(cfg["data"], B, num_batches=16, seed=100 + rank, device=dev)
     batches = pool.batches
 
-    def run(n, offset=0):
+    def run(step_obj, n, offset=0, marks=None):
         for i in range(n):
             bt = batches[(offset + i) % len(batches)]
-            ts.set_batch(bt["image"], bt["mask"])          # device-to-device copy of the resident batch
-            ts.step()
+            step_obj.set_batch(bt["image"], bt["mask"])          # device-to-device copy of the resident batch
+            step_obj.step()
+            if marks is not None:
+                with torch.cuda.stream(step_obj.stream):
+                    ev = ops.Event()
+                    ev.record()
+                marks.append(ev)
 
     def fence():
         torch.cuda.synchronize()
@@ -115,10 +212,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
+    run(ts, args.warmup)
     fence()
+    marks = []
+    with torch.cuda.stream(ts.stream):
+        e0 = ops.Event()
+        e0.record()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    run(ts, args.steps, args.warmup, marks)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -126,6 +227,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     metrics = ts.read_metrics()
+    # spread of the K timed steps (HIP events on the step's stream, one per step; the headline stays K steps / wall time)
+    per_step = sorted(a.elapsed_ms(b) for a, b in zip([e0] + marks[:-1], marks))
+    spread = {"min": round(per_step[0], 4), "median": round(per_step[len(per_step) // 2], 4),
+              "max": round(per_step[-1], 4)} if per_step else None
+
+    # strict arithmetic (every GEMM on the f32 MFMA) on the same batches: a few steps OUTSIDE the timed region
+    f32_ips = None
+    if rank == 0 and world == 1 and not args.f32 and not args.no_f32_aux:
+        m32 = PosteriorMatchingVAE.from_config(cfg["model"], device=dev, seed=1)
+        m32.init(xs)
+        m32.store.use_bf16 = False
+        m32.concurrent = model.concurrent
+        t32 = PMVAETrainStep(m32, cfg, make_opt(), B, xs, seed=1234, use_graph=False)
+        run(t32, 5)
+        torch.cuda.synchronize()
+        n32, t1 = 20, time.perf_counter()
+        run(t32, n32, 5)
+        torch.cuda.synchronize()
+        f32_ips = round(B * n32 / (time.perf_counter() - t1), 1)
+        del t32, m32
 
     # live per-kernel timing with HIP events on the launching stream (eager, outside the timed region)
     roofline = None
@@ -143,50 +264,53 @@ def main():
         ops.set_timer(None)
         summ = timer.summary()
         total_ms = sum(r["ms"] for r in summ.values())
-        name, r = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        avg_s = r["ms"] / r["calls"] * 1e-3
-        flops_per_launch = r["flops"] / r["calls"]
-        achieved = flops_per_launch / avg_s / 1e12
-        is_bf16 = "bf16" in name
-        peak = BF16_MFMA_PEAK_TFLOPS if is_bf16 else F32_MFMA_PEAK_TFLOPS
-        # HBM-side bytes per launch of this kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, with the
-        # gfx950 2x correction for wide loads) of the same command, committed under profiles/ (counters cannot be read
-        # from inside the process)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")) as fp:
-                traffic = json.load(fp).get(name, {}).get("traffic_bytes")
-        except OSError:
-            pass
-        roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "note": ("achieved = ALGORITHMIC (float32-equivalent) flops / time; this kernel issues 3 bf16 MFMA "
-                             "products per algorithmic MAC (bf16x3 split), so the matrix pipe runs at 3x this rate; "
-                             "against the f32 MFMA peak of 157.3 TFLOP/s the fraction is "
-                             f"{achieved / F32_MFMA_PEAK_TFLOPS:.3f}") if is_bf16 else
-                            "f32 MFMA (v_mfma_f32_32x32x2_f32) runs on the VALU pipeline on gfx950",
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": r["calls"] // args.profile_steps,
-                    "share_of_kernel_time": round(r["ms"] / total_ms, 3),
-                    "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
-                    "algorithmic_bytes_per_launch": round(r["bytes"] / r["calls"]),
-                    "traffic_source": "profiles/r01_final_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch)"}
+
+        def entry(name, r):
+            avg_s = r["ms"] / r["calls"] * 1e-3
+            e = {"kernel": name, "avg_launch_us": round(avg_s * 1e6, 2),
+                 "launches_per_step": r["calls"] // args.profile_steps,
+                 "share_of_kernel_time": round(r["ms"] / total_ms, 3),
+                 "algorithmic_bytes_per_launch": round(r["bytes"] / r["calls"]),
+                 "traffic": (traffic or {}).get(name)}
+            if r["flops"] > 0:          # GEMM class: priced against the matrix-core peak of its arithmetic
+                fl = r["flops"] / r["calls"]
+                peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
+                e.update({"bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                          "frac": round(fl / avg_s / 1e12 / peak, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3)})
+            else:                       # row-wise / optimizer class: operand bytes against HBM
+                gbs = r["bytes"] / r["calls"] / avg_s / 1e9
+                e.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            return e
+
+        ranked = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
+        roofline = entry(*ranked[0])                       # the dominant kernel of the step, by time
+        roofline["note"] = ("achieved = ALGORITHMIC (float32-equivalent) flops of valid (position, tap) MACs / HIP-event "
+                            "time on the launching stream; bf16x3 kernels issue 3 bf16 MFMA products per algorithmic MAC, "
+                            "so their matrix pipe runs at 3x this rate")
+        roofline["traffic_source"] = traffic_src
+        roofline["top3"] = [entry(n, r) for n, r in ranked[:3]]
+        roofline["hbm_class"] = [entry(n, r) for n, r in ranked if r["flops"] == 0 and r["bytes"] >= 4e6][:4]
+        roofline["kernel_time_per_step_ms"] = round(total_ms / args.profile_steps, 4)
+        roofline["total_launches_per_step"] = sum(r["calls"] for r in summ.values()) // args.profile_steps
         if os.environ.get("PM_BENCH_KERNEL_TABLE"):
-            rows = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
             with open(os.environ["PM_BENCH_KERNEL_TABLE"], "w") as fp:
-                for k_, v_ in rows:
+                for k_, v_ in ranked:
                     fp.write(f"{k_:45s} calls/step {v_['calls'] // args.profile_steps:3d}  "
                              f"ms/step {v_['ms'] / args.profile_steps:8.4f}  "
                              f"TFLOP/s {(v_['flops'] / (v_['ms'] * 1e-3) / 1e12) if v_['flops'] else 0:7.2f}  "
-                             f"GB/s {(v_['bytes'] / (v_['ms'] * 1e-3) / 1e9):8.1f}\n")
+                             f"GB/s {(v_['bytes'] / (v_['ms'] * 1e-3) / 1e9):8.1f}  "
+                             f"traffic MB/launch {((traffic or {}).get(k_) or 0) / 1e6:8.2f}\n")
                 fp.write(f"sum of kernel time per step: {total_ms / args.profile_steps:.4f} ms\n\n")
                 calls = timer.per_call()
-                per_step = len(calls) // args.profile_steps
+                per_step_n = len(calls) // args.profile_steps
                 fp.write("launch order of the last profiled step:\n")
-                for tag, detail, ms, fl in calls[-per_step:]:
+                for tag, detail, ms, fl in calls[-per_step_n:]:
                     fp.write(f"{tag:42s} {detail:52s} {ms * 1e3:9.1f} us  {fl / (ms * 1e-3) / 1e12 if fl else 0:6.2f} TFLOP/s\n")
 
     if rank == 0:
         value = world * B * args.steps / dt
+        per_gpu = value / world
         line = {
             "metric": "training images/sec, PM-VAE MNIST bs=256 per GPU (ELBO / PM matching-LL in `aux`)",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -196,12 +320,19 @@ def main():
             "config": {"workload": "configs/pm_vae_mnist.py: conv PM-VAE 28x28x1, latent 32, TriL posterior, "
                                    "AR-GMM partial posterior, Bernoulli decoder; full train step (fwd+loss+bwd+Adam)",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "gemm_arithmetic": ("bf16x3: operands split hi+lo bf16, 3 bf16-MFMA products, f32 accumulate "
-                                           "(fwd/dgrad); f32 MFMA (wgrad)") if model.store.use_bf16 else "f32 MFMA",
-                       "launch": "hip_graph_1stream" if args.graph else "eager_2streams", "params": model.num_params},
+                       "gemm_arithmetic": ("bf16x3 on the bf16 matrix cores for forward, data- and weight-gradient GEMMs: "
+                                           "f32 operands split hi+lo bf16, 3 bf16-MFMA products, f32 accumulate; 1- and "
+                                           "2-channel layers on the VALU in f32") if model.store.use_bf16 else "f32 MFMA",
+                       "launch": "hip_graph_1stream" if args.graph else ("eager_1stream" if args.serial else "launch_plan_2streams"),
+                       "allreduce": (None if world == 1 else ("single" if args.no_overlap else "bucketed_overlapped")),
+                       "params": model.num_params},
             "aux": {"elbo": round(metrics["reconstruction_ll"] - metrics["beta"] * metrics["kl"], 4),
                     "matching_ll": round(metrics["matching_ll"], 4), "kl": round(metrics["kl"], 4),
-                    "loss": round(metrics["loss"], 4)},
+                    "loss": round(metrics["loss"], 4), "step_ms": spread, "f32_images_per_sec": f32_ips,
+                    # whole-step fractions SURVEY.md 8(d) asks for, per GPU
+                    "mfma_frac": round(per_gpu * F_ALG_EXECUTED / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+                    "mfma_frac_as_reference_states_ar_gmm": round(per_gpu * F_ALG_AS_WRITTEN / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+                    "hbm_frac": round(per_gpu * B_ALG_F32 / (HBM_PEAK_GBS * 1e9), 4)},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

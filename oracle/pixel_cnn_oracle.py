@@ -249,6 +249,19 @@ def pixel_cnn_sample(p: Params, prefix: str, cfg: dict, conditional_input: Tenso
     return x.reshape(B, num_samples, H, W).permute(1, 0, 2, 3)
 
 
+def pixel_cnn_sample_unconditional(p: Params, prefix: str, cfg: dict, num_samples: int, gumbel: Tensor) -> Tensor:
+    """PixelCNN._sample_n without conditioning (pixel_cnn.py:82-100): `num_samples` chains from an all-zero grid; position
+    i of every chain is replaced by the draw from the network's distribution at that position (`jnp.where(one_hot(i), samples,
+    x)`).  gumbel [H*W, num_samples, K] makes the categorical draws explicit.  Returns [num_samples, H, W]."""
+    H, W = cfg["image_shape"]
+    x = torch.zeros((num_samples, H, W), dtype=torch.long)
+    for i in range(H * W):
+        logits = pixel_cnn_logits(p, prefix, x, cfg, None)
+        r, c = divmod(i, W)
+        x[:, r, c] = torch.argmax(logits[:, r, c, :] + gumbel[i], dim=-1)
+    return x
+
+
 def vqvae_impute(p: Params, vq_params: Params, vq_state, cfg: dict, vqvae_cfg: dict, x: Tensor, b: Tensor,
                  num_samples: int, gumbel: Tensor) -> Tensor:
     """vqvae_impute (vqvae.py:269-312) -> [B, num_samples, H, W, C] with observed pixels kept, clipped to [0,1]."""

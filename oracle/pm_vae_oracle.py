@@ -303,9 +303,13 @@ def _net(p: Params, kind: str, cfg: dict, prefix: str, x: Tensor, dropout_masks=
     raise KeyError(kind)
 
 
-def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor) -> Dict[str, Tensor]:
+def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor,
+                   dropout_masks: Optional[Dict[str, List[Tensor]]] = None) -> Dict[str, Tensor]:
     """PosteriorMatchingVAE.__call__ (vae.py:120-144) with the config plumbing of from_config
     (vae.py:61-118).  ``eps`` is the explicit N(0,1) draw behind posterior.sample (vae.py:124).
+    ``dropout_masks`` (is_training with a ResidualMLP dropout rate, networks.py:114,125): explicit keep masks per
+    network name ("encoder_net" / "decoder_net" / "partial_encoder_net"), one [B, hidden] tensor per residual block,
+    already scaled by 1 / (1 - rate); None = no dropout (is_training False or rate 0).
 
     Quirk kept: from_config reads ``partial_posterior_dist[_config]`` only, so a
     config that sets ``masked_posterior_dist`` (configs/pm_vae_gas.py:24-27) silently gets the
@@ -321,7 +325,8 @@ def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor
     post_kind = model_cfg["posterior_dist"]
     ppost_kind = model_cfg.get("partial_posterior_dist", post_kind)
     ppost_cfg = dict(model_cfg.get("partial_posterior_dist_config", model_cfg.get("posterior_dist_config", {})) or {})
-    feats = _net(p, enc_kind, enc_cfg, "encoder_net", x)
+    dm = dropout_masks or {}
+    feats = _net(p, enc_kind, enc_cfg, "encoder_net", x, dm.get("encoder_net"))
     if post_kind == "TriLGaussian":
         loc, tril = tril_gaussian_params(p, "posterior_dist", feats, k)
     elif post_kind == "DiagonalGaussian":                                 # distributions.py:58-84: MultivariateNormalDiag
@@ -331,7 +336,7 @@ def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor
         raise KeyError(post_kind)
     z = loc + torch.einsum("bij,bj->bi", tril, eps)                       # vae.py:124
 
-    dec = _net(p, dec_kind, dec_cfg, "decoder_net", z)
+    dec = _net(p, dec_kind, dec_cfg, "decoder_net", z, dm.get("decoder_net"))
     dd = model_cfg["decoder_dist"]
     if dd == "Bernoulli":                                                 # distributions.py:20-25
         rec = bernoulli_log_prob(dec, x)
@@ -345,7 +350,7 @@ def pm_vae_forward(p: Params, model_cfg: dict, x: Tensor, b: Tensor, eps: Tensor
     kl = mvn_tril_kl_to_std_normal(loc, tril)                             # vae.py:130
 
     x_o_b = torch.cat([x * b, b], -1)                                     # vae.py:132-133
-    pfeats = _net(p, penc_kind, penc_cfg, "partial_encoder_net", x_o_b)
+    pfeats = _net(p, penc_kind, penc_cfg, "partial_encoder_net", x_o_b, dm.get("partial_encoder_net"))
 
     zm = z.detach() if model_cfg.get("matching_ll_stop_gradients", False) else z   # vae.py:136-137
     if ppost_kind == "AutoregressiveGMM":
@@ -527,9 +532,9 @@ def beta_value(cfg: dict, step: int) -> float:
     raise KeyError(bcfg["schedule"])
 
 
-def pm_vae_loss(p: Params, cfg: dict, x: Tensor, b: Tensor, eps: Tensor, step: int):
+def pm_vae_loss(p: Params, cfg: dict, x: Tensor, b: Tensor, eps: Tensor, step: int, dropout_masks=None):
     """loss_fn (train_pm_vae.py:58-72): -mean(rec - beta*kl) + matching_coef * (-mean(matching_ll))."""
-    out = pm_vae_forward(p, cfg["model"], x, b, eps)
+    out = pm_vae_forward(p, cfg["model"], x, b, eps, dropout_masks)
     beta = beta_value(cfg, step)
     elbo = (out["reconstruction_ll"] - beta * out["kl"]).mean()
     matching_loss = -out["matching_ll"].mean()
@@ -565,11 +570,12 @@ def adam_update(p: Params, g: Params, m: Params, v: Params, count: int, cfg: dic
         p[name].add_(u, alpha=-lr)
 
 
-def train_step(p: Params, m: Params, v: Params, cfg: dict, x: Tensor, b: Tensor, eps: Tensor, step: int):
+def train_step(p: Params, m: Params, v: Params, cfg: dict, x: Tensor, b: Tensor, eps: Tensor, step: int,
+               dropout_masks=None):
     """One bax.Trainer step as the reference drives it (train_pm_vae.py:85-102): value_and_grad of
     loss_fn, optimizer.update, apply_updates.  Returns (loss, aux, grads)."""
     leaves = {k: t.detach().clone().requires_grad_(True) for k, t in p.items()}
-    loss, aux, _ = pm_vae_loss(leaves, cfg, x, b, eps, step)
+    loss, aux, _ = pm_vae_loss(leaves, cfg, x, b, eps, step, dropout_masks)
     grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
     g = {k: (gr if gr is not None else torch.zeros_like(leaves[k])) for k, gr in zip(leaves, grads)}
     adam_update(p, g, m, v, step, cfg)

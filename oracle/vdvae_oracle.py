@@ -226,7 +226,8 @@ def vdvae_loss(p: Params, cfg: dict, x: Tensor, b: Tensor, eps: Sequence[Tensor]
 
 
 def optimizer_update(p: Params, g: Params, m: Params, v: Params, ema: Optional[Params], count: int, cfg: dict) -> bool:
-    """train_pm_vdvae.py:131-154: clip_by_global_norm -> scale_by_adam -> add_decayed_weights -> constant lr ->
+    """train_pm_vdvae.py:128-154: clip_by_global_norm -> scale_by_adam -> add_decayed_weights -> lr schedule (constant
+    config.lr, or optax.linear_schedule(0, config.lr, warm_up) when config.warm_up > 0: lr * clip(count / warm_up, 0, 1)) ->
     scale(-1); Trainer(skip_nonfinite_updates=True, ema_rate).  Returns False when the step was skipped."""
     gn = math.sqrt(sum(float((t.double() ** 2).sum()) for t in g.values()))
     if not math.isfinite(gn):
@@ -236,6 +237,8 @@ def optimizer_update(p: Params, g: Params, m: Params, v: Params, ema: Optional[P
     adam = cfg.get("adam") or {}
     b1, b2, eps = adam.get("b1", 0.9), adam.get("b2", 0.999), adam.get("eps", 1e-8)
     wd, lr, t = cfg.get("weight_decay", 0.0), cfg["lr"], count + 1
+    if cfg.get("warm_up", 0) > 0:
+        lr = lr * min(max(count / cfg["warm_up"], 0.0), 1.0)
     for name in p:
         gg = g[name] * scale
         m[name].mul_(b1).add_(gg, alpha=1 - b1)

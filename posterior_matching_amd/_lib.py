@@ -54,6 +54,7 @@ class AdamCfg(C.Structure):
         ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
         ("lr_init", C.c_float), ("lr_decay_rate", C.c_float), ("lr_transition_steps", C.c_float),
         ("grad_scale", C.c_float),
+        ("lr_kind", C.c_int), ("lr_end", C.c_float),
     ]
 
 
@@ -144,7 +145,8 @@ SIGNATURES = {
     "pm_gmm_sample_step": [_P, _P, _P, _P, _P, _LL, _I, _I, _I],
     "pm_diag_logprob_acc": [_P, _P, _I, _P, _P, _LL, _I, _I, _F],
     "pm_segment_wsum": [_P, _P, _P, _P, _I, _I, _F, _I],
-    "pm_image_mask_mixture": [_P, _P, _I, _I, _I, C.POINTER(MaskComponent), _I, C.c_ulonglong, _P, _I, _P],
+    "pm_image_mask_mixture": [_P, _P, _I, _I, _I, C.POINTER(MaskComponent), _I, C.c_ulonglong, _P, _I, _P, _P,
+                              C.c_ulonglong],
     "pm_bernoulli_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
     "pm_uniform_mask": [_P, _P, _I, _I, _I, _I, C.c_ulonglong, _P, _I],
     "pm_dropout_mask": [_P, _P, _LL, _F, C.c_ulonglong, _P, _I],
@@ -177,6 +179,10 @@ SIGNATURES = {
     "pm_fill_zero": [_P, _P, _LL],
     "pm_axpy1": [_P, _P, _P, _LL],
     "pm_colsum": [_P, _P, _P, _LL, _I],
+    "pm_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _F],
+    "pm_layernorm_bwd": [_P, _P, _P, _P, _P, _LL, _I],
+    "pm_relu_mask_fwd": [_P, _P, _P, _P, _LL],
+    "pm_relu_mask_bwd": [_P, _P, _P, _P, _P, _LL],
     "pm_graph_begin": [_P],
     "pm_graph_end": [_P, C.POINTER(_P)],
     "pm_graph_launch": [_P, _P],
@@ -191,7 +197,9 @@ SIGNATURES = {
                             C.POINTER(_I)],
     "pm_version": [],
 }
-_OTHER_RESTYPE = {"pm_strerror": ([_I], C.c_char_p), "pm_last_error": ([], C.c_char_p)}
+_OTHER_RESTYPE = {"pm_strerror": ([_I], C.c_char_p), "pm_last_error": ([], C.c_char_p),
+                  "pm_kernel_names_enable": ([_I], None), "pm_last_kernel_name": ([], C.c_char_p),
+                  "pm_clear_kernel_name": ([], None)}
 
 _lib = None
 

@@ -1,9 +1,22 @@
 // Runtime glue of libpmhip: error text, HIP graph capture/replay, HIP events.
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include "pm_common.h"
 
 thread_local char pm_err_text[256] = "";
+bool pm_ktag_on = false;
+static thread_local char pm_ktag_text[160] = "";
+
+void pm_ktagf(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(pm_ktag_text, sizeof(pm_ktag_text), fmt, ap);
+    va_end(ap);
+}
+extern "C" void pm_kernel_names_enable(int on) { pm_ktag_on = on != 0; pm_ktag_text[0] = 0; }
+extern "C" const char* pm_last_kernel_name(void) { return pm_ktag_text; }
+extern "C" void pm_clear_kernel_name(void) { pm_ktag_text[0] = 0; }
 
 int pm_check_launch(const char* what) {
     hipError_t e = hipGetLastError();

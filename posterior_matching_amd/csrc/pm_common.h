@@ -10,6 +10,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern thread_local char pm_err_text[256];
 int pm_check_launch(const char* what);
+// Name of the kernel variant a C-ABI call launched, as rocprofv3 prints it (bench.py groups its live HIP-event times by
+// it, so the live table and the rocprof summary have the same rows).  Off unless pm_kernel_names_enable(1).
+extern bool pm_ktag_on;
+void pm_ktagf(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+#define PM_KTAG(...) do { if (pm_ktag_on) pm_ktagf(__VA_ARGS__); } while (0)
 // Zero-fill by a plain kernel (ptr and nbytes multiples of 4).  hipMemsetAsync is avoided on purpose:
 // captured as a memset node of a HIP graph on ROCm 7.2 it was observed to leave every fourth dword
 // of the range non-zero on replay (tests/test_gpu_vqvae.py::test_vqvae_train_steps_match_oracle).

@@ -825,6 +825,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
 
 template <int RN, int DD>
 void launch_direct(hipStream_t s, const GemmArgs& a, dim3 grid) {
+    PM_KTAG("direct_gemm_kernel<%d, %d, %d>", RN, DD, a.g.in_act == PM_ACT_RELU || a.g.in_act == PM_ACT_LEAKY ? a.g.in_act : 0);
     switch (a.g.in_act) {
         case PM_ACT_RELU: hipLaunchKernelGGL((direct_gemm_kernel<RN, DD, PM_ACT_RELU>), grid, dim3(256), 0, s, a); break;
         case PM_ACT_LEAKY: hipLaunchKernelGGL((direct_gemm_kernel<RN, DD, PM_ACT_LEAKY>), grid, dim3(256), 0, s, a); break;
@@ -1638,6 +1639,8 @@ void launch_direct_bf16(hipStream_t s, const GemmArgs& a, dim3 grid, const __bf1
     // of the input in NHWC order) - no taps, no coordinates, no tap lists: 6 us less per launch on the VDVAE's 1x1 layers
     const bool dense = DD == 1 && g.KH == 1 && g.KW == 1 && g.IH == g.OH && g.IW == g.OW && g.a == 1 && g.off == 0 &&
                        g.offx == 0 && g.PY == 1 && g.PX == 1;
+    PM_KTAG("direct_gemm_bf16_kernel<%d, %d, %d, %s>", RN, dense ? 1 : DD,
+            g.in_act == PM_ACT_RELU || g.in_act == PM_ACT_LEAKY ? g.in_act : 0, dense ? "true" : "false");
 #define PM_LB(ACT)                                                                                                   \
     do {                                                                                                              \
         if (dense) hipLaunchKernelGGL((direct_gemm_bf16_kernel<RN, 1, ACT, true>), grid, dim3(256), 0, s, a, ws, npad, plane); \
@@ -2512,6 +2515,7 @@ int pick_mode(const Geom& g, bool vec4, int kblock) {
 template <int BM, int BN>
 void launch_gemm(hipStream_t s, const GemmArgs& a, int groups, int mode) {
     dim3 grid((a.g.M + BM - 1) / BM, (a.g.N + BN - 1) / BN, groups * a.ksplit);
+    PM_KTAG("gather_gemm_kernel<%d, %d, %d>", BM, BN, mode);
     switch (mode) {
         case MODE_TU1: hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, MODE_TU1>), grid, dim3(256), 0, s, a); break;
         case MODE_TU2: hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, MODE_TU2>), grid, dim3(256), 0, s, a); break;
@@ -2522,6 +2526,7 @@ void launch_gemm(hipStream_t s, const GemmArgs& a, int groups, int mode) {
 
 template <int RC, int RN, int DVEC>
 void launch_wgrad_mode(hipStream_t s, const WgradArgs& a, dim3 grid, int mode) {
+    PM_KTAG("gather_wgrad_kernel<%d, %d, %d, %d>", RC, RN, mode, DVEC);
     switch (mode) {
         case MODE_TU1: hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, MODE_TU1, DVEC>), grid, dim3(256), 0, s, a); break;
         case MODE_TU2: hipLaunchKernelGGL((gather_wgrad_kernel<RC, RN, MODE_TU2, DVEC>), grid, dim3(256), 0, s, a); break;
@@ -2734,6 +2739,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_set = true;
         }
+        PM_KTAG("patch_conv_bf16_kernel<%d>", rn);
         if (rn == 1) hipLaunchKernelGGL(patch_conv_bf16_kernel<1>, pp.grid, dim3(256), pp.lds, s, a, ws, npad, plane, pp.tw_log2);
         else hipLaunchKernelGGL(patch_conv_bf16_kernel<2>, pp.grid, dim3(256), pp.lds, s, a, ws, npad, plane, pp.tw_log2);
         return pm_check_launch("pm_gather_gemm_bf16(patch)");
@@ -2751,6 +2757,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_set = true;
         }
+        PM_KTAG("patch_d2_bf16_kernel<%d>", rn_d2);
         if (rn_d2 == 1) hipLaunchKernelGGL(patch_d2_bf16_kernel<1>, pd.grid, dim3(256), pd.lds, s, a, ws, npad, plane, pd.tw_log2, pd.ni);
         else hipLaunchKernelGGL(patch_d2_bf16_kernel<2>, pd.grid, dim3(256), pd.lds, s, a, ws, npad, plane, pd.tw_log2, pd.ni);
         return pm_check_launch("pm_gather_gemm_bf16(patch_d2)");
@@ -2836,6 +2843,7 @@ extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d,
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_wgrad_bf16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                     attr_set = true;
                 }
+                PM_KTAG("patch_wgrad_bf16_kernel<%d, %d>", rn, taps == 25 ? 7 : 3);
                 if (taps == 25 && rn == 1) hipLaunchKernelGGL((patch_wgrad_bf16_kernel<1, 7>), dim3(grid), dim3(256), lds, s, a, tw_log2, ntiles);
                 else if (taps == 25) hipLaunchKernelGGL((patch_wgrad_bf16_kernel<2, 7>), dim3(grid), dim3(256), lds, s, a, tw_log2, ntiles);
                 else if (rn == 1) hipLaunchKernelGGL((patch_wgrad_bf16_kernel<1, 3>), dim3(grid), dim3(256), lds, s, a, tw_log2, ntiles);
@@ -2863,6 +2871,7 @@ extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d,
         a.step_p = (64 - a.step_b * hw) / a.g.OW;
         a.step_q = 64 - a.step_b * hw - a.step_p * a.g.OW;
         dim3 grid2(a.ntiles * p.splits, 1, d->groups);
+        PM_KTAG("gather_wgrad_bf16_sub_kernel<%d>", dd);
         if (dd == 1) hipLaunchKernelGGL((gather_wgrad_bf16_sub_kernel<1>), grid2, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gather_wgrad_bf16_sub_kernel<2>), grid2, dim3(256), 0, s, a);
         return pm_check_launch("pm_gather_wgrad_bf16(sub)");
@@ -2873,6 +2882,7 @@ extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d,
         if (dd == 1) hipLaunchKernelGGL((gather_wgrad_bf16_kernel<RCv, RNv, 1>), grid, dim3(256), 0, s, a);         \
         else hipLaunchKernelGGL((gather_wgrad_bf16_kernel<RCv, RNv, 2>), grid, dim3(256), 0, s, a);                 \
     } while (0)
+    PM_KTAG("gather_wgrad_bf16_kernel<%d, %d, %d>", p.rc, p.rn, dd);
     if (p.rc == 2 && p.rn == 2) PM_WB(2, 2);
     else if (p.rc == 2) PM_WB(2, 1);
     else if (p.rn == 2) PM_WB(1, 2);

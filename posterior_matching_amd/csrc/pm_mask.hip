@@ -50,9 +50,117 @@ constexpr int RECT_MAX_TRIES = 256;
 //   counter (b, 1 + t, step, stream|TAG)  try t of the random rectangle: x1, x2, y1, y2
 // then every thread fills pixels; pixel-Bernoulli examples draw word (e & 3) of counter (e >> 2, 0, step, stream)
 // with e the element's flat index in [B, H, W].
+// ---- RandomPatternMaskGenerator (masking.py:177-232) without the 10 000 x 10 000 cache ------------------------------
+// The reference upsamples a (resolution * max_size)^2 field of uniform noise bicubically (PIL) to max_size^2, thresholds
+// it at `density` and hands out random windows whose covered fraction lies within density +- density_std.  Here the
+// noise field is a Philox function of (cell, epoch) and only the requested window is interpolated, with Pillow's
+// arithmetic (Resample.c precompute_coeffs + the 32bpc horizontal-then-vertical passes: double-precision sums, float32
+// intermediate), so a window equals the crop of the full resize bit for bit (oracle/masking_oracle.py restates it and is
+// pinned against Pillow itself in tests/test_oracle_kat.py).
+constexpr unsigned PATTERN_TAG = 0x50415454u;   // "PATT": word 2 of the noise counters
+constexpr int PAT_MAX_DIM = 128;                // window height / width supported by the LDS plan
+constexpr int PAT_MAX_LOW = 24;                 // low-resolution rows / columns a window may touch
+constexpr int PATTERN_MAX_TRIES = 256;
+
+#pragma clang fp contract(off)
+__device__ double pat_bicubic(double x) {       // Pillow's bicubic_filter, a = -0.5
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0;
+    if (x < 2.0) return (((x - 5.0) * x + 8.0) * x - 4.0) * a;
+    return 0.0;
+}
+
+// taps of output coordinate `o` of an in_size -> out_size upscale: first input index and 5 normalised weights
+__device__ void pat_taps(int o, int in_size, int out_size, int* lo_out, double* w) {
+    const double scale = (double)in_size / (double)out_size;
+    const double centre = ((double)o + 0.5) * scale;
+    int lo = (int)(centre - 2.0 + 0.5);
+    if (lo < 0) lo = 0;
+    int hi = (int)(centre + 2.0 + 0.5);
+    if (hi > in_size) hi = in_size;
+    const int n = hi - lo;
+    double tot = 0.0;
+    for (int k = 0; k < 5; ++k) {
+        const double v = k < n ? pat_bicubic((double)(k + lo) - centre + 0.5) : 0.0;
+        w[k] = v;
+        tot = tot + v;
+    }
+    if (tot != 0.0)
+        for (int k = 0; k < 5; ++k) w[k] = w[k] / tot;
+    *lo_out = lo;
+}
+
+struct PatternLds {
+    double xw[PAT_MAX_DIM][5], yw[PAT_MAX_DIM][5];
+    int xlo[PAT_MAX_DIM], ylo[PAT_MAX_DIM];
+    float low[PAT_MAX_LOW][PAT_MAX_LOW];
+    float hor[PAT_MAX_LOW][PAT_MAX_DIM];
+    unsigned char bits[PAT_MAX_DIM * PAT_MAX_DIM];
+    int pos[4];        // y0, x0, accepted, count
+    int red[4];
+};
+
+// One try: window (y0, x0) of the pattern of `epoch` -> bits[] (1 = inside a blob) and the blob pixel count.  All threads.
+__device__ int pattern_window(PatternLds& L, const MixArgs& a, const pm_mask_component& m, unsigned epoch, int y0, int x0) {
+    const int H = a.H, W = a.W, LS = m.y1, M = m.size, tid = threadIdx.x;
+    for (int i = tid; i < W + H; i += 256) {
+        if (i < W) pat_taps(x0 + i, LS, M, &L.xlo[i], L.xw[i]);
+        else pat_taps(y0 + i - W, LS, M, &L.ylo[i - W], L.yw[i - W]);
+    }
+    __syncthreads();
+    const int r0 = L.ylo[0], c0 = L.xlo[0];                 // taps are monotone in the output coordinate
+    int r1 = L.ylo[H - 1] + 5, c1 = L.xlo[W - 1] + 5;
+    if (r1 > LS) r1 = LS;
+    if (c1 > LS) c1 = LS;
+    const int nr = r1 - r0, nc = c1 - c0;
+    for (int i = tid; i < nr * nc; i += 256) {
+        const int r = i / nc, c = i - r * nc;
+        const unsigned long long cell = (unsigned long long)(r0 + r) * (unsigned)LS + (unsigned)(c0 + c);
+        unsigned ctr[4] = {(unsigned)cell, epoch, PATTERN_TAG, (unsigned)a.stream_id | DESC_TAG};
+        philox4x32_10(ctr, a.k0, a.k1);
+        L.low[r][c] = (float)(ctr[0] >> 8) * 5.9604644775390625e-08f;
+    }
+    __syncthreads();
+    for (int i = tid; i < nr * W; i += 256) {              // horizontal pass: double sums, float32 result
+        const int r = i / W, x = i - r * W;
+        double ssum = 0.0;
+        for (int k = 0; k < 5; ++k) {
+            int c = L.xlo[x] + k;
+            if (c > LS - 1) c = LS - 1;
+            ssum = ssum + (double)L.low[r][c - c0] * L.xw[x][k];
+        }
+        L.hor[r][x] = (float)ssum;
+    }
+    __syncthreads();
+    int cnt = 0;
+    const float dens = m.p;
+    for (int i = tid; i < H * W; i += 256) {               // vertical pass + threshold
+        const int y = i / W, x = i - y * W;
+        double ssum = 0.0;
+        for (int k = 0; k < 5; ++k) {
+            int r = L.ylo[y] + k;
+            if (r > LS - 1) r = LS - 1;
+            ssum = ssum + (double)L.hor[r - r0][x] * L.yw[y][k];
+        }
+        const unsigned char bit = ((float)ssum < dens) ? 1 : 0;
+        L.bits[i] = bit;
+        cnt += bit;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((tid & 63) == 0) L.red[tid >> 6] = cnt;
+    __syncthreads();
+    const int total = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    __syncthreads();
+    return total;
+}
+#pragma clang fp contract(fast)
+
 __global__ __launch_bounds__(256) void image_mask_mixture_kernel(MixArgs a, const int* __restrict__ step_dev,
-                                                                  float* __restrict__ mask, int* __restrict__ desc_out) {
+                                                                  float* __restrict__ mask, int* __restrict__ desc_out,
+                                                                  unsigned long long* __restrict__ pattern_state) {
     __shared__ int d[6];   // kind, y1, x1, y2, x2 (exclusive ends), component
+    extern __shared__ __attribute__((aligned(16))) unsigned char pat_raw[];   // PatternLds when a PATTERN component exists
     const unsigned step = step_dev ? (unsigned)step_dev[0] : 0u;
     const int b = blockIdx.x;
     if (threadIdx.x == 0) {
@@ -99,6 +207,32 @@ __global__ __launch_bounds__(256) void image_mask_mixture_kernel(MixArgs a, cons
     const int kind = d[0], y1 = d[1], x1 = d[2], y2 = d[3], x2 = d[4];
     const int hw = a.H * a.W;
     float* mb = mask + (size_t)b * hw;
+    if (kind == PM_MASK_PATTERN) {
+        // counter (b, 1 + t, step, stream|TAG): try t -> x0 = word 0, y0 = word 1 (uniform over the valid origins);
+        // accepted when density - std < blob pixels / (H*W) < density + std; after PATTERN_MAX_TRIES the last window stands
+        PatternLds& L = *reinterpret_cast<PatternLds*>(pat_raw);
+        const pm_mask_component& m = a.comp[d[5]];
+        const unsigned epoch = pattern_state ? (unsigned)pattern_state[0] : 0u;
+        const double lo_cnt = ((double)m.p - (double)m.min_prop) * (double)hw, hi_cnt = ((double)m.p + (double)m.min_prop) * (double)hw;
+        int y0 = 0, x0 = 0;
+        for (int t = 0; t < PATTERN_MAX_TRIES; ++t) {
+            unsigned r[4] = {(unsigned)b, (unsigned)(1 + t), step, (unsigned)a.stream_id | DESC_TAG};
+            philox4x32_10(r, a.k0, a.k1);
+            x0 = rand_below(r[0], m.size - a.W + 1);
+            y0 = rand_below(r[1], m.size - a.H + 1);
+            const int cnt = pattern_window(L, a, m, epoch, y0, x0);
+            if ((double)cnt > lo_cnt && (double)cnt < hi_cnt) break;
+        }
+        for (int e = threadIdx.x; e < hw; e += 256) mb[e] = L.bits[e] ? 0.f : 1.f;
+        if (threadIdx.x == 0) {
+            if (pattern_state) atomicAdd(&pattern_state[1], (unsigned long long)hw);
+            if (desc_out) {
+                desc_out[6 * b + 1] = y0;
+                desc_out[6 * b + 2] = x0;
+            }
+        }
+        return;
+    }
     if (kind == PM_MASK_PIXEL_BERNOULLI) {
         const unsigned long long thr = (unsigned long long)((double)a.comp[d[5]].p * 4294967296.0);
         const long long e0 = (long long)b * hw;
@@ -168,12 +302,23 @@ __global__ __launch_bounds__(256) void uniform_mask_kernel(float* __restrict__ m
     }
 }
 
+// masking.py:226-228: the noise is redrawn once update_freq * max_size^2 pixels have been handed out.  The reference checks
+// after every mask; here the check runs once per batch (state[0] = epoch the NEXT launch reads, state[1] = pixels handed out).
+__global__ void pattern_advance_kernel(unsigned long long* state, unsigned long long threshold) {
+    if (state[1] > threshold) {
+        state[0] += 1ull;
+        state[1] = 0ull;
+    }
+}
+
 }  // namespace
 
 extern "C" int pm_image_mask_mixture(pm_stream_t stream, float* mask, int B, int H, int W,
                                      const pm_mask_component* comps, int ncomp, unsigned long long seed,
-                                     const int* step_dev, int stream_id, int* desc_out) {
+                                     const int* step_dev, int stream_id, int* desc_out, unsigned long long* pattern_state,
+                                     unsigned long long pattern_refresh) {
     if (!mask || !comps || B <= 0 || H <= 0 || W <= 0 || ncomp <= 0 || ncomp > PM_MASK_MAX_COMPONENTS) return PM_EINVAL;
+    bool has_pattern = false;
     if ((long long)B * H * W >= (1LL << 40) || stream_id < 0) return PM_EINVAL;
     MixArgs a;
     float prev = 0.f;
@@ -186,13 +331,24 @@ extern "C" int pm_image_mask_mixture(pm_stream_t stream, float* mask, int B, int
             case PM_MASK_FIXED_RECT: break;
             case PM_MASK_SQUARE: if (m.size <= 0 || m.size >= H || m.size >= W) return PM_EINVAL; break;
             case PM_MASK_RECT: if (!(m.min_prop <= m.max_prop) || m.max_prop <= 0.f) return PM_EINVAL; break;
+            case PM_MASK_PATTERN: {   // size = max_size, y1 = low-resolution size, p = density, min_prop = density_std
+                if (m.size < H || m.size < W || m.y1 < 2 || m.y1 > m.size || H > PAT_MAX_DIM || W > PAT_MAX_DIM) return PM_EINVAL;
+                const double scale = (double)m.y1 / (double)m.size;
+                if ((double)(H > W ? H : W) * scale + 7.0 > (double)PAT_MAX_LOW || !pattern_state) return PM_EINVAL;
+                has_pattern = true;
+                break;
+            }
             default: return PM_EINVAL;
         }
         a.comp[i] = m;
     }
     a.ncomp = ncomp; a.B = B; a.H = H; a.W = W;
     a.k0 = (unsigned)seed; a.k1 = (unsigned)(seed >> 32); a.stream_id = stream_id;
-    hipLaunchKernelGGL(image_mask_mixture_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, step_dev, mask, desc_out);
+    const size_t lds = has_pattern ? sizeof(PatternLds) : 0;
+    hipLaunchKernelGGL(image_mask_mixture_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, a, step_dev, mask, desc_out,
+                       pattern_state);
+    if (has_pattern && pattern_refresh > 0)
+        hipLaunchKernelGGL(pattern_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pattern_state, pattern_refresh);
     return pm_check_launch("pm_image_mask_mixture");
 }
 

@@ -163,6 +163,67 @@ __global__ __launch_bounds__(256) void mlp_pair_bf16_kernel(PairArgs p) {
     }
 }
 
+
+// ---- hk.LayerNorm(axis=-1, create_scale=False, create_offset=False) of a ResidualMLP (networks.py:116-131) and the
+// relu -> hk.dropout pair between a block's two linears (:124-125).  One wave per row; wave-shuffle reductions.
+//   y = (x - mean(x)) * rsqrt(var(x) + eps), biased variance (jnp.var), eps 1e-5;  out = y + res (the block's h += res)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             float* __restrict__ y, float* __restrict__ out,
+                                                             float* __restrict__ rstd, long long R, int Hd, float eps) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)r * Hd;
+    float s = 0.f;
+    for (int i = lane; i < Hd; i += 64) s += xr[i];
+    const float mean = pm_wave_sum(s) / (float)Hd;
+    float q = 0.f;
+    for (int i = lane; i < Hd; i += 64) {
+        const float d = xr[i] - mean;
+        q += d * d;
+    }
+    const float rs = rsqrtf(pm_wave_sum(q) / (float)Hd + eps);
+    if (lane == 0) rstd[r] = rs;
+    for (int i = lane; i < Hd; i += 64) {
+        const float v = (xr[i] - mean) * rs;
+        y[(size_t)r * Hd + i] = v;
+        if (out) out[(size_t)r * Hd + i] = v + (res ? res[(size_t)r * Hd + i] : 0.f);
+    }
+}
+
+//   dx = rstd * (dy - mean(dy) - y * mean(dy * y))
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ rstd,
+                                                             const float* __restrict__ dy, float* __restrict__ dx, long long R,
+                                                             int Hd) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float* yr = y + (size_t)r * Hd;
+    const float* gr = dy + (size_t)r * Hd;
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < Hd; i += 64) {
+        a += gr[i];
+        b += gr[i] * yr[i];
+    }
+    a = pm_wave_sum(a) / (float)Hd;
+    b = pm_wave_sum(b) / (float)Hd;
+    const float rs = rstd[r];
+    for (int i = lane; i < Hd; i += 64) dx[(size_t)r * Hd + i] = rs * (gr[i] - a - yr[i] * b);
+}
+
+//   out = relu(x) * mask   (mask = keep / (1 - rate), hk.dropout)   and its gradient dx = dout * mask * [x > 0]
+__global__ __launch_bounds__(256) void relu_mask_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                             float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = fmaxf(x[i], 0.f) * mask[i];
+}
+__global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                             const float* __restrict__ dout, float* __restrict__ dx,
+                                                             long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = x[i] > 0.f ? dout[i] * mask[i] : 0.f;
+}
+
 }  // namespace
 
 extern "C" int pm_mlp_pair_bf16(pm_stream_t stream, const float* x, const void* w1_split, const void* w2_split, const float* b1,
@@ -178,4 +239,34 @@ extern "C" int pm_mlp_pair_bf16(pm_stream_t stream, const float* x, const void* 
     p.in_act = in_act; p.mid_act = mid_act; p.aux_act1 = aux_act1; p.aux_act2 = aux_act2; p.slope = slope;
     hipLaunchKernelGGL(mlp_pair_bf16_kernel, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), 0, (hipStream_t)stream, p);
     return pm_check_launch("pm_mlp_pair_bf16");
+}
+
+extern "C" int pm_layernorm_fwd(pm_stream_t stream, const float* x, const float* res, float* y, float* out, float* rstd,
+                                long long R, int H_, float eps) {
+    if (!x || !y || !rstd || R <= 0 || H_ <= 0 || (res && !out)) return PM_EINVAL;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, res, y, out,
+                       rstd, R, H_, eps);
+    return pm_check_launch("pm_layernorm_fwd");
+}
+
+extern "C" int pm_layernorm_bwd(pm_stream_t stream, const float* y, const float* rstd, const float* dy, float* dx, long long R,
+                                int H_) {
+    if (!y || !rstd || !dy || !dx || R <= 0 || H_ <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, rstd, dy, dx,
+                       R, H_);
+    return pm_check_launch("pm_layernorm_bwd");
+}
+
+extern "C" int pm_relu_mask_fwd(pm_stream_t stream, const float* x, const float* mask, float* out, long long n) {
+    if (!x || !mask || !out || n <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(relu_mask_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, out, n);
+    return pm_check_launch("pm_relu_mask_fwd");
+}
+
+extern "C" int pm_relu_mask_bwd(pm_stream_t stream, const float* x, const float* mask, const float* dout, float* dx,
+                                long long n) {
+    if (!x || !mask || !dout || !dx || n <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, dout,
+                       dx, n);
+    return pm_check_launch("pm_relu_mask_bwd");
 }

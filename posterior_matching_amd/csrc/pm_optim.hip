@@ -69,6 +69,14 @@ __global__ __launch_bounds__(256) void pmvae_loss_kernel(const float* __restrict
     }
 }
 
+__device__ __forceinline__ float pm_lr(const pm_adam_cfg& c, int count) {
+    if (c.lr_kind == 1) {   // optax.linear_schedule: polynomial_schedule(power = 1)
+        const float f = fminf(fmaxf((float)count / c.lr_transition_steps, 0.f), 1.f);
+        return (c.lr_init - c.lr_end) * (1.f - f) + c.lr_end;
+    }
+    return c.lr_init * powf(c.lr_decay_rate, (float)count / c.lr_transition_steps);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, long long n,
                                                      long long n_decay, const int* __restrict__ count_dev,
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float t = (float)(count + 1);
     const float bc1 = 1.f - powf(c.b1, t);
     const float bc2 = 1.f - powf(c.b2, t);
-    const float lr = c.lr_init * powf(c.lr_decay_rate, (float)count / c.lr_transition_steps);
+    const float lr = pm_lr(c, count);
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * c.grad_scale;
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void adam_clip_ema_kernel(float* __restrict__ 
     const float t = (float)(count + 1);
     const float bc1 = 1.f - powf(c.b1, t);
     const float bc2 = 1.f - powf(c.b2, t);
-    const float lr = c.lr_init * powf(c.lr_decay_rate, (float)count / c.lr_transition_steps);
+    const float lr = pm_lr(c, count);
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * c.grad_scale * cs;

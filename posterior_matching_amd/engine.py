@@ -49,6 +49,18 @@ class _PlannedStep:
         self._plan, self._warm = None, False
 
 
+def _make_reducer(store, world_size: int, overlap: bool):
+    """data-parallel gradient reduction (parallel.GradReducer): buckets of a quarter of the buffer, 1-16 MB"""
+    if world_size <= 1:
+        store.reducer = None
+        return None
+    from .parallel import GradReducer
+
+    total = store.flat_g.numel() * 4
+    store.reducer = GradReducer(store, bucket_bytes=max(1 << 20, min(16 << 20, total // 4)), overlap=overlap)
+    return store.reducer
+
+
 def loss_cfg_from_config(config: Mapping[str, Any], batch_size: int) -> LossCfg:
     """get_beta_schedule + the loss weights of loss_fn (train_pm_vae.py:28-43,62-70)."""
     c = LossCfg()
@@ -75,7 +87,7 @@ class PMVAETrainStep(_PlannedStep):
 
     def __init__(self, model: PosteriorMatchingVAE, config: Mapping[str, Any], optimizer: Chain, batch_size: int,
                  x_shape, seed: int = 0, world_size: int = 1, rank: int = 0, use_graph: bool = False,
-                 external_eps: bool = False, use_plan: bool = True):
+                 external_eps: bool = False, use_plan: bool = True, overlap_allreduce: bool = True):
         """use_graph=False (default): eager launches, the ELBO and posterior-matching chains overlap on
         two HIP streams.  use_graph=True: one HIP graph replay per step; ROCm 7.2 serialises the
         branches of a captured graph, so this form runs the two chains back to back (measured:
@@ -87,6 +99,7 @@ class PMVAETrainStep(_PlannedStep):
         self.world_size, self.rank, self.seed = world_size, rank, seed
         self.loss_cfg = loss_cfg_from_config(config, batch_size)
         self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.reducer = _make_reducer(model.store, world_size, overlap_allreduce)
         x_shape = tuple(x_shape)
         b_shape = x_shape[:-1] + (1,) if len(x_shape) == 3 else x_shape
         self.x = torch.zeros((batch_size,) + x_shape, device=dev)
@@ -100,6 +113,14 @@ class PMVAETrainStep(_PlannedStep):
         self.external_eps = external_eps
         self.use_graph = use_graph
         self.use_plan = use_plan and not use_graph
+        # hk.dropout(hk.next_rng_key(), ...) inside ResidualMLP (networks.py:125): device Philox keyed by (seed, rank),
+        # the training step counter and one stream id per (network, block)
+        from .models.networks import ResidualMLP
+
+        for i, net in enumerate((model.encoder_net, model.decoder_net, model.partial_encoder_net)):
+            if isinstance(net, ResidualMLP):
+                net.dropout_seed, net.dropout_step_dev = seed + 7919 * rank, self.step_dev
+                net.dropout_stream_base = 2000 + 64 * i
         if use_graph:
             model.concurrent = False
         # HIP graph capture is not allowed on the NULL stream: the step owns a side stream
@@ -126,9 +147,7 @@ class PMVAETrainStep(_PlannedStep):
         ops.counter_increment(self.step_dev)
 
     def _allreduce(self) -> None:
-        from .parallel import allreduce_sum_
-
-        ops.host_call(allreduce_sum_, self.model.store.flat_g)           # sum over ranks; Adam divides by world_size
+        self.reducer.finish()           # buckets issued during the backward pass + the rest; Adam divides by world_size
 
     def _eager_sequence(self) -> None:
         self._forward_backward()
@@ -205,13 +224,14 @@ class VQVAETrainStep(_PlannedStep):
     haiku) -> loss -> backward -> [gradient all-reduce] -> Adam -> step += 1."""
 
     def __init__(self, model, optimizer: Chain, batch_size: int, x_shape, world_size: int = 1, rank: int = 0,
-                 use_graph: bool = False, use_plan: bool = True):
+                 use_graph: bool = False, use_plan: bool = True, overlap_allreduce: bool = True):
         if model.store is None:
             model.init(x_shape)
         dev = model.store.device
         self.model, self.opt, self.B = model, optimizer, batch_size
         self.world_size, self.rank = world_size, rank
         self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.reducer = _make_reducer(model.store, world_size, overlap_allreduce)
         self.x = torch.zeros((batch_size,) + tuple(x_shape), device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.use_graph = use_graph and world_size == 1
@@ -226,9 +246,7 @@ class VQVAETrainStep(_PlannedStep):
         m.zero_grad()
         m.backward()
         if self.world_size > 1:
-            from .parallel import allreduce_sum_
-
-            ops.host_call(allreduce_sum_, s.flat_g)
+            self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
         s.split_all()
         ops.counter_increment(self.step_dev)
@@ -274,7 +292,7 @@ class PMVQVAETrainStep(_PlannedStep):
     not under "vqvae/"), Adam with the exponential-decay schedule, step += 1."""
 
     def __init__(self, vqvae, partial_encoder, pixel_cnn, optimizer: Chain, batch_size: int, x_shape, seed: int = 0,
-                 world_size: int = 1, rank: int = 0, external_dropout: bool = False):
+                 world_size: int = 1, rank: int = 0, external_dropout: bool = False, overlap_allreduce: bool = True):
         from .models.core import ParamStore, Workspace
 
         if vqvae.store is None:
@@ -291,6 +309,7 @@ class PMVQVAETrainStep(_PlannedStep):
             store.allocate(dev, seed)
         self.store, self.ws = pixel_cnn.store, pixel_cnn.ws
         self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.reducer = _make_reducer(self.store, world_size, overlap_allreduce)
         x_shape = tuple(x_shape)
         self.x = torch.zeros((batch_size,) + x_shape, device=dev)
         self.b = torch.zeros((batch_size,) + x_shape[:-1] + (1,), device=dev)
@@ -328,9 +347,7 @@ class PMVQVAETrainStep(_PlannedStep):
         self.penc.backward(dcond)
         self.ws.join_aux()
         if self.world_size > 1:
-            from .parallel import allreduce_sum_
-
-            ops.host_call(allreduce_sum_, s.flat_g)
+            self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
         s.split_all()
         ops.counter_increment(self.step_dev)
@@ -364,9 +381,10 @@ class VDVAETrainStep(_PlannedStep):
     loss = -mean(rec_ll - kl) + mean(pm_kl) -> backward -> [gradient all-reduce] -> global-norm clip +
     Adam (+ parameter EMA, non-finite steps skipped) -> step += 1."""
 
-    def __init__(self, model, lr: float, batch_size: int, gradient_clip: float = 200.0, ema_rate: Optional[float] = 0.999,
+    def __init__(self, model, lr, batch_size: int, gradient_clip: float = 200.0, ema_rate: Optional[float] = 0.999,
                  weight_decay: float = 0.0, adam: Optional[Mapping[str, float]] = None, seed: int = 0, world_size: int = 1,
-                 rank: int = 0, external_eps: bool = False, skip_nonfinite_updates: bool = True):
+                 rank: int = 0, external_eps: bool = False, skip_nonfinite_updates: bool = True,
+                 overlap_allreduce: bool = True):
         from ._lib import AdamCfg
 
         if model.store is None:
@@ -377,9 +395,17 @@ class VDVAETrainStep(_PlannedStep):
         adam = dict(adam or {})
         c = AdamCfg()
         c.b1, c.b2, c.eps = adam.get("b1", 0.9), adam.get("b2", 0.999), adam.get("eps", 1e-8)
-        c.weight_decay, c.lr_init, c.lr_decay_rate, c.lr_transition_steps = weight_decay, lr, 1.0, 1.0
+        from .optim import LinearSchedule
+
+        if isinstance(lr, LinearSchedule):       # warm-up: optax.linear_schedule(0, config.lr, warm_up) (train_pm_vdvae.py:128-130)
+            c.weight_decay, c.lr_kind, c.lr_init, c.lr_end = weight_decay, 1, lr.init_value, lr.end_value
+            c.lr_decay_rate, c.lr_transition_steps = 1.0, lr.transition_steps
+        else:
+            c.weight_decay, c.lr_init, c.lr_decay_rate, c.lr_transition_steps = weight_decay, float(lr), 1.0, 1.0
+            c.lr_kind, c.lr_end = 0, 0.0
         c.grad_scale = 1.0 / world_size
         self.adam_cfg, self.clip, self.skip = c, float(gradient_clip or 0.0), skip_nonfinite_updates
+        self.reducer = _make_reducer(s, world_size, overlap_allreduce)
         self.ema_rate = ema_rate
         self.ema = s.flat_p.clone() if ema_rate is not None else None       # bax: ema_params start at the parameters
         H, W_, C = model.config["image_shape"]
@@ -410,9 +436,7 @@ class VDVAETrainStep(_PlannedStep):
         m.zero_grad()
         m.backward()
         if self.world_size > 1:
-            from .parallel import allreduce_sum_
-
-            ops.host_call(allreduce_sum_, s.flat_g)
+            self.reducer.finish()       # the clip / non-finite decision below sees the REDUCED gradient on every rank
         ops.sumsq(s.flat_g, self.gnorm_sq)
         ops.adam_step_clip_ema(s.flat_p, s.flat_g, s.flat_m, s.flat_v, self.ema, s.n_decay, self.opt_count, self.gnorm_sq,
                                self.adam_cfg, self.clip, self.ema_rate if self.ema_rate is not None else 0.0, self.skip)

@@ -366,19 +366,45 @@ class DeviceUniformMaskGenerator(DeviceMaskGenerator):
         ops.uniform_mask(out, lo, span, self.seed, self._step, self.stream_id)
 
 
-class DeviceImageMixtureMaskGenerator(DeviceMaskGenerator):
-    """MNIST / Omniglot / CIFAR-10 mixtures (weights [2,1,1,1,1,2,2]) in one launch per batch."""
+def _half_plane_spec(d, p, lo, hi):
+    """(kind, weight, fields) of the MNIST / Omniglot / CIFAR-10 mixtures (reference masking.py:235-286)"""
+    h = d // 2
+    return [(0, 2, dict(p=p)), (1, 1, dict(y1=0, x1=0, y2=d, x2=h)), (1, 1, dict(y1=0, x1=0, y2=h, x2=d)),
+            (1, 1, dict(y1=0, x1=h, y2=d, x2=d)), (1, 1, dict(y1=h, x1=0, y2=d, x2=d)),
+            (2, 2, dict(size=h)), (3, 2, dict(min_prop=lo, max_prop=hi))]
 
-    def __init__(self, name: str = "MNISTMaskGenerator", dim: Optional[int] = None, **kw):
+
+def _celeba_spec(max_size=10000, resolution=0.06, density=0.25, density_std=0.05):
+    """CelebAMaskGenerator (masking.py:317-325) flattened: the nested mixtures SIIDGM (weight 1: random pattern,
+    pixel-Bernoulli(0.2), five fixed rectangles, weights [2,2,2,1,1,1,1]), GCF (weight 1: six fixed rectangles) and the
+    random rectangle (weight 2) become ONE 14-component mixture with the product weights."""
+    spec = [(4, 0.25 * 2 / 10, dict(size=max_size, y1=int(resolution * max_size), p=density, min_prop=density_std)),
+            (0, 0.25 * 2 / 10, dict(p=0.2))]
+    spec += [(1, 0.25 * (2 if i == 0 else 1) / 10, dict(y1=r[0], x1=r[1], y2=r[2], x2=r[3])) for i, r in enumerate(_SIIDGM_RECTS)]
+    spec += [(1, 0.25 / 6, dict(y1=r[0], x1=r[1], y2=r[2], x2=r[3])) for r in _GCF_RECTS]
+    spec += [(3, 0.5, dict(min_prop=0.3, max_prop=1.0))]
+    return spec
+
+
+class DeviceImageMixtureMaskGenerator(DeviceMaskGenerator):
+    """MNIST / Omniglot / CIFAR-10 (weights [2,1,1,1,1,2,2]) and CelebA (14 flattened components, one of them the random
+    blob pattern) mixtures in one launch per batch."""
+
+    def __init__(self, name: str = "MNISTMaskGenerator", dim: Optional[int] = None, max_size: int = 10000,
+                 resolution: float = 0.06, update_freq: float = 1, **kw):
         super().__init__(**kw)
+        import torch
+
         from ._lib import MaskComponent
 
-        d0, p, lo, hi = _IMAGE_MIXTURES[name]
-        d = dim if (dim is not None and name == "MNISTMaskGenerator") else d0
-        h = d // 2
-        spec = [(0, 2, dict(p=p)), (1, 1, dict(y1=0, x1=0, y2=d, x2=h)), (1, 1, dict(y1=0, x1=0, y2=h, x2=d)),
-                (1, 1, dict(y1=0, x1=h, y2=d, x2=d)), (1, 1, dict(y1=h, x1=0, y2=d, x2=d)),
-                (2, 2, dict(size=h)), (3, 2, dict(min_prop=lo, max_prop=hi))]
+        self.pattern_state, self.pattern_refresh = None, 0
+        if name == "CelebAMaskGenerator":
+            spec = _celeba_spec(max_size, resolution)
+            self.pattern_state = torch.zeros(2, dtype=torch.int64, device=self.device)     # noise epoch, pixels handed out
+            self.pattern_refresh = int(update_freq * max_size ** 2)                       # masking.py:226-228
+        else:
+            d0, p, lo, hi = _IMAGE_MIXTURES[name]
+            spec = _half_plane_spec(dim if (dim is not None and name == "MNISTMaskGenerator") else d0, p, lo, hi)
         w = np.array([x[1] for x in spec], np.float64)
         cum = np.cumsum(w / w.sum()).astype(np.float32)
         self.comps = (MaskComponent * len(spec))()
@@ -393,7 +419,8 @@ class DeviceImageMixtureMaskGenerator(DeviceMaskGenerator):
 
         if out.dim() != 4 or out.shape[-1] != 1:
             raise AssertionError(f"expected shape of size [batch_dim, height, width, 1], got {tuple(out.shape)}")
-        ops.image_mask_mixture(out, self.comps, self.seed, self._step, self.stream_id, desc_out)
+        ops.image_mask_mixture(out, self.comps, self.seed, self._step, self.stream_id, desc_out, self.pattern_state,
+                               self.pattern_refresh)
 
 
 _GENERATORS = {"BernoulliMaskGenerator": BernoulliMaskGenerator, "UniformMaskGenerator": UniformMaskGenerator,
@@ -403,13 +430,13 @@ _GENERATORS = {"BernoulliMaskGenerator": BernoulliMaskGenerator, "UniformMaskGen
 
 def get_mask_generator(mask_generator_name: str, device=None, **kwargs):
     """reference masking.py:328-335 (KeyError for unknown names).  With `device` (a cuda device) the generator draws
-    on the GPU; CelebAMaskGenerator (random bicubic pattern, masking.py:177-232) has no device form yet."""
+    on the GPU (CelebAMaskGenerator included: its random bicubic pattern, masking.py:177-232, is interpolated per window)."""
     if device is None:
         return _GENERATORS[mask_generator_name](**kwargs)
     if mask_generator_name == "BernoulliMaskGenerator":
         return DeviceBernoulliMaskGenerator(device=device, **kwargs)
     if mask_generator_name == "UniformMaskGenerator":
         return DeviceUniformMaskGenerator(device=device, **kwargs)
-    if mask_generator_name in _IMAGE_MIXTURES:
+    if mask_generator_name in _IMAGE_MIXTURES or mask_generator_name == "CelebAMaskGenerator":
         return DeviceImageMixtureMaskGenerator(mask_generator_name, device=device, **kwargs)
     raise KeyError(mask_generator_name)

@@ -48,6 +48,14 @@ class ParamStore:
         self._split_requests = []      # (param name, LayerGeom, mode, groups, group kw)
         self._split_views = []
         self.use_bf16 = True           # bf16x3 matrix-core path for layers that qualify
+        self.reducer = None            # parallel.GradReducer when the step runs data-parallel (set by the train step)
+
+    def grads_ready(self, prefixes, streams=None) -> None:
+        """A model's backward reports that every parameter under `prefixes` has its final gradient (once the work
+        enqueued so far on `streams` / the current stream has run): the data-parallel reducer may all-reduce that
+        range while the rest of the backward pass runs.  No-op on one GPU."""
+        if self.reducer is not None:
+            self.reducer.ready(prefixes, streams)
 
     def add(self, name: str, shape, fan_in: int = 0) -> None:
         """fan_in > 0: haiku TruncatedNormal(stddev = 1/sqrt(fan_in)); 0: zeros; -1: TruncatedNormal(stddev 1)

@@ -144,15 +144,16 @@ class ResidualMLP(Module):
         super().__init__(name)
         if activation not in ("relu", None) and getattr(activation, "__name__", "") != "relu":
             raise NotImplementedError("ResidualMLP: only the reference default activation (relu) has a HIP path")
-        if layer_norm:
-            raise NotImplementedError("ResidualMLP(layer_norm=True) has no HIP path yet (not used by pm_vae_gas / pm_vae_mnist)")
-        if dropout:
-            raise NotImplementedError("ResidualMLP(dropout>0) has no HIP path yet (not used by pm_vae_gas / pm_vae_mnist)")
         if w_init is not None:
             raise NotImplementedError("custom w_init")
         self._residual_blocks = residual_blocks
         self._hidden_units = hidden_units
         self._activate_final = activate_final
+        self._layer_norm, self._dropout = bool(layer_norm), float(dropout or 0.0)
+        # parity mode: explicit keep masks (one [rows, hidden] tensor per block, already scaled by 1 / (1 - rate)) replace
+        # the device Philox draws of hk.dropout(hk.next_rng_key(), ...)
+        self.dropout_masks = None
+        self.dropout_seed, self.dropout_step_dev, self.dropout_stream_base = 0, None, 0
 
     def build(self, store: ParamStore, prefix: str, in_shape) -> Tuple[int, ...]:
         if len(in_shape) != 1:
@@ -213,7 +214,108 @@ class ResidualMLP(Module):
             return self.buf("dh_out", (rows, hu))
         return self.buf("dys_all", (2 * nb, rows, hu))[2 * nb - 1]
 
+    def _plain(self, is_training: bool) -> bool:
+        """the relu / no-LayerNorm / no-dropout form (pm_vae_gas, the AR-GMM networks): fused kernels below"""
+        return not self._layer_norm and not (self._dropout > 0.0 and is_training)
+
+    def _call_general(self, x: Feat, is_training: bool) -> Feat:
+        """networks.py:111-135 with LayerNorm after every Linear and / or dropout between a block's two Linears
+        (configs/pm_vae_miniboone.py:32-39, pm_vae_bsds.py:32-37): the Linears are the GEMM engine's, LayerNorm and
+        relu -> dropout are row-wise kernels (csrc/pm_mlp.hip).  Stored per block for the backward pass: h (block input,
+        pre-activation), n1 = LN(t1), d = relu(n1) * mask, n2 = LN(t2), the two rstd vectors."""
+        rows, hu, nb, ln = x.t.shape[0], self._hidden_units, self._residual_blocks, self._layer_norm
+        rate = self._dropout if is_training else 0.0
+        self._x, self._general = x, True
+        st = self._st = []
+        t0 = self.buf("g/t0", (rows, hu))
+        ops.layer_forward(self.g_in, x.t, self.P("linear_0/w"), self.P("linear_0/b"), t0, in_act=x.in_act,
+                          wsplit=self._wsf("linear_0"))
+        if ln:
+            h, self._rstd0 = self.buf("g/h0", (rows, hu)), self.buf("g/rstd0", (rows,))
+            ops.layernorm_fwd(t0, None, h, None, self._rstd0)
+        else:
+            h = t0
+        self._h = [h]
+        for k in range(nb):
+            t1 = self.buf(f"g/t1_{k}", (rows, hu))
+            ops.layer_forward(self.g_hid, h, self.P(f"block_{k}/linear_0/w"), self.P(f"block_{k}/linear_0/b"), t1,
+                              in_act=ACT_RELU, wsplit=self._wsf(f"block_{k}/linear_0"))
+            n1, rstd1 = t1, None
+            if ln:
+                n1, rstd1 = self.buf(f"g/n1_{k}", (rows, hu)), self.buf(f"g/rstd1_{k}", (rows,))
+                ops.layernorm_fwd(t1, None, n1, None, rstd1)
+            mask, d = None, None
+            if rate > 0.0:
+                if self.dropout_masks is not None:
+                    mask = self.dropout_masks[k]
+                else:
+                    mask = self.buf(f"g/mask_{k}", (rows, hu))
+                    ops.dropout_mask(mask, rate, self.dropout_seed, self.dropout_step_dev, stream_id=self.dropout_stream_base + k)
+                d = self.buf(f"g/d_{k}", (rows, hu))
+                ops.relu_mask_fwd(n1, mask, d)
+            hn = self.buf(f"g/h_{k + 1}", (rows, hu))
+            n2, rstd2 = None, None
+            lin1_in, lin1_act = (d, ACT_NONE) if d is not None else (n1, ACT_RELU)
+            if ln:
+                t2 = self.buf(f"g/t2_{k}", (rows, hu))
+                ops.layer_forward(self.g_hid, lin1_in, self.P(f"block_{k}/linear_1/w"), self.P(f"block_{k}/linear_1/b"), t2,
+                                  in_act=lin1_act, wsplit=self._wsf(f"block_{k}/linear_1"))
+                n2, rstd2 = self.buf(f"g/n2_{k}", (rows, hu)), self.buf(f"g/rstd2_{k}", (rows,))
+                ops.layernorm_fwd(t2, h, n2, hn, rstd2)                       # h += LN(t2)
+            else:
+                ops.layer_forward(self.g_hid, lin1_in, self.P(f"block_{k}/linear_1/w"), self.P(f"block_{k}/linear_1/b"), hn,
+                                  in_act=lin1_act, res=h, wsplit=self._wsf(f"block_{k}/linear_1"))
+            st.append((n1, rstd1, mask, d, n2, rstd2))
+            self._h.append(hn)
+            h = hn
+        if self._activate_final:
+            return Feat(h, ACT_RELU, ACT_RELU)
+        return Feat(h, ACT_NONE, ACT_NONE)
+
+    def _backward_general(self, dh: torch.Tensor, need_input_grad: bool) -> Optional[torch.Tensor]:
+        rows, hu, nb, ln = dh.shape[0], self._hidden_units, self._residual_blocks, self._layer_norm
+        for k in reversed(range(nb)):
+            n1, rstd1, mask, d, n2, rstd2 = self._st[k]
+            h = self._h[k]
+            dt2 = dh
+            if ln:
+                dt2 = self.buf(f"g/dt2_{k}", (rows, hu))
+                ops.layernorm_bwd(n2, rstd2, dh, dt2)
+            lin1_in, lin1_act = (d, ACT_NONE) if d is not None else (n1, ACT_RELU)
+            self.wgrad(self.g_hid, lin1_in, dt2, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"), in_act=lin1_act)
+            dn1 = self.buf(f"g/dn1_{k}", (rows, hu))
+            if d is not None:
+                dd = self.buf(f"g/dd_{k}", (rows, hu))
+                ops.layer_dgrad(self.g_hid, dt2, self.P(f"block_{k}/linear_1/w"), dd, wsplit=self._wsd(f"block_{k}/linear_1"))
+                ops.relu_mask_bwd(n1, mask, dd, dn1)
+            else:
+                ops.layer_dgrad(self.g_hid, dt2, self.P(f"block_{k}/linear_1/w"), dn1, aux=n1, aux_act=ACT_RELU,
+                                wsplit=self._wsd(f"block_{k}/linear_1"))
+            dt1 = dn1
+            if ln:
+                dt1 = self.buf(f"g/dt1_{k}", (rows, hu))
+                ops.layernorm_bwd(n1, rstd1, dn1, dt1)
+            self.wgrad(self.g_hid, h, dt1, self.G(f"block_{k}/linear_0/w"), self.G(f"block_{k}/linear_0/b"), in_act=ACT_RELU)
+            dprev = self.buf(f"g/dh_{k}", (rows, hu))
+            ops.layer_dgrad(self.g_hid, dt1, self.P(f"block_{k}/linear_0/w"), dprev, aux=h, aux_act=ACT_RELU, res=dh,
+                            wsplit=self._wsd(f"block_{k}/linear_0"))
+            dh = dprev
+        if ln:
+            dt0 = self.buf("g/dt0", (rows, hu))
+            ops.layernorm_bwd(self._h[0], self._rstd0, dh, dt0)
+            dh = dt0
+        self.wgrad(self.g_in, self._x.t, dh, self.G("linear_0/w"), self.G("linear_0/b"), in_act=self._x.in_act)
+        if need_input_grad:
+            dx = self.buf("dx", (rows, self.g_in.CI))
+            ops.layer_dgrad(self.g_in, dh, self.P("linear_0/w"), dx, aux=self._x.t, aux_act=self._x.grad_act,
+                            wsplit=self._wsd("linear_0"))
+            return dx
+        return None
+
     def __call__(self, x: Feat, is_training: bool = False) -> Feat:
+        if not self._plain(is_training):
+            return self._call_general(x, is_training)
+        self._general = False
         rows, hu, nb = x.t.shape[0], self._hidden_units, self._residual_blocks
         self._x = x
         xs = self.buf("xs_all", (2 * nb + 1, rows, hu))
@@ -247,6 +349,8 @@ class ResidualMLP(Module):
 
     def backward(self, dh: torch.Tensor, need_input_grad: bool = False) -> Optional[torch.Tensor]:
         """dh: gradient w.r.t. the stored pre-activation h of the last block."""
+        if getattr(self, "_general", False):
+            return self._backward_general(dh.reshape(dh.shape[0], self._hidden_units), need_input_grad)
         rows, hu, nb = dh.shape[0], self._hidden_units, self._residual_blocks
         grouped = self._grouped()
         if nb > 0:

@@ -232,14 +232,25 @@ class PixelCNN(Module):
         network evaluation per position.  Returns int32 [*sample_shape, B, H, W].  The categorical draw is
         the Gumbel-max trick (what jax.random.categorical does) with device Philox noise, or the explicit
         `gumbel` [H*W, B*n, K] (row b*n + s = sample s of conditioning vector b) in parity mode."""
-        if conditional_input is None:
-            raise NotImplementedError("unconditional PixelCNN sampling is not used by the reference's scripts")
         H, W = self._event_shape
         K, P = self._num_indices, H * W
         shape = (sample_shape,) if isinstance(sample_shape, int) else tuple(sample_shape)
         n = 1
         for v in shape:
             n *= int(v)
+        if conditional_input is None:
+            # the unconditional branch (:82-100): n chains from an all-zero grid; gumbel (parity mode): [H*W, n, K]
+            if self._cond_dim is not None:
+                raise ValueError("this network was built with a conditional_dim: conditional_input is required")
+            dev = self.store.device
+            x = torch.zeros((n, H, W), dtype=torch.int32, device=dev)
+            noise = self.buf("gumbel_uncond", (n, K)) if gumbel is None else None
+            for i in range(P):
+                logits = self.logits(x, False, None)
+                if gumbel is None:
+                    ops.gumbel_fill(noise, seed, None, stream_id=i)
+                ops.categorical_sample(logits.view(n * P, K), noise if gumbel is None else gumbel[i], x.view(-1), P, i)
+            return x.view(*shape, H, W) if shape else x[0]
         B = conditional_input.shape[0]
         cond = conditional_input.reshape(B, -1).repeat_interleave(n, dim=0).contiguous()   # jnp.tile per vmap lane
         x = torch.zeros((B * n, H, W), dtype=torch.int32, device=cond.device)
@@ -265,6 +276,8 @@ class PixelCNN(Module):
         dlogits = self.buf("dlogits", sh(K))
         ops.categorical_ll_bwd(self._logits.view(R, K), self._value.reshape(-1), self._lse, g_ll, dlogits.view(R, K), P)
         self._wg(self.out_conv, self.buf("x_out", sh(F)), dlogits)
+        self.ws.join_aux()
+        self.store.grads_ready([f"{self.prefix}/out_conv"])
         dx_out = self.buf("dx_out", sh(F))
         self._dg(self.out_conv, dlogits, dx_out)
 
@@ -319,6 +332,9 @@ class PixelCNN(Module):
             dce1 = self.buf(f"{n}/dce1", sh(2 * F))
             self._dg(blk.conv1, dx1, dce1)
             ops.concat_elu_bwd(input_x, None, None, dce1, d_in, None, accumulate=True)
+            if self.store.reducer is not None:          # data-parallel: this block's weight gradients are final
+                self.ws.join_aux()
+                self.store.grads_ready([f"{self.prefix}/{n}/{leaf}" for leaf in ("conv1", "linear", "conv2")])
 
         dv0, dh0 = gbuf(self._v0, "v_init"), gbuf(self._h0, "h_init")
         emb = self._emb

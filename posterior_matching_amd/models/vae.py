@@ -236,6 +236,7 @@ class PosteriorMatchingVAE(Module):
             ops.record_event(dz_ready, side)
             self.partial_encoder_net.backward(dpenc, need_input_grad=False)
             self.ws.join_aux()
+            self.store.grads_ready(["partial_encoder_net", "partial_posterior_dist"])     # data-parallel: bucket is complete
         # ELBO branch on the main stream.  It is the longer chain; its weight gradients only feed the optimizer, so
         # (lend_wgrad) they are queued on the side stream behind the posterior-matching branch instead of sitting
         # between the data-gradient kernels of the critical path.
@@ -246,6 +247,9 @@ class PosteriorMatchingVAE(Module):
         dz = self.decoder_net.backward(dpre, need_input_grad=True)
         if lend == "dec":
             self.ws.wgrad_stream = None
+        if not lend:
+            self.ws.join_aux()
+            self.store.grads_ready(["decoder_net", "decoder_dist"])
         if want_dz:
             ops.wait_event(main, dz_ready)
             ops.axpy1(dz_pm, dz)

@@ -657,6 +657,9 @@ class PosteriorMatchingVDVAE(Module):
         dparams = self.ws.get("decoder/d_dmol_params", tuple(self._params.shape))
         ops.dmol_ll_bwd(self._params, self._x, -g, dparams, nm, H * W_)
         self.wgrad(self.out_net.g, self._px_z, dparams, self.store.g[self.out_net.w], self.store.g[self.out_net.b])
+        if self.store.reducer is not None:
+            self.ws.join_all_aux()
+            self.store.grads_ready(["decoder/out_net"])
         dpx = self.ws.get("decoder/d_px_z", tuple(self._px_z.shape))
         ops.layer_dgrad(self.out_net.g, dparams, self.store.p[self.out_net.w], dpx, wsplit=self.store.split_view(self.out_net.ws_d))
         dxs: Dict[int, torch.Tensor] = {}
@@ -676,6 +679,9 @@ class PosteriorMatchingVDVAE(Module):
             blk = self.dec_blocks[i]
             r = blk.base
             dxin = blk.backward(dxs[r], dacts[r], dmacts[r], g, g, streams=streams)
+            if self.store.reducer is not None:          # data-parallel: block i's weight gradients are final once the
+                self.ws.join_all_aux()                  # main chain and the masked-posterior chain (streams[1]) got here
+                self.store.grads_ready([f"decoder/block_{i}"], streams=None if streams is None else (main, streams[1]))
             if blk.mixin is not None:
                 ops.resize_nearest_add_bwd(dxin, dxs[blk.mixin])
             if self._first_use[r] == i:

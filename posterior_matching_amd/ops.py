@@ -62,6 +62,7 @@ _timer: Optional[KernelTimer] = None
 def set_timer(t: Optional[KernelTimer]) -> None:
     global _timer
     _timer = t
+    _lib.load().pm_kernel_names_enable(1 if t is not None else 0)
 
 
 # ---- launch plans: the host side of a training step recorded once, replayed without the Python model code ------
@@ -138,10 +139,14 @@ def _call(fname: str, *args, tag: Optional[str] = None, work: Optional[dict] = N
             _recording.append((fn, full, fname))
         return
     e0, e1 = Event(), Event()
+    lib.pm_clear_kernel_name()
     e0.record()
     _lib.check(fn(_stream(), *args), fname)
     e1.record()
-    _timer.records.append((tag or fname, work or {}, e0, e1))
+    # the library reports which kernel variant it launched (as rocprofv3 names it): rows of the live table = rows of
+    # the rocprof summary.  `tag` (the host-side mirror of the dispatch rules) only names what the library does not.
+    name = lib.pm_last_kernel_name().decode()
+    _timer.records.append((name or tag or fname, work or {}, e0, e1))
 
 
 def _nbytes(*ts) -> float:
@@ -741,6 +746,27 @@ def mlp_pair_bf16(x, w1_split, w2_split, b1, b2, aux1, aux2, out1, out2, in_act,
           work=work)
 
 
+def layernorm_fwd(x, res, y, out, rstd, eps: float = 1e-5) -> None:
+    """y = LayerNorm(x) over the last axis (no scale / offset); out = y + res when given (csrc/pm_mlp.hip)"""
+    H = x.shape[-1]
+    _call("pm_layernorm_fwd", _ptr(x), _ptr(res), _ptr(y), _ptr(out), _ptr(rstd), x.numel() // H, H, eps,
+          tag="layernorm_fwd_kernel", work={"bytes": _nbytes(x, res, y, out)})
+
+
+def layernorm_bwd(y, rstd, dy, dx) -> None:
+    H = y.shape[-1]
+    _call("pm_layernorm_bwd", _ptr(y), _ptr(rstd), _ptr(dy), _ptr(dx), y.numel() // H, H, tag="layernorm_bwd_kernel",
+          work={"bytes": _nbytes(y, dy, dx)})
+
+
+def relu_mask_fwd(x, mask, out) -> None:
+    _call("pm_relu_mask_fwd", _ptr(x), _ptr(mask), _ptr(out), x.numel())
+
+
+def relu_mask_bwd(x, mask, dout, dx) -> None:
+    _call("pm_relu_mask_bwd", _ptr(x), _ptr(mask), _ptr(dout), _ptr(dx), x.numel())
+
+
 # ---- PM-VAE evaluation paths (csrc/pm_eval.hip) ------------------------------------------------------------
 def repeat_rows(src, dst, S: int) -> None:
     """dst[b*S + s, :] = src[b, :]"""
@@ -790,15 +816,21 @@ def segment_wsum(v, w, out, sign: float = 1.0, accumulate: bool = False) -> None
     _call("pm_segment_wsum", _ptr(v), _ptr(w), _ptr(out), B, v.numel() // B, float(sign), int(accumulate))
 
 
-def image_mask_mixture(mask, comps, seed: int, step_dev=None, stream_id: int = 0, desc_out=None) -> None:
-    """mask [B,H,W,1] f32; comps: ctypes array of _lib.MaskComponent (host memory, copied into the launch)"""
+def image_mask_mixture(mask, comps, seed: int, step_dev=None, stream_id: int = 0, desc_out=None, pattern_state=None,
+                       pattern_refresh: int = 0) -> None:
+    """mask [B,H,W,1] f32; comps: ctypes array of _lib.MaskComponent (host memory, copied into the launch);
+    pattern_state: int64 [2] device tensor (noise epoch, pixels handed out) when a PATTERN component is present"""
     B, H, W = mask.shape[0], mask.shape[1], mask.shape[2]
     dptr = None
     if desc_out is not None:
         assert desc_out.is_cuda and desc_out.dtype == torch.int32 and desc_out.is_contiguous() and desc_out.numel() == 6 * B
         dptr = desc_out.data_ptr()
+    sptr = None
+    if pattern_state is not None:
+        assert pattern_state.is_cuda and pattern_state.dtype == torch.int64 and pattern_state.numel() == 2
+        sptr = pattern_state.data_ptr()
     _call("pm_image_mask_mixture", _ptr(mask), B, H, W, comps, len(comps), seed & (2 ** 64 - 1), _iptr(step_dev),
-          stream_id, dptr)
+          stream_id, dptr, sptr, int(pattern_refresh))
 
 
 def bernoulli_mask(mask, p: float, seed: int, step_dev=None, stream_id: int = 0) -> None:
@@ -931,7 +963,8 @@ def pmvae_loss(rec, kl, mll, cfg: _lib.LossCfg, step_dev, out, g_rec, g_kl, g_ml
 
 
 def adam_step(p, g, m, v, n_decay, count_dev, cfg: _lib.AdamCfg) -> None:
-    _call("pm_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay, _iptr(count_dev), C.byref(cfg))
+    _call("pm_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay, _iptr(count_dev), C.byref(cfg),
+          tag="adam_kernel", work={"bytes": 7.0 * 4.0 * p.numel()})       # reads p, g, m, v; writes p, m, v
 
 
 def counter_increment(count_dev) -> None:
@@ -943,7 +976,8 @@ def normal_fill(out, seed: int, step_dev, stream_id: int = 0) -> None:
 
 
 def split_weights(flat_params, out_bf16, jobs_dev, njobs: int, total_blocks: int) -> None:
-    _call("pm_split_weights", _ptr(flat_params), out_bf16.data_ptr(), jobs_dev.data_ptr(), njobs, total_blocks)
+    _call("pm_split_weights", _ptr(flat_params), out_bf16.data_ptr(), jobs_dev.data_ptr(), njobs, total_blocks,
+          tag="split_weights_kernel", work={"bytes": float(out_bf16.numel()) * (2 + 2)})    # f32 read once per hi/lo pair, two bf16 writes
 
 
 def fill_zero(t) -> None:
@@ -952,7 +986,7 @@ def fill_zero(t) -> None:
 
 def colsum(x, out) -> None:
     N = x.shape[-1]
-    _call("pm_colsum", _ptr(x), _ptr(out), x.numel() // N, N)
+    _call("pm_colsum", _ptr(x), _ptr(out), x.numel() // N, N, tag="colsum_kernel", work={"bytes": _nbytes(x, out)})
 
 
 def axpy1(x, y) -> None:

@@ -86,16 +86,32 @@ def constant_schedule(value) -> ExponentialDecay:
     return ExponentialDecay(float(value), 1.0, 1.0)
 
 
-def linear_schedule(init_value, end_value, transition_steps, transition_begin=0):
-    raise NotImplementedError("optax.linear_schedule (the VDVAE warm-up, train_pm_vdvae.py:124-127) is not lowered to the "
-                              "fused optimizer; the reference configs set no warm_up")
+@dataclass
+class LinearSchedule:
+    """optax.linear_schedule(init_value, end_value, transition_steps): the VDVAE warm-up (train_pm_vdvae.py:128-132)."""
+
+    init_value: float
+    end_value: float
+    transition_steps: float
+
+    def __call__(self, count: int) -> float:
+        f = min(max(count / self.transition_steps, 0.0), 1.0)
+        return (self.init_value - self.end_value) * (1.0 - f) + self.end_value
+
+
+def linear_schedule(init_value, end_value, transition_steps, transition_begin=0) -> LinearSchedule:
+    if transition_begin != 0:
+        raise NotImplementedError("linear_schedule(transition_begin != 0) has no HIP path (the reference passes none)")
+    if transition_steps <= 0:
+        raise ValueError("transition_steps must be positive")
+    return LinearSchedule(float(init_value), float(end_value), float(transition_steps))
 
 
 @dataclass
 class Chain:
     adam: ScaleByAdam
     decay: AddDecayedWeights
-    schedule: ExponentialDecay
+    schedule: Any                      # ExponentialDecay | LinearSchedule
     clip: Optional[ClipByGlobalNorm] = None
 
     def adam_cfg(self, grad_scale: float = 1.0):
@@ -104,7 +120,10 @@ class Chain:
         c = AdamCfg()
         c.b1, c.b2, c.eps = self.adam.b1, self.adam.b2, self.adam.eps
         c.weight_decay = self.decay.weight_decay
-        c.lr_init, c.lr_decay_rate = self.schedule.init_value, self.schedule.decay_rate
+        if isinstance(self.schedule, LinearSchedule):
+            c.lr_kind, c.lr_init, c.lr_end, c.lr_decay_rate = 1, self.schedule.init_value, self.schedule.end_value, 1.0
+        else:
+            c.lr_kind, c.lr_init, c.lr_decay_rate, c.lr_end = 0, self.schedule.init_value, self.schedule.decay_rate, 0.0
         c.lr_transition_steps = self.schedule.transition_steps
         c.grad_scale = grad_scale
         return c
@@ -121,7 +140,7 @@ def chain(*transforms) -> Chain:
         transforms = (transforms[0], AddDecayedWeights(0.0), transforms[1], transforms[2])
     if (len(transforms) != 4 or not isinstance(transforms[0], ScaleByAdam)
             or not isinstance(transforms[1], AddDecayedWeights) or not isinstance(transforms[2], ScaleBySchedule)
-            or not isinstance(transforms[2].schedule, ExponentialDecay) or not isinstance(transforms[3], Scale)
+            or not isinstance(transforms[2].schedule, (ExponentialDecay, LinearSchedule)) or not isinstance(transforms[3], Scale)
             or transforms[3].factor != -1.0):
         raise NotImplementedError(
             "only chain(scale_by_adam, add_decayed_weights, scale_by_schedule(exponential_decay), scale(-1.0)) "

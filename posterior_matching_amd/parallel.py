@@ -7,7 +7,7 @@ reference (train_pm_vdvae.py:146-154): batch sizes in the configs 
 from __future__ import annotations
 
 import os
-from typing import Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -54,3 +54,129 @@ def allreduce_mean_scalars(values: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(values, op=dist.ReduceOp.SUM)
         values /= dist.get_world_size()
     return values
+
+
+class GradReducer:
+    """Reverse-order gradient buckets, all-reduced while the rest of the backward pass still runs (SURVEY.md 8(e);
+    what pmap's pmean does for the reference at train_pm_vdvae.py:146-154, one bucket at a time instead of after the fact).
+
+    The flat gradient buffer is [ndim != 1 leaves in creation order | 1-D leaves].  A model's backward calls
+    `ready(prefixes)` on the stream that carried those modules' weight-gradient kernels as soon as every parameter under
+    the prefixes has its final gradient; the weight range of those modules (contiguous: a module's leaves are created
+    together) joins the pending range, and once `bucket_bytes` are pending the range is all-reduced on the communication
+    stream behind an event of the producing stream(s).  `finish()` reduces what is left - in particular the whole 1-D
+    suffix (biases: a few KB) in one call - and makes the current stream wait for every collective.  Sum only: the
+    optimizer kernels divide by the world size (grad_scale), and the VDVAE's global-norm clip / non-finite skip run on the
+    reduced buffer after finish(), so every rank takes the same decision.
+
+    Every operation goes through ops.record_event / ops.wait_event / ops.host_call, so a recorded launch plan replays
+    the same overlap."""
+
+    def __init__(self, store, bucket_bytes: int = 16 << 20, overlap: bool = True, async_issue: Optional[bool] = None):
+        """async_issue: collectives are enqueued without blocking the host (default for nccl = RCCL: the collective is a
+        kernel on RCCL's stream, ordered behind the bucket's event).  gloo stages device tensors through pinned host
+        memory on a two-thread pool; several collectives of one step in flight there were measured 60x slower than one
+        (2 ranks sharing one MI355X: 402 vs 6.9 ms per step), so for gloo (CPU tests, the one-GPU rehearsal) each bucket
+        is reduced synchronously at its ready point: same buckets, same order, same results, no overlap."""
+        self.store, self.bucket_bytes, self.overlap = store, int(bucket_bytes), overlap
+        if async_issue is None:
+            async_issue = dist.is_initialized() and dist.get_backend() == "nccl"
+        self.async_issue = async_issue
+        self.flat = store.flat_g
+        self._cuda = torch.device(store.device).type == "cuda"     # host tensors (gloo, CPU tests): no streams to order
+        self.comm = torch.cuda.Stream(device=store.device) if self._cuda else None
+        self._done: List[Tuple[int, int]] = []          # element ranges already handed to a collective this step
+        self._pending: List[Tuple[int, int]] = []
+        self._pending_events: List["torch.cuda.Event"] = []
+        self._works: List = []
+        self.calls_last_step = 0
+        self._calls = 0
+
+    # -- ranges ---------------------------------------------------------------------------------------------------
+    def _weight_range(self, prefixes: Sequence[str]) -> Optional[Tuple[int, int]]:
+        offs = [(o, o + n) for name, (o, n) in self.store.offsets.items()
+                if o < self.store.n_decay and any(name == p or name.startswith(p + "/") for p in prefixes)]
+        if not offs:
+            return None
+        lo, hi = min(a for a, _ in offs), max(b for _, b in offs)
+        if sum(b - a for a, b in offs) != hi - lo:
+            raise ValueError(f"parameters under {list(prefixes)} are not contiguous in the flat buffer")
+        return lo, hi
+
+    @staticmethod
+    def _merge(ranges):
+        out = []
+        for a, b in sorted(ranges):
+            if out and a <= out[-1][1]:
+                out[-1] = (out[-1][0], max(out[-1][1], b))
+            else:
+                out.append((a, b))
+        return out
+
+    # -- host-side pieces that a launch plan replays --------------------------------------------------------------------
+    def _issue(self, a: int, b: int) -> None:
+        self._calls += 1
+        if not self.async_issue:
+            if self._cuda:
+                self.comm.synchronize()         # the bucket's producers (events the comm stream waits for) have run
+            dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM)
+            return
+        if self._cuda:
+            with torch.cuda.stream(self.comm):
+                self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _wait_all(self) -> None:
+        for w in self._works:
+            w.wait()                      # the current stream waits for the collective (nccl); gloo blocks the host
+        self._works.clear()
+        self.calls_last_step, self._calls = self._calls, 0
+
+    def _flush(self) -> None:
+        from . import ops
+
+        for ev in self._pending_events:
+            ops.wait_event(self.comm, ev)
+        for a, b in self._merge(self._pending):
+            ops.host_call(self._issue, a, b)
+            self._done.append((a, b))
+        self._pending, self._pending_events = [], []
+
+    # -- model-facing API ------------------------------------------------------------------------------------------
+    def ready(self, prefixes: Sequence[str], streams: Optional[Sequence["torch.cuda.Stream"]] = None) -> None:
+        """every parameter under `prefixes` has its final gradient once the work enqueued so far on `streams` (default:
+        the current stream) has run"""
+        if not self.overlap:
+            return
+        from . import ops
+
+        r = self._weight_range(prefixes)
+        if r is None:
+            return
+        for s in ((streams or [torch.cuda.current_stream(self.store.device)]) if self._cuda else ()):
+            ev = torch.cuda.Event()
+            ops.record_event(ev, s)
+            self._pending_events.append(ev)
+        self._pending.append(r)
+        if sum(b - a for a, b in self._pending) * 4 >= self.bucket_bytes:
+            self._flush()
+
+    def finish(self) -> None:
+        """reduces every range not yet handed over (the 1-D suffix included) and joins the collectives; call on the stream
+        the optimizer runs on, after the backward pass has been joined onto it"""
+        from . import ops
+
+        if self._cuda:
+            ev = torch.cuda.Event()
+            ops.record_event(ev, torch.cuda.current_stream(self.store.device))
+            self._pending_events.append(ev)
+        covered = self._merge(self._done + self._pending)
+        pos, total = 0, self.flat.numel()
+        for a, b in covered + [(total, total)]:
+            if a > pos:
+                self._pending.append((pos, a))
+            pos = max(pos, b)
+        self._flush()
+        self._done = []
+        ops.host_call(self._wait_all)

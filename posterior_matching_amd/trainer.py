@@ -158,7 +158,10 @@ class Trainer:
         is_pmvq = isinstance(lf, PMVQVAELoss)
         if isinstance(lf, VDVAELoss):
             opt = self.optimizer
-            ts = VDVAETrainStep(model, opt.schedule.init_value, B, gradient_clip=opt.clip.max_norm if opt.clip else 0.0,
+            from .optim import LinearSchedule
+
+            lr = opt.schedule if isinstance(opt.schedule, LinearSchedule) else opt.schedule.init_value
+            ts = VDVAETrainStep(model, lr, B, gradient_clip=opt.clip.max_norm if opt.clip else 0.0,
                                 ema_rate=self.ema_rate, weight_decay=opt.decay.weight_decay,
                                 adam={"b1": opt.adam.b1, "b2": opt.adam.b2, "eps": opt.adam.eps}, seed=self.seed,
                                 world_size=self.world, rank=self.rank, skip_nonfinite_updates=self.skip_nonfinite)

@@ -46,21 +46,29 @@ bs = torch.tensor(rng.uniform(size=(STEPS, G, 8)) < 0.5, dtype=torch.float32, de
 es = torch.tensor(rng.normal(size=(STEPS, G, 16)), dtype=torch.float32, device=dev)
 
 
-def pmvae(world_size, r, rows):
+def pmvae(world_size, r, rows, overlap=True):
     m = PosteriorMatchingVAE.from_config(cfg["model"], device=dev, seed=3)
     m.init((8,))
     m.store.use_bf16 = False
     opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg["weight_decay"]),
                       optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
-    ts = PMVAETrainStep(m, cfg, opt, rows.stop - rows.start, (8,), world_size=world_size, rank=r, external_eps=True)
+    ts = PMVAETrainStep(m, cfg, opt, rows.stop - rows.start, (8,), world_size=world_size, rank=r, external_eps=True,
+                        overlap_allreduce=overlap)
     for s in range(STEPS):
         ts.set_batch(xs[s, rows], bs[s, rows], es[s, rows])
         ts.step()
     ts.synchronize()
+    if world_size > 1:          # bucketed: decoder / posterior-matching branch / encoder + the 1-D suffix; else one call
+        assert ts.reducer.calls_last_step == (1 if not overlap else ts.reducer.calls_last_step) >= 1
+        report[f"pm_vae_allreduce_calls_overlap_{overlap}"] = ts.reducer.calls_last_step
     return m.params_dict()
 
 
 dp = pmvae(world, rank, shard_rows(G, rank, world))
+dp_single = pmvae(world, rank, shard_rows(G, rank, world), overlap=False)
+for k in dp:                                 # bucketed + overlapped == one all-reduce after the backward pass
+    assert rel(dp[k], dp_single[k]) < 1e-5, ("overlap changes the trajectory", k)     # atomics: not bitwise
+assert report["pm_vae_allreduce_calls_overlap_True"] > report["pm_vae_allreduce_calls_overlap_False"] == 1
 if rank == 0:
     report["pm_vae"] = compare("pm_vae", dp, pmvae(1, 0, slice(0, G)), 2e-4)
 

@@ -105,3 +105,25 @@ def pm_vqvae_celeb_a():
         "steps": 150000, "validation_freq": 2000,
         "lr_schedule": {"init_value": 3e-4, "decay_rate": 0.999995, "transition_steps": 1},
     }
+
+
+def pm_vae_miniboone():
+    """configs/pm_vae_miniboone.py:4-61 of the reference: the ResidualMLP(layer_norm=True, dropout=0.5) family."""
+    return {
+        "data": {"dataset": "miniboone", "train_split": "train", "validation_split": "val",
+                 "train_batch_size": 1024, "val_batch_size": 1024, "training_noise": 0.001,
+                 "mask_generator": "BernoulliMaskGenerator"},
+        "model": {
+            "latent_dim": 32, "encoder_net": "ResidualMLP", "decoder_net": "ResidualMLP",
+            "decoder_dist": "IdentityGaussian", "posterior_dist": "TriLGaussian",
+            "decoder_dist_config": {"event_size": 43},
+            "masked_posterior_dist": "AutoregressiveGMM",
+            "masked_posterior_config": {"hidden_units": 256, "residual_blocks": 3},
+            "encoder_net_config": {"residual_blocks": 5, "hidden_units": 256, "layer_norm": True, "dropout": 0.5},
+            "decoder_net_config": {"residual_blocks": 2, "hidden_units": 256, "layer_norm": True, "dropout": 0.5},
+            "matching_ll_stop_gradients": True,
+        },
+        "beta": {"schedule": "cyclic", "low_value": 0.0, "high_value": 1.0, "period": 5000, "delay": 2000},
+        "steps": 22000, "validation_freq": 1000, "save_final_state": True, "weight_decay": 0.00001,
+        "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 1000},
+    }

@@ -173,6 +173,7 @@ def test_celeba_stage2_default_mode_step_and_properties():
         ts.ws.join_aux()
     ts.synchronize()
     ga = ts.store.flat_g.clone()
+    torch.cuda.synchronize()            # the copy runs on the default stream: it must finish before ts.stream zeroes flat_g
     with torch.cuda.stream(ts.stream):
         ops.fill_zero(ts.store.flat_g)
         ts.penc.backward(ts.pcnn.backward((2.0 * g1).contiguous()))

@@ -155,3 +155,83 @@ def test_device_masks_match_golden_fixture():
     u2 = torch.empty((8, 300), device=dev())
     ops.uniform_mask(u2, 75, 150, 5, None)
     assert np.array_equal(np.packbits(u2.cpu().numpy().astype(np.uint8).reshape(-1)), gold["uniform_bounds"])
+
+
+def _pattern_comps(max_size, low, weight_pattern=3.0):
+    """a pattern-heavy mixture for the bit-exactness test (CelebA itself draws the pattern for 5 % of the examples)"""
+    from posterior_matching_amd._lib import MaskComponent
+
+    oc = [MO.Component(MO.PATTERN, weight_pattern, p=0.25, size=max_size, low_size=low, min_prop=0.05),
+          MO.Component(MO.RECT, 1.0, min_prop=0.3, max_prop=1.0)]
+    cum = MO.cumulative_weights(oc)
+    dc = (MaskComponent * 2)()
+    dc[0].kind, dc[0].p, dc[0].size, dc[0].y1, dc[0].min_prop, dc[0].cum_weight = 4, 0.25, max_size, low, 0.05, float(cum[0])
+    dc[1].kind, dc[1].min_prop, dc[1].max_prop, dc[1].cum_weight = 3, 0.3, 1.0, float(cum[1])
+    return oc, dc
+
+
+@pytest.mark.parametrize("max_size,low,H,W", [(2000, 120, 64, 64), (10000, 600, 64, 64), (500, 40, 32, 48)])
+def test_random_pattern_masks_bit_exact(max_size, low, H, W):
+    """PM_MASK_PATTERN (RandomPatternMaskGenerator, reference masking.py:177-232): window origins, accepted tries and every
+    pixel equal the oracle's, whose bicubic arithmetic is pinned against Pillow (tests/test_oracle_kat.py); blob coverage
+    inside density +- 0.05; the device state counts the pixels handed out and bumps the noise epoch past the threshold."""
+    from posterior_matching_amd import ops
+
+    B, seed = 48, 21
+    oc, dc = _pattern_comps(max_size, low)
+    state = torch.zeros(2, dtype=torch.int64, device=dev())
+    step = torch.tensor([5], dtype=torch.int32, device=dev())
+    out, desc = torch.empty((B, H, W, 1), device=dev()), torch.zeros((B, 6), dtype=torch.int32, device=dev())
+    ops.image_mask_mixture(out, dc, seed, step, 2, desc, state, 10 ** 12)
+    torch.cuda.synchronize()
+    want, wdesc = MO.image_mask_mixture(B, H, W, oc, seed, step=5, stream=2, pattern_epoch=0)
+    assert np.array_equal(desc.cpu().numpy(), wdesc)
+    assert np.array_equal(out.cpu().numpy(), want)
+    pat = wdesc[:, 0] == MO.PATTERN
+    assert pat.sum() >= B // 2
+    cover = 1.0 - want[pat].mean(axis=(1, 2, 3))
+    assert (np.abs(cover - 0.25) < 0.05 + 1e-6).all()
+    assert state.cpu().tolist() == [0, int(pat.sum()) * H * W]
+    # a threshold below the pixels handed out: the next launch reads epoch 1 - a different noise field
+    ops.image_mask_mixture(out, dc, seed, step, 2, desc, state, 10)
+    torch.cuda.synchronize()
+    assert state.cpu().tolist() == [1, 0]
+    ops.image_mask_mixture(out, dc, seed, step, 2, desc, state, 10 ** 12)
+    torch.cuda.synchronize()
+    want1, wdesc1 = MO.image_mask_mixture(B, H, W, oc, seed, step=5, stream=2, pattern_epoch=1)
+    assert np.array_equal(out.cpu().numpy(), want1) and np.array_equal(desc.cpu().numpy(), wdesc1)
+    assert not np.array_equal(want1[pat], want[pat])
+
+
+def test_celeba_device_mixture_bit_exact_and_distribution():
+    """get_mask_generator("CelebAMaskGenerator", device=...) (reference masking.py:289-325, 14 flattened components): two
+    batches bit-exact against the oracle, then 4096 masks: component frequencies = the product weights, the fixed GCF /
+    SIIDGM rectangles exact, rectangles >= 30 % of the area, pixel-Bernoulli mean 0.2, pattern coverage 0.25 +- 0.05."""
+    from posterior_matching_amd.masking import get_mask_generator
+
+    comps = MO.celeba_components()
+    gen = get_mask_generator("CelebAMaskGenerator", device=dev(), seed=9)
+    for step in range(2):
+        got = gen((40, 64, 64, 1))
+        assert np.array_equal(got.cpu().numpy(), MO.image_mask_mixture(40, 64, 64, comps, 9, step=step)[0]), step
+    B = 4096
+    gen = get_mask_generator("CelebAMaskGenerator", device=dev(), seed=10)
+    desc = torch.zeros((B, 6), dtype=torch.int32, device=dev())
+    out = torch.empty((B, 64, 64, 1), device=dev())
+    gen.fill(out, desc_out=desc)
+    d, m = desc.cpu().numpy(), out.cpu().numpy()[..., 0]
+    assert set(np.unique(m)) <= {0.0, 1.0}
+    w = np.array([c.weight for c in comps])
+    freq = np.bincount(d[:, 5], minlength=len(comps)) / B
+    assert np.abs(freq - w / w.sum()).max() < 0.02
+    pat, bern, rect = d[:, 5] == 0, d[:, 5] == 1, d[:, 5] == len(comps) - 1
+    assert (np.abs((1 - m[pat]).mean((1, 2)) - 0.25) < 0.05 + 1e-6).all() and pat.sum() > 100
+    assert abs(m[bern].mean() - 0.2) < 0.01
+    for ci, r in list(enumerate(MO.SIIDGM_RECTS, start=2)) + list(enumerate(MO.GCF_RECTS, start=7)):
+        want = np.ones((64, 64))
+        want[r[0]:r[2], r[1]:r[3]] = 0
+        sel = m[d[:, 5] == ci]
+        assert len(sel) > 0 and (sel == want).all(), ci
+    area = (d[rect, 3] - d[rect, 1]) * (d[rect, 4] - d[rect, 2])
+    assert (area == (1 - m[rect]).sum((1, 2))).all() and area.min() >= 0.3 * 4096
+    assert gen.pattern_state.cpu().tolist() == [0, int(pat.sum()) * 4096]

@@ -457,13 +457,14 @@ def test_train_steps_match_oracle(name, B):
     assert worst[0] < max(1e-5, 6 * worst32[0]), (worst, worst32)
 
 
-def test_bf16x3_training_trajectory_within_1e3():
-    """Default fast path (bf16x3 GEMMs, two streams, eager): 6 optimizer steps at B = 64; ELBO, KL and
-    matching-LL of every step within 1e-3 relative of the float64 oracle trajectory."""
+@pytest.mark.parametrize("B,steps", [(64, 6), (256, 4)])
+def test_bf16x3_training_trajectory_within_1e3(B, steps):
+    """Default fast path (bf16x3 GEMMs, two streams, launch-plan replay from step 3): optimizer steps at B = 64 and at
+    the BASELINE batch 256 (the benchmarked configuration and arithmetic); ELBO, KL and matching-LL of every step
+    within 1e-3 relative of the float64 oracle trajectory."""
     from posterior_matching_amd import optim
     from posterior_matching_amd.engine import PMVAETrainStep
 
-    B = 64
     cfg, xs, _, _, _ = _inputs("mnist", B, 7)
     m = _product_model(cfg, xs, bf16x3=True)
     p = {n: t.cpu().double() for n, t in m.params_dict().items()}
@@ -472,7 +473,7 @@ def test_bf16x3_training_trajectory_within_1e3():
     opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(0.0),
                       optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
     ts = PMVAETrainStep(m, cfg, opt, B, xs, external_eps=True)
-    for step in range(6):
+    for step in range(steps):
         _, _, x, b, eps = _inputs("mnist", B, 300 + step)
         ts.set_batch(x.float().to(dev()), b.float().to(dev()), eps.float().to(dev()))
         ts.step()
@@ -692,3 +693,147 @@ def test_diagonal_gaussian_heads_and_model():
     torch.cuda.synchronize()
     for n, gt in m.grads_dict().items():
         assert rel_err(gt, grads[n]) < 5e-5, n
+
+
+# ----------------------------------------------------------------------------------------------
+# ResidualMLP(layer_norm=True, dropout > 0): reference networks.py:116-131, configs/pm_vae_miniboone.py:29-39
+# ----------------------------------------------------------------------------------------------
+def test_layernorm_and_relu_dropout_kernels():
+    """pm_layernorm_{fwd,bwd}, pm_relu_mask_{fwd,bwd} vs float64 autograd (2e-6 / 5e-6)."""
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(3)
+    for R, H in ((37, 256), (5, 100), (130, 1024)):
+        x = torch.randn((R, H), generator=gen, dtype=F64) * 2 + 0.3
+        res, g = torch.randn((R, H), generator=gen, dtype=F64), torch.randn((R, H), generator=gen, dtype=F64)
+        xr = x.clone().requires_grad_(True)
+        y = O.layer_norm(xr)
+        (y * g).sum().backward()
+        d = dev()
+        yd, od, rs = torch.empty((R, H), device=d), torch.empty((R, H), device=d), torch.empty(R, device=d)
+        ops.layernorm_fwd(x.float().to(d), res.float().to(d), yd, od, rs)
+        assert rel_err(yd, y) < 2e-6 and rel_err(od, y + res) < 2e-6
+        var = ((x - x.mean(-1, keepdim=True)) ** 2).mean(-1)
+        assert rel_err(rs, 1.0 / torch.sqrt(var + 1e-5)) < 2e-6
+        dx = torch.empty((R, H), device=d)
+        ops.layernorm_bwd(yd, rs, g.float().to(d), dx)
+        assert rel_err(dx, xr.grad) < 5e-6
+        mask = (torch.rand((R, H), generator=gen) > 0.5).double() * 2.0
+        out, dxx = torch.empty((R, H), device=d), torch.empty((R, H), device=d)
+        ops.relu_mask_fwd(x.float().to(d), mask.float().to(d), out)
+        assert torch.equal(out.cpu(), (torch.relu(x.float()) * mask.float()))
+        ops.relu_mask_bwd(x.float().to(d), mask.float().to(d), g.float().to(d), dxx)
+        assert torch.equal(dxx.cpu(), (g.float() * mask.float() * (x.float() > 0)))
+
+
+def _miniboone(B, seed):
+    from tests.ref_configs import pm_vae_miniboone
+
+    cfg, xs = pm_vae_miniboone(), (43,)
+    rng = np.random.default_rng(seed)
+    x = torch.tensor(rng.normal(size=(B,) + xs))
+    b = torch.tensor((rng.uniform(size=(B,) + xs) < 0.5).astype(np.float64))
+    eps = torch.tensor(rng.normal(size=(B, 32)))
+    masks = {"encoder_net": [torch.tensor((rng.uniform(size=(B, 256)) > 0.5) * 2.0) for _ in range(5)],
+             "decoder_net": [torch.tensor((rng.uniform(size=(B, 256)) > 0.5) * 2.0) for _ in range(2)],
+             "partial_encoder_net": [torch.tensor((rng.uniform(size=(B, 256)) > 0.5) * 2.0) for _ in range(5)]}
+    return cfg, xs, x, b, eps, masks
+
+
+def _set_masks(m, masks):
+    for name, net in (("encoder_net", m.encoder_net), ("decoder_net", m.decoder_net),
+                      ("partial_encoder_net", m.partial_encoder_net)):
+        if net.dropout_masks is None:
+            net.dropout_masks = [t.float().to(dev()).contiguous() for t in masks[name]]
+        else:
+            for dst, src in zip(net.dropout_masks, masks[name]):
+                dst.copy_(src.float())
+
+
+@pytest.mark.parametrize("bf16x3,training", [(False, True), (True, True), (False, False)])
+def test_miniboone_layernorm_dropout_model(bf16x3, training):
+    """configs/pm_vae_miniboone.py network (5 / 2 residual blocks with LayerNorm after every Linear and dropout 0.5,
+    TriL posterior AND - the from_config key quirk - TriL partial posterior): outputs and all gradient tensors against the
+    float64 oracle with explicit keep masks (f32: 1e-5 / max(5e-5, 10x f32-CPU error); bf16x3: 1e-4 / 1e-2)."""
+    from posterior_matching_amd import ops
+    from posterior_matching_amd.engine import loss_cfg_from_config
+
+    B = 19
+    cfg, xs, x, b, eps, masks = _miniboone(B, 5)
+    m = _product_model(cfg, xs, bf16x3=bf16x3)
+    p64 = {n: t.cpu().double() for n, t in m.params_dict().items()}
+    assert list(p64) == list(O.param_shapes(cfg["model"], xs))
+    step = 4500                                                      # cyclic beta = 1.0 at 2000 + 2500
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, aux, out = O.pm_vae_loss(leaves, cfg, x, b, eps, step, masks if training else None)
+    d = dev()
+    _set_masks(m, masks)
+    got = m(x.float().to(d), b.float().to(d), is_training=training, eps=eps.float().to(d))
+    for key in ("reconstruction_ll", "kl", "matching_ll"):
+        assert rel_err(got[key], out[key]) < (1e-4 if bf16x3 else 1e-5), key
+    if not training:
+        return
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    step_dev = torch.tensor([step], dtype=torch.int32, device=d)
+    metrics = torch.zeros(8, device=d)
+    g = [torch.empty(B, device=d) for _ in range(3)]
+    ops.pmvae_loss(got["reconstruction_ll"], got["kl"], got["matching_ll"], loss_cfg_from_config(cfg, B), step_dev,
+                   metrics, *g)
+    assert abs(metrics[0].item() - loss.item()) < (1e-4 if bf16x3 else 1e-5) * abs(loss.item())
+    m.zero_grad()
+    m.backward(*g)
+    torch.cuda.synchronize()
+    gd = m.grads_dict()
+    l32 = {n: t.float().clone().requires_grad_(True) for n, t in p64.items()}
+    m32 = {k: [t.float() for t in v] for k, v in masks.items()}
+    loss32, _, _ = O.pm_vae_loss(l32, cfg, x.float(), b.float(), eps.float(), step, m32)
+    g32_ = dict(zip(l32, torch.autograd.grad(loss32, list(l32.values()))))
+    for n in grads:
+        e, e32 = rel_err(gd[n], grads[n]), rel_err(g32_[n], grads[n])
+        if not bf16x3:
+            assert e < max(5e-5, 10 * e32) and e < 2e-4, (n, e, e32)
+        else:
+            assert e < 1e-2, (n, e, e32)
+
+
+def test_miniboone_train_steps_and_device_dropout():
+    """3 optimizer steps (launch plan replay from step 3) with explicit masks in static buffers track the float64 oracle
+    (loss 1e-4 at steps 0-1, 1e-3 after); then the device Philox dropout: keep masks in {0, 2} with mean 1, a different
+    draw every step, the same draw for the same (seed, step)."""
+    from posterior_matching_amd import optim
+    from posterior_matching_amd.engine import PMVAETrainStep
+
+    B = 32
+    cfg, xs, *_ = _miniboone(B, 7)
+    m = _product_model(cfg, xs, bf16x3=False)
+    p = {n: t.cpu().double() for n, t in m.params_dict().items()}
+    mo, vo = {n: torch.zeros_like(t) for n, t in p.items()}, {n: torch.zeros_like(t) for n, t in p.items()}
+    opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg["weight_decay"]),
+                      optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
+    ts = PMVAETrainStep(m, cfg, opt, B, xs, external_eps=True)
+    ts.step_dev.fill_(2400)                                          # cyclic beta = 0.16 .. : a schedule value in (0, 1)
+    for step in range(3):
+        _, _, x, b, eps, masks = _miniboone(B, 100 + step)
+        _set_masks(m, masks)
+        ts.set_batch(x.float().to(dev()), b.float().to(dev()), eps.float().to(dev()))
+        ts.step()
+        loss, aux, _ = O.train_step(p, mo, vo, cfg, x, b, eps, 2400 + step, masks)
+        got = ts.read_metrics()
+        assert got["beta"] == pytest.approx(aux["beta"], rel=1e-6)
+        for key, want in (("loss", loss), ("kl", aux["kl"]), ("matching_ll", aux["matching_ll"])):
+            assert abs(got[key] - float(want)) <= (1e-4 if step < 2 else 1e-3) * abs(float(want)), (step, key)
+    # device dropout
+    for net in (m.encoder_net, m.decoder_net, m.partial_encoder_net):
+        net.dropout_masks = None
+    ts.invalidate_plan()
+    drawn = []
+    for _ in range(3):
+        ts.step()
+        ts.synchronize()
+        drawn.append(m.encoder_net.buf("g/mask_0", (B, 256)).clone())
+        assert np.isfinite(ts.read_metrics()["loss"])
+    vals = set(torch.unique(drawn[0]).cpu().tolist())
+    assert vals == {0.0, 2.0} and abs(drawn[0].mean().item() - 1.0) < 0.05
+    assert not torch.equal(drawn[0], drawn[1]) and not torch.equal(drawn[1], drawn[2])
+    assert not torch.equal(m.encoder_net.buf("g/mask_0", (B, 256)), m.encoder_net.buf("g/mask_1", (B, 256)))
+    assert not torch.equal(m.encoder_net.buf("g/mask_0", (B, 256)), m.partial_encoder_net.buf("g/mask_0", (B, 256)))

@@ -217,6 +217,28 @@ def test_pixelcnn_is_autoregressive_on_device():
             assert not same.all()
 
 
+def test_pixelcnn_unconditional_sampling_matches_oracle():
+    """PixelCNN.sample without conditional_input (reference pixel_cnn.py:82-100): exact index grids under explicit Gumbel
+    noise; device noise: reproducible per seed; a network built WITH a conditional_dim refuses to sample without input."""
+    cfg = dict(SMALL, image_shape=(4, 4))
+    pc, store = _build_pixelcnn(cfg, None)
+    p64 = {n: t.cpu().double() for n, t in store.to_dict("p").items()}
+    assert not any("/cond/" in n for n in p64)
+    n, K, P = 5, cfg["num_indices"], 16
+    rng = np.random.default_rng(11)
+    gumbel = torch.tensor(-np.log(-np.log(rng.uniform(1e-6, 1 - 1e-6, size=(P, n, K)))))
+    want = PO.pixel_cnn_sample_unconditional(p64, "pc", cfg, n, gumbel)
+    got = pc.sample(seed=0, sample_shape=n, gumbel=f32d(gumbel))
+    torch.cuda.synchronize()
+    assert got.shape == (n, 4, 4) and got.dtype == torch.int32 and torch.equal(got.cpu().long(), want)
+    s1, s2, s3 = pc.sample(seed=3, sample_shape=(2, 3)), pc.sample(seed=3, sample_shape=(2, 3)), pc.sample(seed=4, sample_shape=(2, 3))
+    assert s1.shape == (2, 3, 4, 4) and torch.equal(s1, s2) and not torch.equal(s1, s3)
+    assert pc.sample(seed=1).shape == (4, 4) and int(s1.min()) >= 0 and int(s1.max()) < K
+    pc2, _ = _build_pixelcnn(SMALL, 16)
+    with pytest.raises(ValueError):
+        pc2.sample(seed=0, sample_shape=2)
+
+
 # ----------------------------------------------------------------------------------------------
 # stage 2 of PM-VQVAE: frozen VQ-VAE + partial encoder + PixelCNN
 # ----------------------------------------------------------------------------------------------
@@ -334,6 +356,31 @@ def test_stage2_train_steps_match_oracle():
     for n, t in ts.vqvae.params_dict().items():                     # trainable_predicate: "vqvae/" stays frozen
         assert torch.equal(t, frozen_before[n]), n
     assert int(ts.vqvae.state["counter"]) == 0
+
+
+@pytest.mark.parametrize("size", ["tiny", "mnist"])
+def test_stage2_default_mode_trajectory_within_1e3(size):
+    """Default arithmetic (bf16x3 GEMMs in the partial encoder and the PixelCNN, launch-plan style static dropout-mask
+    buffers): 4 optimizer steps; loss = -mean log p(codes | x_o) of every step within 1e-3 relative of the float64 oracle
+    trajectory - at the tiny sizes and at the configs/pm_vqvae_mnist.py sizes (35.0 M trainable parameters, batch 4).
+    The frozen VQ-VAE encoder stays on the strict path so that both sides see the same code indices."""
+    if size == "tiny":
+        cfg, vq_cfg, xs, B = TINY_CFG, TINY_VQ, (12, 12, 1), 4
+    else:
+        cfg, vq_cfg, xs, B = pm_vqvae_mnist(), vqvae_mnist()["model"], (28, 28, 1), 4
+    ts, p64, vq64, st64 = _stage2(cfg, vq_cfg, xs, B, seed=9, bf16x3=True)
+    m = {k: torch.zeros_like(v) for k, v in p64.items()}
+    v = {k: torch.zeros_like(t) for k, t in p64.items()}
+    rng = np.random.default_rng(4)
+    for step in range(4):
+        x, b = _batch(rng, B, xs)
+        masks = _masks(rng, cfg, B)
+        loss, _ = PO.train_step(p64, vq64, st64, m, v, cfg, vq_cfg, x, b, step, masks)
+        ts.dropout_masks = [f32d(t) for t in masks]
+        ts.set_batch(f32d(x), f32d(b))
+        ts.step()
+        assert abs(ts.read_metrics()["loss"] - loss.item()) < 1e-3 * abs(loss.item()), (step, ts.read_metrics(), loss.item())
+    assert ts.step_dev.item() == 4
 
 
 def test_stage2_reference_config_small_batch():

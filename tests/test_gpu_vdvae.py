@@ -190,6 +190,42 @@ def test_clipped_adam_with_ema_and_nonfinite_skip():
         assert torch.isfinite(pd).all()
 
 
+def test_vdvae_lr_warm_up_schedule():
+    """optax.linear_schedule(0, lr, warm_up) inside the fused clip + Adam + EMA kernel (train_pm_vdvae.py:128-132): 7 updates
+    across the end of a 5-step warm-up against the oracle (2e-6), and the host-side schedule object's known answers."""
+    from posterior_matching_amd import ops, optim
+    from posterior_matching_amd._lib import AdamCfg
+
+    sched = optim.linear_schedule(0, 1.5e-4, 5)
+    assert [sched(c) for c in (0, 1, 5, 9)] == pytest.approx([0.0, 3e-5, 1.5e-4, 1.5e-4])
+    chain = optim.chain(optim.clip_by_global_norm(2.0), optim.scale_by_adam(), optim.add_decayed_weights(0.01),
+                        optim.scale_by_schedule(sched), optim.scale(-1.0))
+    c = chain.adam_cfg()
+    assert c.lr_kind == 1 and c.lr_end == pytest.approx(1.5e-4) and c.lr_transition_steps == 5.0
+    gen = torch.Generator().manual_seed(4)
+    n, n_decay = 3000, 2000
+    p = {"w": torch.randn(n_decay, 1, generator=gen, dtype=F64) * 0.05, "b": torch.randn(n - n_decay, generator=gen, dtype=F64) * 0.05}
+    m, v = {k: torch.zeros_like(t) for k, t in p.items()}, {k: torch.zeros_like(t) for k, t in p.items()}
+    ema = {k: t.clone() for k, t in p.items()}
+    cfg = {"lr": 1.5e-4, "gradient_clip": 2.0, "ema_rate": 0.999, "weight_decay": 0.01, "warm_up": 5}
+    d = dev()
+    flat = lambda dd: torch.cat([dd["w"].reshape(-1), dd["b"]]).float().to(d)   # noqa: E731
+    pd, md, vd, ed = flat(p), flat(m), flat(v), flat(ema)
+    count, gn = torch.zeros(1, dtype=torch.int32, device=d), torch.zeros(1, device=d)
+    for step in range(7):
+        g = {"w": torch.randn(n_decay, 1, generator=gen, dtype=F64) * 0.02, "b": torch.randn(n - n_decay, generator=gen, dtype=F64) * 0.02}
+        before = pd.clone()
+        DO.optimizer_update(p, g, m, v, ema, step, cfg)
+        gd = flat(g)
+        ops.sumsq(gd, gn)
+        ops.adam_step_clip_ema(pd, gd, md, vd, ed, n_decay, count, gn, c, 2.0, 0.999, True)
+        torch.cuda.synchronize()
+        if step == 0:
+            assert torch.equal(pd, before)                                  # lr(0) = 0: the first update moves nothing
+        assert rel_err(pd, flat(p)) < 2e-6 and rel_err(ed, flat(ema)) < 2e-6
+    assert count.item() == 7
+
+
 # ----------------------------------------------------------------------------------------------
 # the model
 # ----------------------------------------------------------------------------------------------
@@ -290,6 +326,35 @@ def test_vdvae_train_steps_match_oracle():
             assert e < max(3e-4, 20 * e32) and e < 5e-3, (step, n, e, e32)
             assert rel_err(ed[n], ema[n]) < max(3e-4, 20 * e32), (step, n)
     assert clipped >= 1 and ts.opt_count.item() == 3 and ts.step_dev.item() == 3
+
+
+@pytest.mark.parametrize("size", ["tiny", "reference"])
+def test_vdvae_default_mode_trajectory_within_1e3(size):
+    """Default arithmetic (bf16x3 GEMMs, companion streams, launch-plan replay from step 3): 4 optimizer steps; ELBO
+    (= reconstruction_ll - kl), pm_kl and bpd of every step within 1e-3 relative of the float64 oracle trajectory - at the
+    tiny sizes (B = 4) and at configs/pm_vdvae_mnist.py (7.27 M parameters, B = 2)."""
+    from posterior_matching_amd.engine import VDVAETrainStep
+
+    cfg, B = (TINY, 4) if size == "tiny" else (pm_vdvae_mnist(), 2)
+    m, p64, x, b, eps = _setup(cfg, B, seed=13, bf16x3=True)
+    H = cfg["model"]["image_shape"][0]
+    ts = VDVAETrainStep(m, cfg["lr"], B, gradient_clip=cfg["gradient_clip"], ema_rate=cfg["ema_rate"], external_eps=True)
+    mo, vo = {k: torch.zeros_like(t) for k, t in p64.items()}, {k: torch.zeros_like(t) for k, t in p64.items()}
+    ema = {k: t.clone() for k, t in p64.items()}
+    rng = np.random.default_rng(17)
+    for step in range(4):
+        xb = torch.tensor(np.round(rng.uniform(size=(B, H, H, 1)) * 255.0 * (rng.uniform(size=(B, H, H, 1)) < 0.4)))
+        bb = torch.tensor((rng.uniform(size=(B, H, H, 1)) < 0.5).astype(np.float64))
+        ee = [torch.tensor(rng.normal(size=s)) for s in m.eps_shapes(B)]
+        loss, aux, _ = DO.train_step(p64, mo, vo, ema, cfg, xb, bb, ee, step)
+        ts.set_batch(f32d(xb), f32d(bb), [f32d(e) for e in ee])
+        ts.step()
+        met = ts.read_metrics()
+        elbo = float(aux["reconstruction_ll"] - aux["kl"])
+        assert abs((met["reconstruction_ll"] - met["kl"]) - elbo) <= 1e-3 * abs(elbo), (step, met, elbo)
+        assert abs(met["pm_kl"] - float(aux["pm_kl"])) <= 1e-3 * abs(float(aux["pm_kl"])), (step, met, float(aux["pm_kl"]))
+        assert abs(met["bpd"] - float(aux["bpd"])) <= 1e-3 * abs(float(aux["bpd"])), (step, met)
+    assert ts.step_dev.item() == 4
 
 
 def test_vdvae_reference_config_small_batch():

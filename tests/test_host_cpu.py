@@ -15,12 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_configs_match_reference_values():
     from posterior_matching_amd.config_dict import load_config_file
-    from tests.ref_configs import (pm_vae_gas, pm_vae_mnist, pm_vdvae_mnist, pm_vqvae_celeb_a, pm_vqvae_mnist,
-                                   vqvae_celeb_a, vqvae_mnist)
+    from tests.ref_configs import (pm_vae_gas, pm_vae_miniboone, pm_vae_mnist, pm_vdvae_mnist, pm_vqvae_celeb_a,
+                                   pm_vqvae_mnist, vqvae_celeb_a, vqvae_mnist)
 
     for name, ref in (("pm_vae_mnist", pm_vae_mnist()), ("pm_vae_gas", pm_vae_gas()), ("vqvae_mnist", vqvae_mnist()),
                       ("pm_vqvae_mnist", pm_vqvae_mnist()), ("pm_vdvae_mnist", pm_vdvae_mnist()),
-                      ("vqvae_celeb_a", vqvae_celeb_a()), ("pm_vqvae_celeb_a", pm_vqvae_celeb_a())):
+                      ("vqvae_celeb_a", vqvae_celeb_a()), ("pm_vqvae_celeb_a", pm_vqvae_celeb_a()),
+                      ("pm_vae_miniboone", pm_vae_miniboone())):
         cfg = load_config_file(os.path.join(ROOT, "configs", name + ".py")).to_dict()
         assert cfg == ref, name
 
@@ -236,6 +237,39 @@ loss_full, flat_full = grads(slice(0, G))
 assert torch.allclose(flat, flat_full, rtol=1e-10, atol=1e-14), (flat - flat_full).abs().max()
 m = allreduce_mean_scalars(torch.stack([loss_r]))
 assert torch.allclose(m[0], loss_full, rtol=1e-12)
+
+# bucketed reduction (parallel.GradReducer, the N > 1 path of every train step): modules report in reverse order, weight
+# ranges are reduced as buckets fill, the 1-D suffix and anything unreported at finish(); each element exactly once
+from posterior_matching_amd.parallel import GradReducer
+class FakeStore:
+    device = torch.device("cpu")
+    def __init__(self):
+        specs = [("enc/l0/w", 600), ("enc/l1/w", 500), ("dec/l0/w", 700), ("dec/l1/w", 300), ("extra/w", 50),
+                 ("enc/l0/b", 6), ("enc/l1/b", 5), ("dec/l0/b", 7), ("dec/l1/b", 3)]
+        self.offsets, off = {{}}, 0
+        for n, c in specs:
+            self.offsets[n] = (off, c); off += c
+        self.n_decay = 600 + 500 + 700 + 300 + 50
+        g = torch.Generator().manual_seed(100 + rank)
+        self.flat_g = torch.randn(off, generator=g, dtype=torch.float64)
+both = [torch.randn(2171, generator=torch.Generator().manual_seed(100 + r), dtype=torch.float64) for r in range(world)]
+for overlap in (True, False):
+    st = FakeStore()
+    red = GradReducer(st, bucket_bytes=4 * 900, overlap=overlap)
+    for step in range(2):                                 # two steps: the bookkeeping resets
+        st.flat_g.copy_(both[rank])
+        red.ready(["dec"])                                # 1000 elements >= bucket -> issued at once
+        red.ready(["enc/l1"])                             # 500: pending
+        red.ready(["enc/l0"])                             # adjacent -> merged 1100 -> issued as ONE range
+        red.finish()
+        assert torch.allclose(st.flat_g, both[0] + both[1], rtol=0, atol=0), (overlap, step)
+        assert red.calls_last_step == (3 if overlap else 1), red.calls_last_step
+    try:
+        red.ready(["enc/l0", "dec"])                      # not contiguous: refused
+        assert not overlap
+    except ValueError:
+        assert overlap
+    red.finish()
 dist.barrier()
 if rank == 0:
     print("DP-OK")

@@ -546,3 +546,34 @@ def test_mask_oracle_matches_golden_fixture():
     assert sorted(gold.files) == sorted(now)
     for k in gold.files:
         assert np.array_equal(gold[k], now[k]), k
+
+
+def test_pattern_window_equals_crop_of_pillow_resize():
+    """The oracle's windowed bicubic (RandomPatternMaskGenerator, reference masking.py:192-199 calls PIL.Image.resize with
+    BICUBIC on a float32 noise field) is bit-identical to a crop of Pillow's own full resize of the same Philox noise
+    field - the external pin of the one third-party routine on the mask path - and the CelebA mixture restates
+    masking.py:289-325: 14 components, weights 1/4 x [2,2,2,1,1,1,1]/10, 1/4 x 1/6, 1/2."""
+    import numpy as np
+    from PIL import Image
+
+    from oracle import masking_oracle as MO
+
+    key = MO._key(99)
+    for L, M, epoch in ((120, 2000, 0), (45, 700, 3)):
+        noise = lambda rr, cc: MO.pattern_noise(L, rr, cc, epoch, 1, key)   # noqa: E731
+        low = noise(np.arange(L), np.arange(L))
+        assert low.dtype == np.float32 and 0.0 <= low.min() and low.max() < 1.0 and abs(low.mean() - 0.5) < 0.02
+        full = np.array(Image.fromarray(low).resize((M, M), Image.BICUBIC))
+        for y0, x0, h, w in ((0, 0, 64, 64), (M - 64, M - 64, 64, 64), (M // 3, 7, 32, 48), (5, M - 48, 32, 48)):
+            assert np.array_equal(MO.bicubic_window(noise, L, M, y0, x0, h, w), full[y0:y0 + h, x0:x0 + w]), (L, y0, x0)
+        if epoch:
+            other = MO.pattern_noise(L, np.arange(L), np.arange(L), 0, 1, key)
+            assert not np.array_equal(other, low)
+    comps = MO.celeba_components()
+    w = np.array([c.weight for c in comps])
+    assert len(comps) == 14 and abs(w.sum() - 1.0) < 1e-12
+    assert np.allclose(w[:7], 0.25 * np.array([2, 2, 2, 1, 1, 1, 1]) / 10) and np.allclose(w[7:13], 0.25 / 6) and w[13] == 0.5
+    mask, desc = MO.image_mask_mixture(96, 64, 64, comps, 3)
+    pat = desc[:, 0] == MO.PATTERN
+    assert mask.shape == (96, 64, 64, 1) and set(np.unique(mask)) <= {0.0, 1.0}
+    assert pat.any() and (np.abs((1 - mask[pat]).mean((1, 2, 3)) - 0.25) < 0.05).all()
