@@ -275,3 +275,12 @@ def uniform_mask(B: int, D: int, lo: int, span: int, seed: int, step: int = 0, s
         order = np.lexsort((i, keys))                   # by key, ties by index
         out[b, order[:nobs]] = 1.0
     return out
+
+
+def random_indices(B: int, N: int, seed: int, step: int = 0, stream: int = 0) -> np.ndarray:
+    """pm_random_indices (the shuffle of reference utils.py:43 as sampling with replacement): index i = word i % 4 of the
+    Philox counter (i // 4, 0, step, stream), mapped to [0, N) by multiply-shift"""
+    i = np.arange(B, dtype=np.int64)
+    blocks = philox4x32_10(_counters(i >> 2, 0, step, stream), _key(seed))
+    words = np.take_along_axis(blocks, (i & 3)[:, None], axis=-1)[:, 0]
+    return _rand_below(words, N).astype(np.int32)

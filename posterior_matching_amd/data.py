@@ -78,6 +78,83 @@ class SyntheticDataset:
             i += 1
 
 
+class DeviceUint8Dataset:
+    """A uint8 image array [N, H, W, C] resident in HBM (MNIST 47 MB, CelebA 64x64 2.4 GB of the 288 GB): every yielded
+    batch draws its B row indices from a device Philox stream and gathers + converts the rows in one kernel
+    (pm_random_indices, pm_gather_u8_rows) - the reference's tfds uint8 -> shuffle -> batch -> cast [/ 255] pipeline
+    (utils.py:36-58) with no host work per step and a quarter of the bytes of float32 storage.  Sampling is with
+    replacement (the reference reshuffles a 40 000-element buffer; same marginal distribution).  Batches are dicts like
+    the reference's; masks come from a device generator (one launch) or, without one, are absent (stage-1 VQ-VAE).
+    CelebA inputs must already be cropped / resized to 64 x 64 (utils.py:76-85 does that with tf.image.resize)."""
+
+    def __init__(self, config: Mapping, images, batch_size: int, seed: int = 0, device="cuda:0", normalize_images: bool = True,
+                 training: bool = True):
+        from . import ops  # noqa: F401  (fails loudly without the HIP library)
+
+        images = np.ascontiguousarray(images)
+        if images.dtype != np.uint8:
+            raise TypeError(f"DeviceUint8Dataset holds uint8 pixels, got {images.dtype}")
+        shape = data_shape(config["dataset"])
+        if tuple(images.shape[1:]) != tuple(shape):
+            raise ValueError(f"{config['dataset']} examples are {shape}, the array holds {tuple(images.shape[1:])}")
+        self.device = torch.device(device)
+        self.images = torch.from_numpy(images).to(self.device)
+        self.key, self.batch_size, self.shape, self.seed = "image", batch_size, shape, seed
+        self.scale = 1.0 / 255.0 if normalize_images else 1.0
+        self._step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._idx = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
+        self._x = torch.empty((batch_size,) + shape, dtype=torch.float32, device=self.device)
+        self._mask, self._gen = None, None
+        if config.get("mask_generator") is not None:
+            self._gen = get_mask_generator(config["mask_generator"], device=self.device, seed=seed + 1,
+                                           **config.get("mask_generator_kwargs", {}))
+            self._mask = torch.empty((batch_size,) + shape[:-1] + (1,), dtype=torch.float32, device=self.device)
+        self.sequential = not training          # validation: walk the array in order instead of sampling
+        self._cursor = 0
+
+    def next_batch(self) -> Dict[str, torch.Tensor]:
+        from . import ops
+
+        if self.sequential:
+            n = self.images.shape[0]
+            start = self._cursor if self._cursor + self.batch_size <= n else 0
+            self._cursor = start + self.batch_size
+            ops.gather_u8_rows(self.images[start:start + self.batch_size], None, self._x, self.scale)
+        else:
+            ops.random_indices(self._idx, self.images.shape[0], self.seed, self._step, stream_id=77)
+            ops.gather_u8_rows(self.images, self._idx, self._x, self.scale)
+            ops.counter_increment(self._step)
+        batch = {self.key: self._x}
+        if self._gen is not None:
+            self._gen(self._mask.shape, out=self._mask)
+            batch["mask"] = self._mask
+        return batch
+
+    @property
+    def batches(self):
+        """a few materialised batches (callbacks that index `.batches`, Trainer._validate)"""
+        n = max(1, min(8, self.images.shape[0] // self.batch_size))
+        out = []
+        for _ in range(n):
+            b = self.next_batch()
+            out.append({k: v.clone() for k, v in b.items()})
+        return out
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        while True:
+            yield self.next_batch()
+
+
+def make_dataset(config: Mapping, batch_size: int, num_batches: int, seed: int, device, training: bool = True, arrays=None,
+                 normalize_images: bool = True, device_masks: bool = False):
+    """What the train scripts call: a uint8 image .npy stays in HBM as uint8 (DeviceUint8Dataset); anything else (float
+    arrays, feature tables, no array at all) goes through SyntheticDataset's pre-generated pool."""
+    if arrays is not None and getattr(arrays, "dtype", None) == np.uint8 and arrays.ndim == 4:
+        return DeviceUint8Dataset(config, arrays, batch_size, seed, device, normalize_images, training)
+    return SyntheticDataset(config, batch_size, num_batches, seed, device, training=training, arrays=arrays,
+                            normalize_images=normalize_images, device_masks=device_masks)
+
+
 def load_datasets(config: Mapping, device="cpu", seed: int = 0, num_batches: int = 64):
     """Counterpart of reference utils.py:36-121 for synthetic / .npy data: (train, val)."""
     train = SyntheticDataset(config, config["train_batch_size"], num_batches, seed, device, training=True)

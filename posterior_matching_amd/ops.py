@@ -842,6 +842,21 @@ def uniform_mask(mask, lo: int, span: int, seed: int, step_dev=None, stream_id: 
     _call("pm_uniform_mask", _ptr(mask), B, D, int(lo), int(span), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
 
 
+def random_indices(idx, N: int, seed: int, step_dev=None, stream_id: int = 0) -> None:
+    """idx int32 [B] <- uniform row indices in [0, N) (device Philox; a fresh draw per step)"""
+    _call("pm_random_indices", _iptr(idx), idx.numel(), int(N), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
+
+
+def gather_u8_rows(src_u8, idx, dst, scale: float = 1.0) -> None:
+    """dst [B, ...] f32 <- scale * src_u8[idx] (uint8 dataset resident in HBM; idx None: the first B rows)"""
+    assert src_u8.is_cuda and src_u8.dtype == torch.uint8 and src_u8.is_contiguous()
+    B = dst.shape[0]
+    D = dst.numel() // B
+    assert src_u8.numel() // src_u8.shape[0] == D
+    _call("pm_gather_u8_rows", src_u8.data_ptr(), _iptr(idx), _ptr(dst), B, D, float(scale),
+          work={"bytes": float(B * D * 5)})
+
+
 def gumbel_fill(out, seed: int, step_dev=None, stream_id: int = 0) -> None:
     _call("pm_gumbel_fill", _ptr(out), out.numel(), seed & (2 ** 64 - 1), _iptr(step_dev), stream_id)
 

@@ -183,6 +183,9 @@ class Trainer:
                 ts.set_batch(batch[key].to(dev, non_blocking=True))
             else:
                 ts.set_batch(batch[key].to(dev, non_blocking=True), batch["mask"].to(dev, non_blocking=True))
+            # datasets that refill static device buffers (uint8 gather, device masks) do so on the current stream: it must
+            # not run ahead of the copies set_batch queued on the step's stream (it may overlap the step itself)
+            torch.cuda.current_stream(dev).wait_stream(ts.stream)
             ts.step()
             if validation_freq and ((step + 1) % validation_freq == 0 or step + 1 == steps):
                 logs = dict(ts.read_metrics())

@@ -124,6 +124,75 @@ def test_reference_import_paths_resolve():
         importlib.import_module(mod)
 
 
+def test_checkpoint_importer_renames_haiku_trees():
+    """posterior_matching_amd.checkpoint (the half that needs no jax): haiku-style module paths of the
+    reference (auto-numbered conv2_d / conv2_d_transpose / linear, explicit enc_i / res3x3_i / dec_i, the stage-2 "vqvae/"
+    prefix, the "x_bias_{res}]" typo) map onto this package's parameter names with identical shapes; wrong shapes and
+    missing leaves are refused."""
+    from oracle import pm_vae_oracle as O
+    from oracle import vdvae_oracle as DO
+    from oracle import vqvae_oracle as VO
+    from posterior_matching_amd.checkpoint import haiku_to_native, vq_state_to_native
+    from tests.ref_configs import pm_vae_gas, pm_vae_mnist, pm_vdvae_mnist, vqvae_mnist
+
+    rng = np.random.default_rng(0)
+
+    def fake(shapes, to_haiku):
+        native = {n: rng.normal(size=s).astype(np.float32) for n, s in shapes.items()}
+        tree = {}
+        for n, v in native.items():
+            mod, leaf = to_haiku(n).rsplit("/", 1)
+            tree.setdefault(mod, {})[leaf] = v
+        return native, tree
+
+    def vae_names(n):
+        m = re.match(r"(.*)/conv_t_(\d+)/(w|b)$", n)
+        if m:
+            return f"{m.group(1)}/conv2_d_transpose{'' if m.group(2) == '0' else '_' + m.group(2)}/{m.group(3)}"
+        m = re.match(r"(.*)/conv_(\d+)/(w|b)$", n)
+        if m:
+            return f"{m.group(1)}/conv2_d{'' if m.group(2) == '0' else '_' + m.group(2)}/{m.group(3)}"
+        n = n.replace("/mlp/", "/residual_mlp/").replace("/gmm/", "/one_dimensional_gmm/")
+        m = re.match(r"(.*)/block_(\d+)/linear_(\d)/(w|b)$", n)
+        if m:
+            return f"{m.group(1)}/linear_{1 + 2 * int(m.group(2)) + int(m.group(3))}/{m.group(4)}"
+        return re.sub(r"/linear_0/(w|b)$", r"/linear/\1", n)
+
+    for cfg, xs in ((pm_vae_mnist(), (28, 28, 1)), (pm_vae_gas(), (8,))):
+        shapes = O.param_shapes(cfg["model"], xs)
+        native, tree = fake(shapes, vae_names)
+        assert "encoder_net/conv2_d_1" in tree or "encoder_net/linear_1" in tree
+        got = haiku_to_native(tree, shapes)
+        assert list(got) == list(shapes) and all(np.array_equal(got[n], native[n]) for n in shapes)
+
+    def vq_names(n):
+        n = re.sub(r"^(encoder|decoder)/(res\dx\d_\d+)/", lambda m: f"conv_residual_{m.group(1)}/conv_residual_stack/{m.group(2)}/", n)
+        n = re.sub(r"^(encoder|decoder)/", lambda m: f"conv_residual_{m.group(1)}/", n)
+        return "vqvae/~/" + n if n.count("/") else "vqvae/" + n
+
+    shapes = VO.param_shapes(vqvae_mnist()["model"], 1)
+    native, tree = fake(shapes, vq_names)
+    got = haiku_to_native(tree, shapes)
+    assert all(np.array_equal(got[n], native[n]) for n in shapes)
+
+    shapes = DO.param_shapes(pm_vdvae_mnist()["model"])
+    native, tree = fake(shapes, lambda n: re.sub(r"x_bias_(\d+)$", r"x_bias_\1]", "posterior_matching_vdvae/" + n)
+                        if "x_bias" in n else "posterior_matching_vdvae/" + n)
+    got = haiku_to_native(tree, shapes)
+    assert len(got) == len(shapes) and np.array_equal(got["decoder/x_bias_28"], native["decoder/x_bias_28"])
+
+    bad = dict(tree)
+    first = next(iter(bad))
+    bad[first] = {k: v[..., :-1] for k, v in bad[first].items()}
+    with pytest.raises((KeyError, ValueError)):
+        haiku_to_native(bad, shapes)
+    st = {"vqvae/~/vector_quantizer_ema": {"embeddings": np.zeros((64, 256), np.float32)},
+          "vqvae/~/vector_quantizer_ema/~/ema_cluster_size": {"hidden": np.zeros(256), "average": np.zeros(256), "counter": np.array(7)},
+          "vqvae/~/vector_quantizer_ema/~/ema_dw": {"hidden": np.zeros((64, 256)), "average": np.zeros((64, 256)), "counter": np.array(7)}}
+    vs = vq_state_to_native(st)
+    assert vs["counter"].tolist() == [7] and vs["ema_dw/hidden"].shape == (64, 256)
+
+
 def test_library_exports_every_declared_symbol():
     """the C-ABI library loads (no GPU needed) and exports every function include/pmhip.h declares"""
     from posterior_matching_amd import _lib

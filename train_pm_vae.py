@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from posterior_matching_amd import optim  # noqa: E402
 from posterior_matching_amd.config_dict import apply_overrides, load_config_file  # noqa: E402
-from posterior_matching_amd.data import SyntheticDataset  # noqa: E402
+from posterior_matching_amd.data import make_dataset  # noqa: E402
 from posterior_matching_amd.models.vae import PosteriorMatchingVAE  # noqa: E402
 from posterior_matching_amd.parallel import env_world  # noqa: E402
 from posterior_matching_amd.trainer import (CheckpointCallback, LearningRateLoggerCallback, PMVAELoss,  # noqa: E402
@@ -33,7 +33,8 @@ configure_environment()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
-    ap.add_argument("--data", default=None, help="optional .npy with the training examples")
+    ap.add_argument("--data", default=None, help="optional .npy with the training examples; a uint8 [N,H,W,C] image array stays "
+                                                 "resident in HBM as uint8 and is sampled / converted on the device")
     ap.add_argument("--device_masks", action="store_true",
                     help="draw a fresh mask for every training batch on the GPU (pm_image_mask_mixture & co.) "
                          "instead of cycling host-generated masks")
@@ -50,9 +51,9 @@ def main():
 
     device = torch.device("cuda", local_rank)
     arrays = np.load(args.data) if args.data else None
-    train_dataset = SyntheticDataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
+    train_dataset = make_dataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
                                      training=True, arrays=arrays, device_masks=args.device_masks)
-    val_dataset = SyntheticDataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
+    val_dataset = make_dataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
                                    training=False, arrays=arrays)
     data_key = train_dataset.key
 

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from posterior_matching_amd import optim  # noqa: E402
 from posterior_matching_amd.config_dict import apply_overrides, load_config_file  # noqa: E402
-from posterior_matching_amd.data import SyntheticDataset  # noqa: E402
+from posterior_matching_amd.data import make_dataset  # noqa: E402
 from posterior_matching_amd.models.vdvae import PosteriorMatchingVDVAE  # noqa: E402
 from posterior_matching_amd.parallel import env_world  # noqa: E402
 from posterior_matching_amd.trainer import CheckpointCallback, LearningRateLoggerCallback, Trainer, VDVAELoss  # noqa: E402
@@ -75,10 +75,10 @@ def main():
     device = torch.device("cuda", local_rank)
     arrays = np.load(args.data) if args.data else None
     # load_datasets(config.data, normalize_images=False) (train_pm_vdvae.py:107): raw 0..255 pixel values
-    train_dataset = SyntheticDataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
+    train_dataset = make_dataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
                                      training=True, arrays=arrays, normalize_images=False,
                                      device_masks=args.device_masks)
-    val_dataset = SyntheticDataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
+    val_dataset = make_dataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
                                    training=False, arrays=arrays, normalize_images=False)
 
     model = PosteriorMatchingVDVAE(**config.model, device=device, seed=config.seed)

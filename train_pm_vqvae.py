@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from posterior_matching_amd import optim  # noqa: E402
 from posterior_matching_amd.config_dict import apply_overrides, load_config_file  # noqa: E402
-from posterior_matching_amd.data import SyntheticDataset, data_shape  # noqa: E402
+from posterior_matching_amd.data import data_shape, make_dataset  # noqa: E402
 from posterior_matching_amd.models.vqvae import VQVAE, build_partial_posterior, vqvae_impute  # noqa: E402
 from posterior_matching_amd.parallel import env_world  # noqa: E402
 from posterior_matching_amd.trainer import CheckpointCallback, PMVQVAELoss, Trainer  # noqa: E402
@@ -53,7 +53,8 @@ class ImputationCallback(Callback):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
-    ap.add_argument("--data", default=None, help="optional .npy with the training examples")
+    ap.add_argument("--data", default=None, help="optional .npy with the training examples; a uint8 [N,H,W,C] image array stays "
+                                                 "resident in HBM as uint8 and is sampled / converted on the device")
     ap.add_argument("--device_masks", action="store_true",
                     help="draw a fresh mask for every training batch on the GPU (pm_image_mask_mixture & co.) "
                          "instead of cycling host-generated masks")
@@ -69,9 +70,9 @@ def main():
 
     device = torch.device("cuda", local_rank)
     arrays = np.load(args.data) if args.data else None
-    train_dataset = SyntheticDataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
+    train_dataset = make_dataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
                                      training=True, arrays=arrays, device_masks=args.device_masks)
-    val_dataset = SyntheticDataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
+    val_dataset = make_dataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
                                    training=False, arrays=arrays)
 
     with open(os.path.join(config.vqvae_dir, "model_config.json"), "r") as fp:

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from posterior_matching_amd import optim  # noqa: E402
 from posterior_matching_amd.config_dict import apply_overrides, load_config_file  # noqa: E402
-from posterior_matching_amd.data import SyntheticDataset  # noqa: E402
+from posterior_matching_amd.data import make_dataset  # noqa: E402
 from posterior_matching_amd.models.vqvae import VQVAE  # noqa: E402
 from posterior_matching_amd.parallel import env_world  # noqa: E402
 from posterior_matching_amd.trainer import CheckpointCallback, Trainer, VQVAELoss  # noqa: E402
@@ -50,7 +50,8 @@ class ReconstructionCallback(Callback):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
-    ap.add_argument("--data", default=None, help="optional .npy with the training examples")
+    ap.add_argument("--data", default=None, help="optional .npy with the training examples; a uint8 [N,H,W,C] image array stays "
+                                                 "resident in HBM as uint8 and is sampled / converted on the device")
     args, rest = ap.parse_known_args()
     config = load_config_file(args.config)
     apply_overrides(config, [r[len("--config."):] for r in rest if r.startswith("--config.")])
@@ -64,9 +65,9 @@ def main():
 
     device = torch.device("cuda", local_rank)
     arrays = np.load(args.data) if args.data else None
-    train_dataset = SyntheticDataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
+    train_dataset = make_dataset(config.data, config.data.train_batch_size, 64, config.seed + rank, device,
                                      training=True, arrays=arrays)
-    val_dataset = SyntheticDataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
+    val_dataset = make_dataset(config.data, config.data.val_batch_size, 8, config.seed + 10007 + rank, device,
                                    training=False, arrays=arrays)
 
     model = VQVAE(**config.model, device=device, seed=config.seed)
