@@ -1,0 +1,510 @@
+// A VDVAE bottleneck Block (reference vdvae.py:263-299) as ONE launch forward and ONE launch for its data gradients.
+//
+//   forward :  h1 = c1(xg)   h2 = c2(gelu h1)   h3 = c3(gelu h2)   out = c4(gelu h3) + res       (xg = gelu(x), built by the caller)
+//   backward:  dh3 = (dout W4^T) gelu'(h3)   dh2 = (c3^T dh3) gelu'(h2)   dh1 = (c2^T dh2) gelu'(h1)   dxg = dh1 W1^T [gelu'(x) + res]
+//
+// c1 / c4 are 1x1, c2 / c3 are 3x3 SAME (1x1 at resolutions <= 2), the bottleneck width is `mid` (48 for every reference
+// config) and the step of 1 860 launches was bound by the dependent chain of these tiny GEMMs (15 - 27 us each, one kernel in
+// flight 75 % of the time: DESIGN.md section 6).  Here a workgroup owns a band of R rows of NI images: the `mid`-channel
+// intermediates never leave the CU - they sit in LDS as hi / lo bf16 planes (zero halo columns left and right, zero rows
+// outside the image), the 3x3 taps are shifted 16-byte LDS reads, and the halo rows a band needs from its neighbours are
+// recomputed (1x1 stage on R + 4 rows, first 3x3 on R + 2).  Arithmetic is the engine's bf16x3 (three bf16 MFMA products
+// per operand pair, f32 accumulate) on v_mfma_f32_16x16x32_bf16: 16-column tiles cover mid = 48 exactly.  Weights are
+// the K-contiguous hi / lo copies pm_split_weights already keeps per layer and direction ([plane][tap][32-chunk][npad][32]),
+// read as MFMA B fragments straight from L2, two k-steps ahead.
+// The pre-activations h1..h3 and their gelus g1..g3 (inputs of the weight gradients) are stored exactly as the unfused
+// path stores them, so the weight-gradient launches and every parity test are unchanged.
+#include "pm_common.h"
+
+namespace {
+
+typedef __bf16 vb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float vb_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned vb_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MIDP = 64;         // LDS channels per position: mid padded to whole 32-chunks (zeros past mid)
+constexpr int PS = MIDP + 8;     // bf16 per position incl. 16 B pad: 144-byte pitch, conflict-free 16-byte reads
+constexpr int MAXM = 256;        // positions a workgroup may own per stage (16 m-tiles of 16)
+
+struct BlockArgs {
+    // tensors
+    const float* xin;            // forward: xg [B,H,W,Cin];  backward: dout [B,H,W,Cout]
+    const float* res;            // forward: residual added to out (may be NULL);  backward: added to dxg (may be NULL)
+    const float* xpre;           // backward only: dxg *= gelu'(xpre) (may be NULL)
+    float* hh[3];                // h1, h2, h3 [B,H,W,mid]       (backward: read)
+    float* gg[3];                // forward: g1, g2, g3 written;  backward: dh1, dh2, dh3 written (index = layer - 1)
+    float* out;                  // forward: out [B,H,W,Cout];    backward: dxg [B,H,W,Cin]
+    const __bf16* w[4];          // split weights of c1..c4 for this direction
+    long long plane[4];          // elements between the hi and lo planes of each
+    const float* bias[4];        // forward only
+    int B, H, W, Cin, Cout, mid, k3;   // k3: 3 (3x3 middle convs) or 1
+    int R, NI, bands;            // rows per band, images per workgroup, bands per image
+};
+
+__device__ __forceinline__ void vb_split8(const f32x4& x0, const f32x4& x1, vb_bf16x8& hi, vb_bf16x8& lo) {
+    vb_u32x4 hp, lp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = j < 2 ? x0[2 * j] : x1[2 * j - 4];
+        const float a1 = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(vb_f32x2{a0, a1}, vb_bf16x2));
+        const float f0 = __builtin_bit_cast(float, h << 16);
+        const float f1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        hp[j] = h;
+        lp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(vb_f32x2{a0 - f0, a1 - f1}, vb_bf16x2));
+    }
+    hi = __builtin_bit_cast(vb_bf16x8, hp);
+    lo = __builtin_bit_cast(vb_bf16x8, lp);
+}
+
+__device__ __forceinline__ void vb_store_split(__bf16* hi, __bf16* lo, int off, float v) {
+    const __bf16 h = (__bf16)v;
+    hi[off] = h;
+    lo[off] = (__bf16)(v - (float)h);
+}
+
+// One stage of the chain.  `rows` band rows starting at image row ys (may be negative / past H: those rows are zero),
+// NI images; position p = (img_local * rows + y) * W + x.
+struct Stage {
+    int rows, ys;                // rows of this stage's band, image row of its first row
+};
+
+// ---- shared helpers: a GEMM of M positions x N columns over K, A from global rows (1x1 conv) or from an LDS band ----------
+//   acc[mt][nt] 16x16 tiles: wave w owns m-tiles w, w + NW, ...; every wave computes all n-tiles.
+constexpr int NW = 8;                   // waves per workgroup (512 threads: two per SIMD hide each other's load latency)
+constexpr int NTHR = 64 * NW;
+constexpr int MAXMT = MAXM / 16 / NW;   // m-tiles per wave
+constexpr int MAXNT = 3;                // n-tiles of the mid-wide stages (mid <= 48)
+
+// B fragment of (k-chunk kc, n-tile nt): lane (col = lane & 15, kg = lane >> 4) reads 8 consecutive k
+__device__ __forceinline__ void load_b(const __bf16* w, long long plane, int npad, int kc, int nt, int lane, vb_bf16x8& bh,
+                                        vb_bf16x8& bl) {
+    const size_t o = ((size_t)kc * npad + 16 * nt + (lane & 15)) * 32 + 8 * (lane >> 4);
+    bh = *reinterpret_cast<const vb_bf16x8*>(w + o);
+    bl = *reinterpret_cast<const vb_bf16x8*>(w + plane + o);
+}
+
+__device__ __forceinline__ f32x4 mma3(const vb_bf16x8& ah, const vb_bf16x8& al, const vb_bf16x8& bh, const vb_bf16x8& bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    return c;
+}
+
+// position p of a stage band -> (image, y in image, x) and validity (inside the batch and the image)
+struct Pos {
+    int img, y, x;
+    bool ok;
+};
+__device__ __forceinline__ Pos decode(const BlockArgs& a, int img0, const Stage& s, int p, int M) {
+    Pos r;
+    const int per = s.rows * a.W;
+    const int il = p / per;
+    const int rem = p - il * per;
+    const int yl = rem / a.W;
+    r.x = rem - yl * a.W;
+    r.y = s.ys + yl;
+    r.img = img0 + il;
+    r.ok = p < M && r.img < a.B && r.y >= 0 && r.y < a.H;
+    return r;
+}
+
+// LDS offset (in bf16 elements) of position (il, yl, x) of a band buffer with `rows` rows: [NI][rows][W + 2][PS], x = -1 and x = W are
+// the zero halo columns
+__device__ __forceinline__ int band_off(int il, int yl, int x, int rows, int W) { return ((il * rows + yl) * (W + 2) + x + 1) * PS; }
+
+// ---- 1x1 stage with A from GLOBAL memory: C[p][n] = sum_k A[p][k] W[k][n],  N <= 48 (mid-wide) ------------------------------
+// A rows are [K] floats at ain + ((img*H + y)*W + x) * K; rows outside the image contribute zeros.
+template <int NT>
+__device__ __forceinline__ void gemm_global_mid(const BlockArgs& a, const float* __restrict__ ain, int K, const __bf16* w,
+                                                long long plane, int img0, const Stage& s, int M, int wave, int lane,
+                                                f32x4 (&acc)[MAXMT][NT]) {
+    const int kch = (K + 31) / 32;
+    const int npad = (a.mid + 31) / 32 * 32;               // the split layout pads N to whole 32s
+    const int nmt = (M + 15) / 16;
+    const float* rowp[MAXMT];
+    bool rok[MAXMT];
+#pragma unroll
+    for (int t = 0; t < MAXMT; ++t) {
+        const int mt = wave + NW * t;
+        const Pos q = decode(a, img0, s, mt * 16 + (lane & 15), M);
+        rok[t] = mt < nmt && q.ok;
+        rowp[t] = ain + (rok[t] ? ((size_t)(q.img * a.H + q.y) * a.W + q.x) * K : 0) + 8 * (lane >> 4);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int kg = 8 * (lane >> 4);
+    vb_bf16x8 bh[2][NT], bl[2][NT];
+    f32x4 xa[2][MAXMT][2];                                  // A rows, one k-step ahead
+    auto load_a = [&](int kc, int buf) {
+        const bool kin = 32 * kc + kg + 8 <= K;             // K % 8 == 0: a lane's 8 channels are all inside or all outside
+#pragma unroll
+        for (int t = 0; t < MAXMT; ++t) {
+            xa[buf][t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xa[buf][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rok[t] && kin) {
+                xa[buf][t][0] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc);
+                xa[buf][t][1] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc + 4);
+            }
+        }
+    };
+#pragma unroll
+    for (int n = 0; n < NT; ++n) load_b(w, plane, npad, 0, n, lane, bh[0][n], bl[0][n]);
+    load_a(0, 0);
+    for (int kc = 0; kc < kch; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < kch) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) load_b(w, plane, npad, kc + 1, n, lane, bh[cur ^ 1][n], bl[cur ^ 1][n]);
+            load_a(kc + 1, cur ^ 1);
+        }
+#pragma unroll
+        for (int t = 0; t < MAXMT; ++t) {
+            if (wave + NW * t >= nmt) continue;               // wave-uniform
+            vb_bf16x8 ah, al;
+            vb_split8(xa[cur][t][0], xa[cur][t][1], ah, al);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[cur][n], bl[cur][n], acc[t][n]);
+        }
+    }
+}
+
+// ---- k3 x k3 stage with A from an LDS band: C[p][n] = sum_{tap, c} band[p + tap][c] W[tap][c][n] --------------------------------
+// `sign` = +1 forward (source = p + (tap - centre)), -1 data gradient (source = p - (tap - centre)).
+template <int NT>
+__device__ __forceinline__ void gemm_band_mid(const BlockArgs& a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
+                                              const __bf16* w, long long plane, int img0, const Stage& s, int M, int sign,
+                                              int wave, int lane, f32x4 (&acc)[MAXMT][NT]) {
+    const int npad = (a.mid + 31) / 32 * 32, cch = (a.mid + 31) / 32;   // 32-channel chunks per tap (zero-padded past mid)
+    const int nmt = (M + 15) / 16;
+    const int taps = a.k3 * a.k3, ctr = a.k3 / 2;
+    int base[MAXMT];
+#pragma unroll
+    for (int t = 0; t < MAXMT; ++t) {
+        const int mt = wave + NW * t;
+        int p = mt * 16 + (lane & 15);
+        p = p < M ? p : M - 1;                               // padded slots recompute the last position (never stored)
+        const int per = s.rows * a.W;
+        const int il = p / per, rem = p - il * per;
+        const int yl = rem / a.W, x = rem - yl * a.W;
+        // row of the input band that holds image row (s.ys + yl): yl + (s.ys - in_ys)
+        base[t] = band_off(il, yl + (s.ys - in_ys), x, in_rows, a.W) + 8 * (lane >> 4);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nk = taps * cch;
+    vb_bf16x8 bh[2][NT], bl[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) load_b(w, plane, npad, 0, n, lane, bh[0][n], bl[0][n]);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) load_b(w, plane, npad, ks + 1, n, lane, bh[cur ^ 1][n], bl[cur ^ 1][n]);
+        }
+        const int tap = ks / cch, cc = ks - tap * cch;
+        const int ky = tap / a.k3, kx = tap - ky * a.k3;
+        const int shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
+#pragma unroll
+        for (int t = 0; t < MAXMT; ++t) {
+            if (wave + NW * t >= nmt) continue;
+            const vb_bf16x8 ah = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + shift);
+            const vb_bf16x8 al = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + shift);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[cur][n], bl[cur][n], acc[t][n]);
+        }
+    }
+}
+
+// ---- wide 1x1 stage with A from an LDS band (mid channels) and N = Nout columns in chunks of NT n-tiles: the last layer --------
+// epi(t, e, n, value) is called for every element: row (wave + 4t)*16 + 4*(lane >> 4) + e, column n
+template <typename Epi>
+__device__ __forceinline__ void gemm_band_wide(const BlockArgs& a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
+                                               const __bf16* w, long long plane, int Nout, int img0, const Stage& s, int M,
+                                               int wave, int lane, Epi epi) {
+    const int npad = (Nout + 31) / 32 * 32, cch = (a.mid + 31) / 32;
+    const int nmt = (M + 15) / 16, nnt = (Nout + 15) / 16;
+    int base[MAXMT];
+#pragma unroll
+    for (int t = 0; t < MAXMT; ++t) {
+        const int mt = wave + NW * t;
+        int p = mt * 16 + (lane & 15);
+        p = p < M ? p : M - 1;
+        const int per = s.rows * a.W;
+        const int il = p / per, rem = p - il * per;
+        const int yl = rem / a.W, x = rem - yl * a.W;
+        base[t] = band_off(il, yl + (s.ys - in_ys), x, in_rows, a.W) + 8 * (lane >> 4);
+    }
+    vb_bf16x8 ah[MAXMT][2], al[MAXMT][2];                    // the A fragments (K = 64) are loaded once and reused for every n-tile
+#pragma unroll
+    for (int t = 0; t < MAXMT; ++t)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            ah[t][cc] = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + 32 * cc);
+            al[t][cc] = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + 32 * cc);
+        }
+    vb_bf16x8 bh[2][2], bl[2][2];                            // [buffer][k-chunk]
+    load_b(w, plane, npad, 0, 0, lane, bh[0][0], bl[0][0]);
+    load_b(w, plane, npad, cch - 1, 0, lane, bh[0][1], bl[0][1]);      // cch == 1: the second chunk is never multiplied
+    for (int nt = 0; nt < nnt; ++nt) {
+        const int cur = nt & 1;
+        if (nt + 1 < nnt) {
+            load_b(w, plane, npad, 0, nt + 1, lane, bh[cur ^ 1][0], bl[cur ^ 1][0]);
+            load_b(w, plane, npad, cch - 1, nt + 1, lane, bh[cur ^ 1][1], bl[cur ^ 1][1]);
+        }
+#pragma unroll
+        for (int t = 0; t < MAXMT; ++t) {
+            if (wave + NW * t >= nmt) continue;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+                if (cc < cch) c = mma3(ah[t][cc], al[t][cc], bh[cur][cc], bl[cur][cc], c);
+            const int n = 16 * nt + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) epi(t, e, n, c[e]);
+        }
+    }
+}
+
+// zero the band buffers (halo columns, rows outside the image and the padding channels stay zero afterwards)
+__device__ __forceinline__ void zero_lds(__bf16* base, int elems, int tid) {
+    vb_u32x4 z = {0u, 0u, 0u, 0u};
+    for (int e = tid * 8; e < elems; e += NTHR * 8) *reinterpret_cast<vb_u32x4*>(base + e) = z;
+}
+
+// output row offsets ((img*H + y)*W + x, or -1) of the positions a lane's accumulator rows hold
+__device__ __forceinline__ void row_offsets(const BlockArgs& a, int img0, const Stage& s, int M, int wave, int lane,
+                                            int (&ro)[MAXMT][4], int (&bo)[MAXMT][4], int (&yy)[MAXMT][4]) {
+    const int per = s.rows * a.W;
+#pragma unroll
+    for (int t = 0; t < MAXMT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int p = (wave + NW * t) * 16 + 4 * (lane >> 4) + e;
+            const Pos q = decode(a, img0, s, p, M);
+            ro[t][e] = q.ok ? (q.img * a.H + q.y) * a.W + q.x : -1;
+            yy[t][e] = q.y;
+            const int il = p / per, yl = (p - il * per) / a.W;
+            bo[t][e] = band_off(il, yl, q.x, s.rows, a.W);
+        }
+}
+
+// =================================================== forward ===================================================================
+__global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = a.k3 / 2;                                // 1 for 3x3 middle convs, 0 for 1x1
+    const int band = blockIdx.x % a.bands, img0 = (blockIdx.x / a.bands) * a.NI;
+    const int y0 = band * a.R;
+    const Stage s1{a.R + 4 * halo, y0 - 2 * halo}, s2{a.R + 2 * halo, y0 - halo}, s3{a.R, y0};
+    const int M1 = a.NI * s1.rows * a.W, M2 = a.NI * s2.rows * a.W, M3 = a.NI * s3.rows * a.W;
+    const int e1 = a.NI * s1.rows * (a.W + 2) * PS, e2 = a.NI * s2.rows * (a.W + 2) * PS;
+    // LDS: band 1 (g1, later g3) | band 2 (g2); each hi then lo; one spare position in front for the padded-slot address
+    __bf16* b1h = reinterpret_cast<__bf16*>(smem_raw) + PS;
+    __bf16* b1l = b1h + e1 + PS;
+    __bf16* b2h = b1l + e1 + PS;
+    __bf16* b2l = b2h + e2 + PS;
+    zero_lds(reinterpret_cast<__bf16*>(smem_raw), 2 * (e1 + PS) + 2 * (e2 + PS), tid);
+    __syncthreads();
+
+    f32x4 acc[MAXMT][MAXNT];
+    // ---- stage 1: h1 = c1(xg) on the rows of s1 -> g1 band ----
+    gemm_global_mid<MAXNT>(a, a.xin, a.Cin, a.w[0], a.plane[0], img0, s1, M1, wave, lane, acc);
+    int ro[MAXMT][4], bo[MAXMT][4], yy[MAXMT][4];
+    // (pointers are passed explicitly: indexing the kernel-argument arrays with a runtime layer number would force the whole
+    // argument block into scratch memory)
+    auto epilogue_mid = [&](const Stage& s, int M, const float* __restrict__ biasp, float* __restrict__ hdst,
+                            float* __restrict__ gdst, __bf16* oh, __bf16* ol, int own_lo, int own_hi) {
+        const int nmt = (M + 15) / 16;
+        row_offsets(a, img0, s, M, wave, lane, ro, bo, yy);
+#pragma unroll
+        for (int n = 0; n < MAXNT; ++n) {
+            const int col = 16 * n + (lane & 15);
+            if (col >= a.mid) continue;
+            const float bv = biasp[col];
+#pragma unroll
+            for (int t = 0; t < MAXMT; ++t) {
+                if (wave + NW * t >= nmt) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ro[t][e] < 0) continue;                 // outside the image: the band keeps its zeros (SAME padding)
+                    const float v = acc[t][n][e] + bv;
+                    const float gv = pm_gelu_tanh(v);
+                    vb_store_split(oh, ol, bo[t][e] + col, gv);
+                    if (yy[t][e] >= own_lo && yy[t][e] < own_hi) {   // rows this band owns: stored for the backward pass
+                        const size_t o = (size_t)ro[t][e] * a.mid + col;
+                        hdst[o] = v;
+                        gdst[o] = gv;
+                    }
+                }
+            }
+        }
+    };
+    const int own_hi = y0 + a.R < a.H ? y0 + a.R : a.H;
+    epilogue_mid(s1, M1, a.bias[0], a.hh[0], a.gg[0], b1h, b1l, y0, own_hi);
+    __syncthreads();
+    // ---- stage 2: h2 = c2(g1) on the rows of s2 -> g2 band ----
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, a.w[1], a.plane[1], img0, s2, M2, +1, wave, lane, acc);
+    epilogue_mid(s2, M2, a.bias[1], a.hh[1], a.gg[1], b2h, b2l, y0, own_hi);
+    __syncthreads();
+    // ---- stage 3: h3 = c3(g2) on the owned rows -> g3 into band 1 (g1 is dead) ----
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, a.w[2], a.plane[2], img0, s3, M3, +1, wave, lane, acc);
+    __syncthreads();                                          // every wave is done reading band 1's successor inputs (band 2 only)
+    {   // g3 goes into band 1 laid out with s3's rows; stale g1 there is overwritten or unread (c4 is 1x1: no halo, and
+        // the padding channels mid..63 of every slot were zeroed once and are never written)
+        epilogue_mid(s3, M3, a.bias[2], a.hh[2], a.gg[2], b1h, b1l, y0, own_hi);
+    }
+    __syncthreads();
+    // ---- stage 4: out = c4(g3) + bias + res ----
+    row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
+    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, a.w[3], a.plane[3], a.Cout, img0, s3, M3, wave, lane,
+                   [&](int t, int e, int n, float v) {
+                       if (ro[t][e] < 0 || n >= a.Cout) return;
+                       const size_t o = (size_t)ro[t][e] * a.Cout + n;
+                       v += a.bias[3][n];
+                       if (a.res) v += a.res[o];
+                       a.out[o] = v;
+                   });
+}
+
+// =================================================== backward ==================================================================
+// stage T1: dg3 = dout W4^T on s1 rows (K = Cout from global), dh3 = dg3 * gelu'(h3) -> band 1
+// stage T2: dg2 = c3^T(dh3) on s2 rows, dh2 = dg2 * gelu'(h2) -> band 2
+// stage T3: dg1 = c2^T(dh2) on s3 rows, dh1 = dg1 * gelu'(h1) -> band 1
+// stage T4: dxg = dh1 W1^T (N = Cin) [* gelu'(xpre)] [+ res]
+__global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = a.k3 / 2;
+    const int band = blockIdx.x % a.bands, img0 = (blockIdx.x / a.bands) * a.NI;
+    const int y0 = band * a.R;
+    const Stage s1{a.R + 4 * halo, y0 - 2 * halo}, s2{a.R + 2 * halo, y0 - halo}, s3{a.R, y0};
+    const int M1 = a.NI * s1.rows * a.W, M2 = a.NI * s2.rows * a.W, M3 = a.NI * s3.rows * a.W;
+    const int e1 = a.NI * s1.rows * (a.W + 2) * PS, e2 = a.NI * s2.rows * (a.W + 2) * PS;
+    __bf16* b1h = reinterpret_cast<__bf16*>(smem_raw) + PS;
+    __bf16* b1l = b1h + e1 + PS;
+    __bf16* b2h = b1l + e1 + PS;
+    __bf16* b2l = b2h + e2 + PS;
+    zero_lds(reinterpret_cast<__bf16*>(smem_raw), 2 * (e1 + PS) + 2 * (e2 + PS), tid);
+    __syncthreads();
+
+    f32x4 acc[MAXMT][MAXNT];
+    const int own_hi = y0 + a.R < a.H ? y0 + a.R : a.H;
+    int ro[MAXMT][4], bo[MAXMT][4], yy[MAXMT][4];
+    auto epilogue_mid = [&](const Stage& s, int M, const float* __restrict__ hsrc, float* __restrict__ dhdst, __bf16* oh,
+                            __bf16* ol) {
+        const int nmt = (M + 15) / 16;
+        row_offsets(a, img0, s, M, wave, lane, ro, bo, yy);
+#pragma unroll
+        for (int n = 0; n < MAXNT; ++n) {
+            const int col = 16 * n + (lane & 15);
+            if (col >= a.mid) continue;
+#pragma unroll
+            for (int t = 0; t < MAXMT; ++t) {
+                if (wave + NW * t >= nmt) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ro[t][e] < 0) continue;
+                    const size_t o = (size_t)ro[t][e] * a.mid + col;
+                    const float v = acc[t][n][e] * pm_gelu_tanh_d(hsrc[o]);
+                    vb_store_split(oh, ol, bo[t][e] + col, v);
+                    if (yy[t][e] >= y0 && yy[t][e] < own_hi) dhdst[o] = v;
+                }
+            }
+        }
+    };
+    gemm_global_mid<MAXNT>(a, a.xin, a.Cout, a.w[3], a.plane[3], img0, s1, M1, wave, lane, acc);
+    epilogue_mid(s1, M1, a.hh[2], a.gg[2], b1h, b1l);
+    __syncthreads();
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, a.w[2], a.plane[2], img0, s2, M2, -1, wave, lane, acc);
+    epilogue_mid(s2, M2, a.hh[1], a.gg[1], b2h, b2l);
+    __syncthreads();
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, a.w[1], a.plane[1], img0, s3, M3, -1, wave, lane, acc);
+    __syncthreads();
+    epilogue_mid(s3, M3, a.hh[0], a.gg[0], b1h, b1l);
+    __syncthreads();
+    row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
+    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, a.w[0], a.plane[0], a.Cin, img0, s3, M3, wave, lane,
+                   [&](int t, int e, int n, float v) {
+                       if (ro[t][e] < 0 || n >= a.Cin) return;
+                       const size_t o = (size_t)ro[t][e] * a.Cin + n;
+                       if (a.xpre) v *= pm_gelu_tanh_d(a.xpre[o]);
+                       if (a.res) v += a.res[o];
+                       a.out[o] = v;
+                   });
+}
+
+// band plan: rows per band and images per workgroup so that no stage owns more than MAXM positions and the LDS fits
+struct BandPlan { int R, NI, bands; size_t lds; };
+bool plan_block(int B, int H, int W, int k3, BandPlan& bp) {
+    const int halo = k3 / 2;
+    if (W > 62 || H < 1) return false;
+    int R = H, NI = 1;
+    while (R > 1 && (R + 4 * halo) * W > MAXM) R = (R + 1) / 2;
+    if ((R + 4 * halo) * W > MAXM) return false;
+    // the chain inside a workgroup is serial: prefer many small bands (>= 64 workgroups) while a band keeps >= 3 rows, and
+    // pack whole small images (resolution <= 3) several per workgroup only when the grid stays >= 128 workgroups
+    while (halo > 0 && R > 4 && (long long)B * ((H + R - 1) / R) < 64) R = (R + 1) / 2;
+    if (R == H)
+        while (NI < B && (NI + 1) * (H + 4 * halo) * W <= MAXM && (B + NI) / (NI + 1) >= 128) ++NI;
+    bp.R = R; bp.NI = NI; bp.bands = (H + R - 1) / R;
+    const size_t e1 = (size_t)NI * (R + 4 * halo) * (W + 2) * PS, e2 = (size_t)NI * (R + 2 * halo) * (W + 2) * PS;
+    bp.lds = (2 * (e1 + PS) + 2 * (e2 + PS)) * sizeof(__bf16);
+    return bp.lds <= 150 * 1024;
+}
+
+int launch_block(hipStream_t stream, bool backward, BlockArgs& a) {
+    BandPlan bp;
+    if (!plan_block(a.B, a.H, a.W, a.k3, bp)) return PM_EINVAL;
+    a.R = bp.R; a.NI = bp.NI; a.bands = bp.bands;
+    const unsigned grid = (unsigned)(((a.B + a.NI - 1) / a.NI) * a.bands);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    if (backward) hipLaunchKernelGGL(vdvae_block_bwd_kernel, dim3(grid), dim3(NTHR), bp.lds, stream, a);
+    else hipLaunchKernelGGL(vdvae_block_fwd_kernel, dim3(grid), dim3(NTHR), bp.lds, stream, a);
+    return pm_check_launch(backward ? "pm_vdvae_block_bwd" : "pm_vdvae_block_fwd");
+}
+
+bool block_shape_ok(int B, int H, int W, int Cin, int Cout, int mid, int k3) {
+    return B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && mid % 8 == 0 && mid <= 48 && (k3 == 1 || k3 == 3) &&
+           (long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1LL << 31);
+}
+
+}  // namespace
+
+extern "C" int pm_vdvae_block_fwd(pm_stream_t stream, const float* xg, const float* res, const void* const* wsplit,
+                                  const long long* planes, const float* const* bias, float* const* h, float* const* g, float* out,
+                                  int B, int H, int W, int Cin, int Cout, int mid, int k3) {
+    if (!xg || !wsplit || !planes || !bias || !h || !g || !out || !block_shape_ok(B, H, W, Cin, Cout, mid, k3)) return PM_EINVAL;
+    BlockArgs a;
+    a.xin = xg; a.res = res; a.xpre = nullptr; a.out = out;
+    for (int i = 0; i < 3; ++i) { a.hh[i] = h[i]; a.gg[i] = g[i]; if (!h[i] || !g[i]) return PM_EINVAL; }
+    for (int i = 0; i < 4; ++i) {
+        a.w[i] = reinterpret_cast<const __bf16*>(wsplit[i]); a.plane[i] = planes[i]; a.bias[i] = bias[i];
+        if (!wsplit[i] || !bias[i]) return PM_EINVAL;
+    }
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.mid = mid; a.k3 = k3;
+    PM_KTAG("vdvae_block_fwd_kernel");
+    return launch_block((hipStream_t)stream, false, a);
+}
+
+extern "C" int pm_vdvae_block_bwd(pm_stream_t stream, const float* dout, const float* res, const float* xpre,
+                                  const void* const* wsplit_dgrad, const long long* planes, float* const* h, float* const* dh,
+                                  float* dxg, int B, int H, int W, int Cin, int Cout, int mid, int k3) {
+    if (!dout || !wsplit_dgrad || !planes || !h || !dh || !dxg || !block_shape_ok(B, H, W, Cin, Cout, mid, k3)) return PM_EINVAL;
+    BlockArgs a;
+    a.xin = dout; a.res = res; a.xpre = xpre; a.out = dxg;
+    for (int i = 0; i < 3; ++i) { a.hh[i] = h[i]; a.gg[i] = dh[i]; if (!h[i] || !dh[i]) return PM_EINVAL; }
+    for (int i = 0; i < 4; ++i) {
+        a.w[i] = reinterpret_cast<const __bf16*>(wsplit_dgrad[i]); a.plane[i] = planes[i]; a.bias[i] = nullptr;
+        if (!wsplit_dgrad[i]) return PM_EINVAL;
+    }
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.mid = mid; a.k3 = k3;
+    PM_KTAG("vdvae_block_bwd_kernel");
+    return launch_block((hipStream_t)stream, true, a);
+}

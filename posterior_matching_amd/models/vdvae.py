@@ -73,10 +73,34 @@ class Block(Module):
         ops.layer_forward(L.g, x, self.store.p[L.w], self.store.p[L.b], out, res=res, wsplit=self.store.split_view(L.ws_f),
                           out2=out2, act2=ops.ACT_GELU if out2 is not None else ops.ACT_NONE)
 
+    def _fused(self):
+        """split views (forward, data-gradient) of c1..c4 when the one-launch form applies: default arithmetic (bf16x3),
+        shapes inside pm_vdvae_block_fwd's preconditions; PM_NO_VDVAE_FUSED=1 restores the layer-by-layer path"""
+        import os
+
+        if os.environ.get("PM_NO_VDVAE_FUSED") or not self.store.use_bf16:
+            return None
+        layers = (self.c1, self.c2, self.c3, self.c4)
+        f = [self.store.split_view(L.ws_f) for L in layers]
+        d = [self.store.split_view(L.ws_d) for L in layers]
+        if any(v is None for v in f + d):
+            return None
+        if not ops.vdvae_block_fused_ok(1, self.H, self.W, self.cin, self.cout, self.mid, self.c2.g.k):
+            return None
+        return f, d
+
     def forward(self, xg: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, H, W = xg.shape[0], self.H, self.W
         self._xg = xg
         sh = lambda c: (B, H, W, c)   # noqa: E731
+        fused = self._fused()
+        if fused is not None:            # the four convolutions and the three gelus between them in ONE launch
+            self._h = [self.buf(f"h{i + 1}", sh(self.mid)) for i in range(3)]
+            self._g = [self.buf(f"g{i + 1}", sh(self.mid)) for i in range(3)]
+            out = self.buf("out", sh(self.cout))
+            biases = [self.store.p[L.b] for L in (self.c1, self.c2, self.c3, self.c4)]
+            ops.vdvae_block_fwd(xg, res, fused[0], biases, self._h, self._g, out, self.c2.g.k)
+            return out
         self._h, self._g = [], []
         x = xg
         for i, L in enumerate((self.c1, self.c2, self.c3)):
@@ -99,6 +123,17 @@ class Block(Module):
         sh = lambda c: (B, self.H, self.W, c)   # noqa: E731
         d = dout
         layers = (self.c1, self.c2, self.c3, self.c4)
+        fused = self._fused()
+        if fused is not None:
+            # the four data gradients (with the gelu' factors between them) in ONE launch; the four weight gradients follow:
+            # they read the stored g1..g3 / dh1..dh3 and only feed the optimizer
+            dhs = [self.buf(f"dh{i + 1}", sh(self.mid)) for i in range(3)]
+            ops.vdvae_block_bwd(dout, res if x_pre is not None else None, x_pre, fused[1], self._h, dhs, dx, self.c2.g.k)
+            self.wgrad(self.c4.g, self._g[2], dout, self.store.g[self.c4.w], self.store.g[self.c4.b])
+            self.wgrad(self.c3.g, self._g[1], dhs[2], self.store.g[self.c3.w], self.store.g[self.c3.b])
+            self.wgrad(self.c2.g, self._g[0], dhs[1], self.store.g[self.c2.w], self.store.g[self.c2.b])
+            self.wgrad(self.c1.g, self._xg, dhs[0], self.store.g[self.c1.w], self.store.g[self.c1.b])
+            return
         for i in (3, 2, 1):
             L = layers[i]
             self.wgrad(L.g, self._g[i - 1], d, self.store.g[L.w], self.store.g[L.b])

@@ -918,6 +918,37 @@ def scale_shift(x, a: float, c: float, out) -> None:
     _call("pm_scale_shift", _ptr(x), a, c, _ptr(out), x.numel())
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def vdvae_block_fused_ok(B: int, H: int, W: int, cin: int, cout: int, mid: int, k3: int) -> bool:
+    """preconditions of pm_vdvae_block_fwd / _bwd (include/pmhip.h)"""
+    return cin % 8 == 0 and cout % 8 == 0 and mid % 8 == 0 and mid <= 48 and W <= 62 and k3 in (1, 3)
+
+
+def vdvae_block_fwd(xg, res, wsplits, biases, hs, gs, out, k3: int) -> None:
+    """csrc/pm_vdvae_block.hip: c1..c4 of a Block in one launch (wsplits: the four layers' forward split views)"""
+    B, H, W, cin = xg.shape
+    cout, mid = out.shape[-1], hs[0].shape[-1]
+    planes = (C.c_longlong * 4)(*[w.numel() // 2 for w in wsplits])
+    flops = 2.0 * B * H * W * (cin * mid + 2 * k3 * k3 * mid * mid + mid * cout)
+    _call("pm_vdvae_block_fwd", _ptr(xg), _ptr(res), _ptr_array(wsplits), planes, _ptr_array(biases), _ptr_array(hs),
+          _ptr_array(gs), _ptr(out), B, H, W, cin, cout, mid, k3, tag="vdvae_block_fwd_kernel",
+          work={"flops": flops, "bytes": _nbytes(xg, res, out, *hs, *gs), "detail": f"B{B} {H}x{W} {cin}->{mid}->{cout} k{k3}"})
+
+
+def vdvae_block_bwd(dout, res, xpre, wsplits_d, hs, dhs, dxg, k3: int) -> None:
+    """the four data gradients of a Block in one launch (wsplits_d: the layers' data-gradient split views, c1..c4)"""
+    B, H, W, cout = dout.shape
+    cin, mid = dxg.shape[-1], hs[0].shape[-1]
+    planes = (C.c_longlong * 4)(*[w.numel() // 2 for w in wsplits_d])
+    flops = 2.0 * B * H * W * (cin * mid + 2 * k3 * k3 * mid * mid + mid * cout)
+    _call("pm_vdvae_block_bwd", _ptr(dout), _ptr(res), _ptr(xpre), _ptr_array(wsplits_d), planes, _ptr_array(hs),
+          _ptr_array(dhs), _ptr(dxg), B, H, W, cin, cout, mid, k3, tag="vdvae_block_bwd_kernel",
+          work={"flops": flops, "bytes": _nbytes(dout, res, xpre, dxg, *hs, *dhs), "detail": f"B{B} {H}x{W} {cin}<-{mid}<-{cout} k{k3}"})
+
+
 def diag_sample_kl_fwd(post, prior, eps, z, kl, P: int) -> None:
     Z = eps.shape[-1]
     _call("pm_diag_sample_kl_fwd", _ptr(post), _ptr(prior), prior.shape[-1], _ptr(eps), _ptr(z), _ptr(kl), eps.numel() // Z, Z, P)

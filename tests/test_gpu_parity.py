@@ -382,6 +382,37 @@ def test_model_forward_and_grads(name, B, bf16x3):
             assert e < 1e-2, (n, e, e32)
 
 
+def test_bf16x3_gradients_at_batch_64():
+    """The per-tensor gradient bar of the default arithmetic, justified by measurement (tools/grad_errors.py mnist 64 on
+    MI355X): at B = 64 the STRICT f32 path itself sits at 1e-4 .. 1.5e-3 per tensor against the float64 oracle (d loss / d
+    activations is ill-conditioned: softmax / sigmoid differences), bf16x3 at 6e-5 .. 2.6e-3.  Bars: bf16x3 < 5e-3 per
+    tensor (2x tighter than the B = 6 bar above, where single examples dominate), f32 < 2.5e-3, and bf16x3 never more
+    than 10x the strict path (floor 1e-3)."""
+    cfg, xs, x, b, eps = _inputs("mnist", 64, 5)
+    m = _product_model(cfg, xs)
+    p64 = {n: t.cpu().double() for n, t in m.params_dict().items()}
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, aux, out = O.pm_vae_loss(leaves, cfg, x, b, eps, 0)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    d = dev()
+    errs = {}
+    for use in (False, True):
+        m.store.use_bf16 = use
+        m.store.split_all()
+        got = m(x.float().to(d), b.float().to(d), True, eps=eps.float().to(d))
+        for key in ("reconstruction_ll", "kl", "matching_ll"):
+            assert rel_err(got[key], out[key]) < (1e-4 if use else 1e-5), (use, key)
+        g = [torch.full((64,), v, device=d) for v in (-1.0 / 64, 1.0 / 64, -1.0 / 64)]
+        m.zero_grad()
+        m.backward(*g)
+        torch.cuda.synchronize()
+        gd = m.grads_dict()
+        errs[use] = {n: rel_err(gd[n], grads[n]) for n in grads}
+    for n in grads:
+        assert errs[False][n] < 2.5e-3, (n, errs[False][n])
+        assert errs[True][n] < 5e-3 and errs[True][n] < max(10 * errs[False][n], 1e-3), (n, errs[True][n], errs[False][n])
+
+
 def test_adam_kernel_matches_optax_chain():
     """pm_adam_step vs the oracle's optax restatement on identical (p, g, m, v, count)."""
     from posterior_matching_amd import ops, optim
@@ -740,6 +771,19 @@ def _miniboone(B, seed):
     return cfg, xs, x, b, eps, masks
 
 
+def _tame_tril_heads(m):
+    """A 32-dimensional TriL head on LayerNorm-ed features with randomly perturbed weights has diagonal entries near
+    softplus(-3): the triangular solve of log q(z | x_o) then reaches 1e38 and overflows float32.  Scale the head weights
+    so that the test exercises arithmetic, not overflow."""
+    vals = {}
+    for n, t in m.params_dict().items():
+        if n in ("posterior_dist/linear/w", "partial_posterior_dist/linear/w"):
+            vals[n] = t.cpu() * 0.05
+        elif n in ("posterior_dist/linear/b", "partial_posterior_dist/linear/b"):
+            vals[n] = t.cpu() * 0.2 + 0.5
+    m.load_params(vals)
+
+
 def _set_masks(m, masks):
     for name, net in (("encoder_net", m.encoder_net), ("decoder_net", m.decoder_net),
                       ("partial_encoder_net", m.partial_encoder_net)):
@@ -761,6 +805,7 @@ def test_miniboone_layernorm_dropout_model(bf16x3, training):
     B = 19
     cfg, xs, x, b, eps, masks = _miniboone(B, 5)
     m = _product_model(cfg, xs, bf16x3=bf16x3)
+    _tame_tril_heads(m)
     p64 = {n: t.cpu().double() for n, t in m.params_dict().items()}
     assert list(p64) == list(O.param_shapes(cfg["model"], xs))
     step = 4500                                                      # cyclic beta = 1.0 at 2000 + 2500
@@ -806,6 +851,7 @@ def test_miniboone_train_steps_and_device_dropout():
     B = 32
     cfg, xs, *_ = _miniboone(B, 7)
     m = _product_model(cfg, xs, bf16x3=False)
+    _tame_tril_heads(m)
     p = {n: t.cpu().double() for n, t in m.params_dict().items()}
     mo, vo = {n: torch.zeros_like(t) for n, t in p.items()}, {n: torch.zeros_like(t) for n, t in p.items()}
     opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg["weight_decay"]),

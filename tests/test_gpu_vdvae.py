@@ -253,6 +253,72 @@ def _setup(cfg, B, seed=5, bf16x3=False, perturb=True):
     return m, p64, x, b, eps
 
 
+@pytest.mark.parametrize("B,H,cin,cout,mid,residual", [
+    (3, 28, 192, 192, 48, True),      # encoder / resnet block at the top resolution: 7 bands of 4 rows per image
+    (2, 28, 384, 32, 48, False),      # posterior block (two concatenated sources): 2 Z = 32 outputs
+    (5, 14, 384, 152, 48, False),     # masked posterior: Z + Z(Z+1)/2 = 152 outputs (not a multiple of 32)
+    (4, 14, 192, 224, 48, False),     # prior: 2 Z + width
+    (7, 7, 192, 192, 48, True),
+    (9, 3, 192, 192, 48, True),       # 3x3 grid: every tap but the centre hits padding somewhere
+    (6, 1, 192, 192, 48, True),       # resolution 1: the middle convolutions are 1x1
+    (2, 12, 64, 40, 24, True),        # other widths: mid < 48 leaves an n-tile half empty
+])
+def test_fused_block_matches_oracle_and_layerwise_path(B, H, cin, cout, mid, residual):
+    """pm_vdvae_block_fwd / _bwd (a Block's four convolutions, and its four data gradients, in one launch each with the
+    bottleneck activations in LDS) against the float64 oracle's Block (reference vdvae.py:263-299) and against the
+    layer-by-layer path of the same engine: out, h1..h3, g1..g3, dx, dh1..dh3 within 2e-5 relative (bf16x3 forward
+    values carry 5e-6), all eight weight / bias gradients within 2e-4."""
+    import os
+
+    from posterior_matching_amd import _lib, ops
+    from posterior_matching_amd.models.core import ParamStore, Workspace
+    from posterior_matching_amd.models.vdvae import Block
+
+    _lib.load()
+    store, ws = ParamStore(), Workspace(dev())
+    blk = Block(store, ws, "blk", H, H, cin, mid, cout, H > 2)
+    store.allocate(dev(), 3)
+    gen = torch.Generator().manual_seed(H * 1000 + cin + cout)
+    store.load_dict({n: t.cpu() + 0.05 * torch.randn(t.shape, generator=gen) for n, t in store.to_dict("p").items()})
+    p64 = {n: t.cpu().double() for n, t in store.to_dict("p").items()}
+    x = torch.randn((B, H, H, cin), generator=gen, dtype=F64)
+    dout = torch.randn((B, H, H, cout), generator=gen, dtype=F64)
+    xr = x.clone().requires_grad_(True)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    want = DO.block(leaves, "blk", xr, H > 2, residual and cin == cout)
+    grads = torch.autograd.grad((want * dout).sum(), [xr] + list(leaves.values()))
+    want_dx, want_g = grads[0], dict(zip(leaves, grads[1:]))
+
+    def run():
+        xd = f32d(x)
+        xg = torch.empty_like(xd)
+        ops.gelu_fwd(xd, None, xg)
+        out = blk.forward(xg, res=xd if residual and cin == cout else None).clone()
+        inter = [t.clone() for t in blk._h + blk._g]
+        ops.fill_zero(store.flat_g)
+        dx = torch.empty_like(xd)
+        dd = f32d(dout)
+        blk.backward(dd, dx, x_pre=xd, res=dd if residual and cin == cout else None)
+        torch.cuda.synchronize()
+        dhs = [ws.get(f"blk/dh{i}", (B, H, H, mid)).clone() for i in (1, 2, 3)]
+        return out, inter, dx.clone(), dhs, {n: t.clone() for n, t in store.to_dict("g").items()}
+
+    assert blk._fused() is not None
+    fused = run()
+    os.environ["PM_NO_VDVAE_FUSED"] = "1"
+    try:
+        assert blk._fused() is None
+        plain = run()
+    finally:
+        del os.environ["PM_NO_VDVAE_FUSED"]
+    assert rel_err(fused[0], want) < 2e-5 and rel_err(fused[2], want_dx) < 2e-5
+    assert rel_err(fused[0], plain[0]) < 2e-5 and rel_err(fused[2], plain[2]) < 2e-5
+    for a, b_ in zip(fused[1] + fused[3], plain[1] + plain[3]):
+        assert rel_err(a, b_) < 2e-5
+    for n in want_g:
+        assert rel_err(fused[4][n], want_g[n]) < 2e-4, (n, rel_err(fused[4][n], want_g[n]))
+
+
 def test_vdvae_param_names_and_init_match_oracle():
     cfg = pm_vdvae_mnist()
     m, p64, x, b, eps = _setup(cfg, 1, perturb=False)
