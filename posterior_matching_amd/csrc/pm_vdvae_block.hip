@@ -58,11 +58,28 @@ __device__ __forceinline__ void vb_split8(const f32x4& x0, const f32x4& x1, vb_b
     lo = __builtin_bit_cast(vb_bf16x8, lp);
 }
 
+// jax.nn.gelu(approximate=True) and its derivative through ONE exponential each: tanh(u) = 1 - 2 / (1 + e^(2u)).
+// (tanhf expands to a long polynomial / branch sequence; inlined 72 times it alone overflowed the instruction cache)
+__device__ __forceinline__ float vb_tanh(float u) { return 1.f - 2.f / (1.f + __expf(2.f * u)); }
+__device__ __forceinline__ float vb_gelu(float x) {
+    return 0.5f * x * (1.f + vb_tanh(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float vb_gelu_d(float x) {
+    const float t = vb_tanh(0.7978845608028654f * (x + 0.044715f * x * x * x));
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 0.134145f * x * x);
+}
+
 __device__ __forceinline__ void vb_store_split(__bf16* hi, __bf16* lo, int off, float v) {
     const __bf16 h = (__bf16)v;
     hi[off] = h;
     lo[off] = (__bf16)(v - (float)h);
 }
+
+// the few integers the helpers need, copied out of the kernel-argument block into registers (handing the by-value argument
+// struct itself to the helpers made the compiler spill it to scratch memory: every field read became a private-memory load)
+struct Dims {
+    int B, H, W, mid, k3;
+};
 
 // One stage of the chain.  `rows` band rows starting at image row ys (may be negative / past H: those rows are zero),
 // NI images; position p = (img_local * rows + y) * W + x.
@@ -97,7 +114,7 @@ struct Pos {
     int img, y, x;
     bool ok;
 };
-__device__ __forceinline__ Pos decode(const BlockArgs& a, int img0, const Stage& s, int p, int M) {
+__device__ __forceinline__ Pos decode(const Dims a, int img0, const Stage& s, int p, int M) {
     Pos r;
     const int per = s.rows * a.W;
     const int il = p / per;
@@ -117,7 +134,7 @@ __device__ __forceinline__ int band_off(int il, int yl, int x, int rows, int W) 
 // ---- 1x1 stage with A from GLOBAL memory: C[p][n] = sum_k A[p][k] W[k][n],  N <= 48 (mid-wide) ------------------------------
 // A rows are [K] floats at ain + ((img*H + y)*W + x) * K; rows outside the image contribute zeros.
 template <int NT>
-__device__ __forceinline__ void gemm_global_mid(const BlockArgs& a, const float* __restrict__ ain, int K, const __bf16* w,
+__device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __restrict__ ain, int K, const __bf16* w,
                                                 long long plane, int img0, const Stage& s, int M, int wave, int lane,
                                                 f32x4 (&acc)[MAXMT][NT]) {
     const int kch = (K + 31) / 32;
@@ -135,37 +152,50 @@ __device__ __forceinline__ void gemm_global_mid(const BlockArgs& a, const float*
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int kg = 8 * (lane >> 4);
-    vb_bf16x8 bh[2][NT], bl[2][NT];
-    f32x4 xa[2][MAXMT][2];                                  // A rows, one k-step ahead
-    auto load_a = [&](int kc, int buf) {
+    // two explicit register sets (B fragments and A rows of the next k-step are in flight while the current one is multiplied);
+    // indexing ONE array with kc & 1 would put it in scratch memory
+    vb_bf16x8 bh0[NT], bl0[NT], bh1[NT], bl1[NT];
+    f32x4 xa0[MAXMT][2], xa1[MAXMT][2];
+    auto load_a = [&](int kc, f32x4 (&xa)[MAXMT][2]) {
         const bool kin = 32 * kc + kg + 8 <= K;             // K % 8 == 0: a lane's 8 channels are all inside or all outside
 #pragma unroll
         for (int t = 0; t < MAXMT; ++t) {
-            xa[buf][t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            xa[buf][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xa[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xa[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (rok[t] && kin) {
-                xa[buf][t][0] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc);
-                xa[buf][t][1] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc + 4);
+                xa[t][0] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc);
+                xa[t][1] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc + 4);
             }
         }
     };
+    auto load_bs = [&](int kc, vb_bf16x8 (&bh)[NT], vb_bf16x8 (&bl)[NT]) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) load_b(w, plane, npad, 0, n, lane, bh[0][n], bl[0][n]);
-    load_a(0, 0);
-    for (int kc = 0; kc < kch; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < kch) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) load_b(w, plane, npad, kc + 1, n, lane, bh[cur ^ 1][n], bl[cur ^ 1][n]);
-            load_a(kc + 1, cur ^ 1);
-        }
+        for (int n = 0; n < NT; ++n) load_b(w, plane, npad, kc, n, lane, bh[n], bl[n]);
+    };
+    auto step = [&](const f32x4 (&xa)[MAXMT][2], const vb_bf16x8 (&bh)[NT], const vb_bf16x8 (&bl)[NT]) {
 #pragma unroll
         for (int t = 0; t < MAXMT; ++t) {
-            if (wave + NW * t >= nmt) continue;               // wave-uniform
+            if (wave + NW * t >= nmt) continue;              // wave-uniform
             vb_bf16x8 ah, al;
-            vb_split8(xa[cur][t][0], xa[cur][t][1], ah, al);
+            vb_split8(xa[t][0], xa[t][1], ah, al);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[cur][n], bl[cur][n], acc[t][n]);
+            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[n], bl[n], acc[t][n]);
+        }
+    };
+    load_bs(0, bh0, bl0);
+    load_a(0, xa0);
+    for (int kc = 0; kc < kch; kc += 2) {
+        if (kc + 1 < kch) {
+            load_bs(kc + 1, bh1, bl1);
+            load_a(kc + 1, xa1);
+        }
+        step(xa0, bh0, bl0);
+        if (kc + 1 < kch) {
+            if (kc + 2 < kch) {
+                load_bs(kc + 2, bh0, bl0);
+                load_a(kc + 2, xa0);
+            }
+            step(xa1, bh1, bl1);
         }
     }
 }
@@ -173,7 +203,7 @@ __device__ __forceinline__ void gemm_global_mid(const BlockArgs& a, const float*
 // ---- k3 x k3 stage with A from an LDS band: C[p][n] = sum_{tap, c} band[p + tap][c] W[tap][c][n] --------------------------------
 // `sign` = +1 forward (source = p + (tap - centre)), -1 data gradient (source = p - (tap - centre)).
 template <int NT>
-__device__ __forceinline__ void gemm_band_mid(const BlockArgs& a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
+__device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
                                               const __bf16* w, long long plane, int img0, const Stage& s, int M, int sign,
                                               int wave, int lane, f32x4 (&acc)[MAXMT][NT]) {
     const int npad = (a.mid + 31) / 32 * 32, cch = (a.mid + 31) / 32;   // 32-channel chunks per tap (zero-padded past mid)
@@ -194,15 +224,12 @@ __device__ __forceinline__ void gemm_band_mid(const BlockArgs& a, const __bf16* 
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nk = taps * cch;
-    vb_bf16x8 bh[2][NT], bl[2][NT];
+    vb_bf16x8 bh0[NT], bl0[NT], bh1[NT], bl1[NT];
+    auto load_bs = [&](int ks, vb_bf16x8 (&bh)[NT], vb_bf16x8 (&bl)[NT]) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) load_b(w, plane, npad, 0, n, lane, bh[0][n], bl[0][n]);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) load_b(w, plane, npad, ks + 1, n, lane, bh[cur ^ 1][n], bl[cur ^ 1][n]);
-        }
+        for (int n = 0; n < NT; ++n) load_b(w, plane, npad, ks, n, lane, bh[n], bl[n]);
+    };
+    auto step = [&](int ks, const vb_bf16x8 (&bh)[NT], const vb_bf16x8 (&bl)[NT]) {
         const int tap = ks / cch, cc = ks - tap * cch;
         const int ky = tap / a.k3, kx = tap - ky * a.k3;
         const int shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
@@ -212,7 +239,16 @@ __device__ __forceinline__ void gemm_band_mid(const BlockArgs& a, const __bf16* 
             const vb_bf16x8 ah = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + shift);
             const vb_bf16x8 al = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + shift);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[cur][n], bl[cur][n], acc[t][n]);
+            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[n], bl[n], acc[t][n]);
+        }
+    };
+    load_bs(0, bh0, bl0);
+    for (int ks = 0; ks < nk; ks += 2) {
+        if (ks + 1 < nk) load_bs(ks + 1, bh1, bl1);
+        step(ks, bh0, bl0);
+        if (ks + 1 < nk) {
+            if (ks + 2 < nk) load_bs(ks + 2, bh0, bl0);
+            step(ks + 1, bh1, bl1);
         }
     }
 }
@@ -220,7 +256,7 @@ __device__ __forceinline__ void gemm_band_mid(const BlockArgs& a, const __bf16* 
 // ---- wide 1x1 stage with A from an LDS band (mid channels) and N = Nout columns in chunks of NT n-tiles: the last layer --------
 // epi(t, e, n, value) is called for every element: row (wave + 4t)*16 + 4*(lane >> 4) + e, column n
 template <typename Epi>
-__device__ __forceinline__ void gemm_band_wide(const BlockArgs& a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
+__device__ __forceinline__ void gemm_band_wide(const Dims a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
                                                const __bf16* w, long long plane, int Nout, int img0, const Stage& s, int M,
                                                int wave, int lane, Epi epi) {
     const int npad = (Nout + 31) / 32 * 32, cch = (a.mid + 31) / 32;
@@ -244,25 +280,31 @@ __device__ __forceinline__ void gemm_band_wide(const BlockArgs& a, const __bf16*
             ah[t][cc] = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + 32 * cc);
             al[t][cc] = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + 32 * cc);
         }
-    vb_bf16x8 bh[2][2], bl[2][2];                            // [buffer][k-chunk]
-    load_b(w, plane, npad, 0, 0, lane, bh[0][0], bl[0][0]);
-    load_b(w, plane, npad, cch - 1, 0, lane, bh[0][1], bl[0][1]);      // cch == 1: the second chunk is never multiplied
-    for (int nt = 0; nt < nnt; ++nt) {
-        const int cur = nt & 1;
-        if (nt + 1 < nnt) {
-            load_b(w, plane, npad, 0, nt + 1, lane, bh[cur ^ 1][0], bl[cur ^ 1][0]);
-            load_b(w, plane, npad, cch - 1, nt + 1, lane, bh[cur ^ 1][1], bl[cur ^ 1][1]);
-        }
+    vb_bf16x8 bh0[2], bl0[2], bh1[2], bl1[2];                // two register sets x [k-chunk]
+    auto load_bs = [&](int nt, vb_bf16x8 (&bh)[2], vb_bf16x8 (&bl)[2]) {
+        load_b(w, plane, npad, 0, nt, lane, bh[0], bl[0]);
+        load_b(w, plane, npad, cch - 1, nt, lane, bh[1], bl[1]);   // cch == 1: the second chunk is never multiplied
+    };
+    auto step = [&](int nt, const vb_bf16x8 (&bh)[2], const vb_bf16x8 (&bl)[2]) {
 #pragma unroll
         for (int t = 0; t < MAXMT; ++t) {
             if (wave + NW * t >= nmt) continue;
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
-                if (cc < cch) c = mma3(ah[t][cc], al[t][cc], bh[cur][cc], bl[cur][cc], c);
+                if (cc < cch) c = mma3(ah[t][cc], al[t][cc], bh[cc], bl[cc], c);
             const int n = 16 * nt + (lane & 15);
 #pragma unroll
             for (int e = 0; e < 4; ++e) epi(t, e, n, c[e]);
+        }
+    };
+    load_bs(0, bh0, bl0);
+    for (int nt = 0; nt < nnt; nt += 2) {
+        if (nt + 1 < nnt) load_bs(nt + 1, bh1, bl1);
+        step(nt, bh0, bl0);
+        if (nt + 1 < nnt) {
+            if (nt + 2 < nnt) load_bs(nt + 2, bh0, bl0);
+            step(nt + 1, bh1, bl1);
         }
     }
 }
@@ -274,7 +316,7 @@ __device__ __forceinline__ void zero_lds(__bf16* base, int elems, int tid) {
 }
 
 // output row offsets ((img*H + y)*W + x, or -1) of the positions a lane's accumulator rows hold
-__device__ __forceinline__ void row_offsets(const BlockArgs& a, int img0, const Stage& s, int M, int wave, int lane,
+__device__ __forceinline__ void row_offsets(const Dims a, int img0, const Stage& s, int M, int wave, int lane,
                                             int (&ro)[MAXMT][4], int (&bo)[MAXMT][4], int (&yy)[MAXMT][4]) {
     const int per = s.rows * a.W;
 #pragma unroll
@@ -291,15 +333,26 @@ __device__ __forceinline__ void row_offsets(const BlockArgs& a, int img0, const 
 }
 
 // =================================================== forward ===================================================================
-__global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs a) {
+__global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Dims a{ka.B, ka.H, ka.W, ka.mid, ka.k3};
+    const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
+    const float* __restrict__ xin = ka.xin;
+    const float* __restrict__ resp = ka.res;
+    const float* __restrict__ xpre = ka.xpre;
+    float* __restrict__ outp = ka.out;
+    float* const hh0 = ka.hh[0]; float* const hh1 = ka.hh[1]; float* const hh2 = ka.hh[2];
+    float* const gg0 = ka.gg[0]; float* const gg1 = ka.gg[1]; float* const gg2 = ka.gg[2];
+    const __bf16* const w0 = ka.w[0]; const __bf16* const w1 = ka.w[1]; const __bf16* const w2 = ka.w[2]; const __bf16* const w3 = ka.w[3];
+    const long long pl0 = ka.plane[0], pl1 = ka.plane[1], pl2 = ka.plane[2], pl3 = ka.plane[3];
+    const float* const bs0 = ka.bias[0]; const float* const bs1 = ka.bias[1]; const float* const bs2 = ka.bias[2]; const float* const bs3 = ka.bias[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = a.k3 / 2;                                // 1 for 3x3 middle convs, 0 for 1x1
-    const int band = blockIdx.x % a.bands, img0 = (blockIdx.x / a.bands) * a.NI;
-    const int y0 = band * a.R;
-    const Stage s1{a.R + 4 * halo, y0 - 2 * halo}, s2{a.R + 2 * halo, y0 - halo}, s3{a.R, y0};
-    const int M1 = a.NI * s1.rows * a.W, M2 = a.NI * s2.rows * a.W, M3 = a.NI * s3.rows * a.W;
-    const int e1 = a.NI * s1.rows * (a.W + 2) * PS, e2 = a.NI * s2.rows * (a.W + 2) * PS;
+    const int band = blockIdx.x % abands, img0 = (blockIdx.x / abands) * aNI;
+    const int y0 = band * aR;
+    const Stage s1{aR + 4 * halo, y0 - 2 * halo}, s2{aR + 2 * halo, y0 - halo}, s3{aR, y0};
+    const int M1 = aNI * s1.rows * a.W, M2 = aNI * s2.rows * a.W, M3 = aNI * s3.rows * a.W;
+    const int e1 = aNI * s1.rows * (a.W + 2) * PS, e2 = aNI * s2.rows * (a.W + 2) * PS;
     // LDS: band 1 (g1, later g3) | band 2 (g2); each hi then lo; one spare position in front for the padded-slot address
     __bf16* b1h = reinterpret_cast<__bf16*>(smem_raw) + PS;
     __bf16* b1l = b1h + e1 + PS;
@@ -310,7 +363,7 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs a) {
 
     f32x4 acc[MAXMT][MAXNT];
     // ---- stage 1: h1 = c1(xg) on the rows of s1 -> g1 band ----
-    gemm_global_mid<MAXNT>(a, a.xin, a.Cin, a.w[0], a.plane[0], img0, s1, M1, wave, lane, acc);
+    gemm_global_mid<MAXNT>(a, xin, aCin, w0, pl0, img0, s1, M1, wave, lane, acc);
     int ro[MAXMT][4], bo[MAXMT][4], yy[MAXMT][4];
     // (pointers are passed explicitly: indexing the kernel-argument arrays with a runtime layer number would force the whole
     // argument block into scratch memory)
@@ -330,7 +383,7 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     if (ro[t][e] < 0) continue;                 // outside the image: the band keeps its zeros (SAME padding)
                     const float v = acc[t][n][e] + bv;
-                    const float gv = pm_gelu_tanh(v);
+                    const float gv = vb_gelu(v);
                     vb_store_split(oh, ol, bo[t][e] + col, gv);
                     if (yy[t][e] >= own_lo && yy[t][e] < own_hi) {   // rows this band owns: stored for the backward pass
                         const size_t o = (size_t)ro[t][e] * a.mid + col;
@@ -341,30 +394,30 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs a) {
             }
         }
     };
-    const int own_hi = y0 + a.R < a.H ? y0 + a.R : a.H;
-    epilogue_mid(s1, M1, a.bias[0], a.hh[0], a.gg[0], b1h, b1l, y0, own_hi);
+    const int own_hi = y0 + aR < a.H ? y0 + aR : a.H;
+    epilogue_mid(s1, M1, bs0, hh0, gg0, b1h, b1l, y0, own_hi);
     __syncthreads();
     // ---- stage 2: h2 = c2(g1) on the rows of s2 -> g2 band ----
-    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, a.w[1], a.plane[1], img0, s2, M2, +1, wave, lane, acc);
-    epilogue_mid(s2, M2, a.bias[1], a.hh[1], a.gg[1], b2h, b2l, y0, own_hi);
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w1, pl1, img0, s2, M2, +1, wave, lane, acc);
+    epilogue_mid(s2, M2, bs1, hh1, gg1, b2h, b2l, y0, own_hi);
     __syncthreads();
     // ---- stage 3: h3 = c3(g2) on the owned rows -> g3 into band 1 (g1 is dead) ----
-    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, a.w[2], a.plane[2], img0, s3, M3, +1, wave, lane, acc);
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w2, pl2, img0, s3, M3, +1, wave, lane, acc);
     __syncthreads();                                          // every wave is done reading band 1's successor inputs (band 2 only)
     {   // g3 goes into band 1 laid out with s3's rows; stale g1 there is overwritten or unread (c4 is 1x1: no halo, and
         // the padding channels mid..63 of every slot were zeroed once and are never written)
-        epilogue_mid(s3, M3, a.bias[2], a.hh[2], a.gg[2], b1h, b1l, y0, own_hi);
+        epilogue_mid(s3, M3, bs2, hh2, gg2, b1h, b1l, y0, own_hi);
     }
     __syncthreads();
     // ---- stage 4: out = c4(g3) + bias + res ----
     row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
-    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, a.w[3], a.plane[3], a.Cout, img0, s3, M3, wave, lane,
+    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w3, pl3, aCout, img0, s3, M3, wave, lane,
                    [&](int t, int e, int n, float v) {
-                       if (ro[t][e] < 0 || n >= a.Cout) return;
-                       const size_t o = (size_t)ro[t][e] * a.Cout + n;
-                       v += a.bias[3][n];
-                       if (a.res) v += a.res[o];
-                       a.out[o] = v;
+                       if (ro[t][e] < 0 || n >= aCout) return;
+                       const size_t o = (size_t)ro[t][e] * aCout + n;
+                       v += bs3[n];
+                       if (resp) v += resp[o];
+                       outp[o] = v;
                    });
 }
 
@@ -373,15 +426,26 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs a) {
 // stage T2: dg2 = c3^T(dh3) on s2 rows, dh2 = dg2 * gelu'(h2) -> band 2
 // stage T3: dg1 = c2^T(dh2) on s3 rows, dh1 = dg1 * gelu'(h1) -> band 1
 // stage T4: dxg = dh1 W1^T (N = Cin) [* gelu'(xpre)] [+ res]
-__global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs a) {
+__global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Dims a{ka.B, ka.H, ka.W, ka.mid, ka.k3};
+    const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
+    const float* __restrict__ xin = ka.xin;
+    const float* __restrict__ resp = ka.res;
+    const float* __restrict__ xpre = ka.xpre;
+    float* __restrict__ outp = ka.out;
+    float* const hh0 = ka.hh[0]; float* const hh1 = ka.hh[1]; float* const hh2 = ka.hh[2];
+    float* const gg0 = ka.gg[0]; float* const gg1 = ka.gg[1]; float* const gg2 = ka.gg[2];
+    const __bf16* const w0 = ka.w[0]; const __bf16* const w1 = ka.w[1]; const __bf16* const w2 = ka.w[2]; const __bf16* const w3 = ka.w[3];
+    const long long pl0 = ka.plane[0], pl1 = ka.plane[1], pl2 = ka.plane[2], pl3 = ka.plane[3];
+    const float* const bs0 = ka.bias[0]; const float* const bs1 = ka.bias[1]; const float* const bs2 = ka.bias[2]; const float* const bs3 = ka.bias[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = a.k3 / 2;
-    const int band = blockIdx.x % a.bands, img0 = (blockIdx.x / a.bands) * a.NI;
-    const int y0 = band * a.R;
-    const Stage s1{a.R + 4 * halo, y0 - 2 * halo}, s2{a.R + 2 * halo, y0 - halo}, s3{a.R, y0};
-    const int M1 = a.NI * s1.rows * a.W, M2 = a.NI * s2.rows * a.W, M3 = a.NI * s3.rows * a.W;
-    const int e1 = a.NI * s1.rows * (a.W + 2) * PS, e2 = a.NI * s2.rows * (a.W + 2) * PS;
+    const int band = blockIdx.x % abands, img0 = (blockIdx.x / abands) * aNI;
+    const int y0 = band * aR;
+    const Stage s1{aR + 4 * halo, y0 - 2 * halo}, s2{aR + 2 * halo, y0 - halo}, s3{aR, y0};
+    const int M1 = aNI * s1.rows * a.W, M2 = aNI * s2.rows * a.W, M3 = aNI * s3.rows * a.W;
+    const int e1 = aNI * s1.rows * (a.W + 2) * PS, e2 = aNI * s2.rows * (a.W + 2) * PS;
     __bf16* b1h = reinterpret_cast<__bf16*>(smem_raw) + PS;
     __bf16* b1l = b1h + e1 + PS;
     __bf16* b2h = b1l + e1 + PS;
@@ -390,7 +454,7 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs a) {
     __syncthreads();
 
     f32x4 acc[MAXMT][MAXNT];
-    const int own_hi = y0 + a.R < a.H ? y0 + a.R : a.H;
+    const int own_hi = y0 + aR < a.H ? y0 + aR : a.H;
     int ro[MAXMT][4], bo[MAXMT][4], yy[MAXMT][4];
     auto epilogue_mid = [&](const Stage& s, int M, const float* __restrict__ hsrc, float* __restrict__ dhdst, __bf16* oh,
                             __bf16* ol) {
@@ -407,31 +471,31 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     if (ro[t][e] < 0) continue;
                     const size_t o = (size_t)ro[t][e] * a.mid + col;
-                    const float v = acc[t][n][e] * pm_gelu_tanh_d(hsrc[o]);
+                    const float v = acc[t][n][e] * vb_gelu_d(hsrc[o]);
                     vb_store_split(oh, ol, bo[t][e] + col, v);
                     if (yy[t][e] >= y0 && yy[t][e] < own_hi) dhdst[o] = v;
                 }
             }
         }
     };
-    gemm_global_mid<MAXNT>(a, a.xin, a.Cout, a.w[3], a.plane[3], img0, s1, M1, wave, lane, acc);
-    epilogue_mid(s1, M1, a.hh[2], a.gg[2], b1h, b1l);
+    gemm_global_mid<MAXNT>(a, xin, aCout, w3, pl3, img0, s1, M1, wave, lane, acc);
+    epilogue_mid(s1, M1, hh2, gg2, b1h, b1l);
     __syncthreads();
-    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, a.w[2], a.plane[2], img0, s2, M2, -1, wave, lane, acc);
-    epilogue_mid(s2, M2, a.hh[1], a.gg[1], b2h, b2l);
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w2, pl2, img0, s2, M2, -1, wave, lane, acc);
+    epilogue_mid(s2, M2, hh1, gg1, b2h, b2l);
     __syncthreads();
-    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, a.w[1], a.plane[1], img0, s3, M3, -1, wave, lane, acc);
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w1, pl1, img0, s3, M3, -1, wave, lane, acc);
     __syncthreads();
-    epilogue_mid(s3, M3, a.hh[0], a.gg[0], b1h, b1l);
+    epilogue_mid(s3, M3, hh0, gg0, b1h, b1l);
     __syncthreads();
     row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
-    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, a.w[0], a.plane[0], a.Cin, img0, s3, M3, wave, lane,
+    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w0, pl0, aCin, img0, s3, M3, wave, lane,
                    [&](int t, int e, int n, float v) {
-                       if (ro[t][e] < 0 || n >= a.Cin) return;
-                       const size_t o = (size_t)ro[t][e] * a.Cin + n;
-                       if (a.xpre) v *= pm_gelu_tanh_d(a.xpre[o]);
-                       if (a.res) v += a.res[o];
-                       a.out[o] = v;
+                       if (ro[t][e] < 0 || n >= aCin) return;
+                       const size_t o = (size_t)ro[t][e] * aCin + n;
+                       if (xpre) v *= vb_gelu_d(xpre[o]);
+                       if (resp) v += resp[o];
+                       outp[o] = v;
                    });
 }
 

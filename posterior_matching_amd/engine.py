@@ -426,7 +426,9 @@ class VDVAETrainStep(_PlannedStep):
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         # Weight gradients on companion streams: measured on this chain of ~1 900 tiny launches they do NOT pay (B = 8 / 16:
         # 375 -> 364 / 632 -> 623 img/s; with 8 hardware queues the cross-queue waits triple the step): off unless asked for.
-        model.ws.overlap_wgrad = os.environ.get("PM_VDVAE_WGRAD_STREAMS", "0") != "0"
+        # PM_VDVAE_WGRAD_STREAMS=n: n > 1 = a round-robin pool of n streams for the Blocks' weight gradients
+        n_ws = int(os.environ.get("PM_VDVAE_WGRAD_STREAMS", "0"))
+        model.ws.overlap_wgrad = n_ws if n_ws > 1 else (n_ws == 1)
 
     def _sequence(self) -> None:
         m, s = self.model, self.model.store

@@ -185,6 +185,8 @@ class Workspace:
         self.device = device
         self._bufs: Dict[Tuple[str, Tuple[int, ...]], torch.Tensor] = {}
         self._aux_streams: Dict[int, "torch.cuda.Stream"] = {}
+        self._aux_pool: list = []
+        self._aux_next = -1
         self.overlap_wgrad = False   # measured on MI355X: 4 streams (3.23 ms/step) lose to 2 (2.93 ms/step)
         self.wgrad_stream = None     # set by a model while a chain whose weight gradients should run elsewhere is issued
 
@@ -198,6 +200,12 @@ class Workspace:
             return self.wgrad_stream
         if not self.overlap_wgrad:
             return cur
+        n = int(self.overlap_wgrad) if not isinstance(self.overlap_wgrad, bool) else 1
+        if n > 1:                               # a pool shared by every chain, handed out round-robin (VDVAE: the weight
+            if len(self._aux_pool) < n:         # gradients of several Blocks in flight beside the data-gradient chains)
+                self._aux_pool += [torch.cuda.Stream(device=self.device) for _ in range(n - len(self._aux_pool))]
+            self._aux_next = (self._aux_next + 1) % n
+            return self._aux_pool[self._aux_next]
         aux = self._aux_streams.get(cur.cuda_stream)
         if aux is None:
             aux = torch.cuda.Stream(device=self.device)
@@ -215,7 +223,7 @@ class Workspace:
         runs on several streams)"""
         cur = torch.cuda.current_stream(self.device)
         if self.overlap_wgrad:
-            for aux in self._aux_streams.values():
+            for aux in list(self._aux_streams.values()) + self._aux_pool:
                 ops.wait_stream(cur, aux)
 
     def get(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:

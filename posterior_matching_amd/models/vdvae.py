@@ -129,10 +129,14 @@ class Block(Module):
             # they read the stored g1..g3 / dh1..dh3 and only feed the optimizer
             dhs = [self.buf(f"dh{i + 1}", sh(self.mid)) for i in range(3)]
             ops.vdvae_block_bwd(dout, res if x_pre is not None else None, x_pre, fused[1], self._h, dhs, dx, self.c2.g.k)
-            self.wgrad(self.c4.g, self._g[2], dout, self.store.g[self.c4.w], self.store.g[self.c4.b])
-            self.wgrad(self.c3.g, self._g[1], dhs[2], self.store.g[self.c3.w], self.store.g[self.c3.b])
-            self.wgrad(self.c2.g, self._g[0], dhs[1], self.store.g[self.c2.w], self.store.g[self.c2.b])
-            self.wgrad(self.c1.g, self._xg, dhs[0], self.store.g[self.c1.w], self.store.g[self.c1.b])
+            cur, aux = torch.cuda.current_stream(self.ws.device), self.ws.aux_stream()
+            pairs = ((self.c4, self._g[2], dout), (self.c3, self._g[1], dhs[2]), (self.c2, self._g[0], dhs[1]),
+                     (self.c1, self._xg, dhs[0]))
+            if aux is not cur and aux != cur:
+                ops.wait_stream(aux, cur)           # ONE dependency per Block: its four weight gradients share a stream
+            with torch.cuda.stream(aux):
+                for L, xin, dy in pairs:
+                    ops.layer_wgrad(L.g, xin, dy, self.store.g[L.w], self.store.g[L.b], bf16=self.store.use_bf16)
             return
         for i in (3, 2, 1):
             L = layers[i]
