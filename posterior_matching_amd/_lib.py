@@ -93,6 +93,7 @@ SIGNATURES = {
     "pm_gather_gemm_bf16_dual": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P, _P, _I],
     "pm_split_weights": [_P, _P, _P, _P, _I, _I],
     "pm_gather_wgrad_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
+    "pm_gather_wgrad_table": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _I, _I],
     "pm_thin_conv": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
     "pm_thin_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P],
     "pm_thin_to1_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],

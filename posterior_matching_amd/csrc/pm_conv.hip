@@ -61,7 +61,15 @@ struct WgradArgs {
     int chunks_per_split;
     int step_b, step_p, step_q;  // 128 rows = step_b images + step_p rows + step_q pixels
     int ntiles, nsplits, xcd_map;  // bf16 kernel: (k-block, n-block) tiles x m-splits, see the block-id remap there
+    // optional per-group element offsets (gathered, dense, dw, db) relative to the four base pointers, in DEVICE memory:
+    // groups whose operands are separately allocated buffers (the weight gradients of many same-shaped layers in one launch)
+    const long long* gtab;
 };
+
+// element offset of group `grp`'s operand `which` (0 gathered, 1 dense, 2 dw, 3 db)
+__device__ __forceinline__ long long wg_off(const WgradArgs& p, int grp, int which, long long stride) {
+    return p.gtab ? p.gtab[4 * grp + which] : (long long)grp * stride;
+}
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;  // 144-byte rows: 16-B aligned, ds_read_b128 conflict-free
@@ -1756,8 +1764,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
     const int kk0 = kkb * CB;
     const int n0 = nb * NB;
     const int grp = blockIdx.z;
-    const float* gin = p.gathered + (size_t)grp * p.in_gs;
-    const float* din = p.dense + (size_t)grp * p.out_gs;
+    const float* gin = p.gathered + wg_off(p, grp, 0, p.in_gs);
+    const float* din = p.dense + wg_off(p, grp, 1, p.out_gs);
     const bool do_bias = (p.db != nullptr) && (kkb == 0);
     // tap-uniform modes: this block's tap and first channel
     const int tap_u = kk0 / g.C;
@@ -1890,7 +1898,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
                 red[wave * CB * NB + cl * NB + nl] = acc[a][b][e];
             }
     __syncthreads();
-    float* dw = p.dw + (size_t)grp * p.w_gs;
+    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
     for (int e = tid; e < CB * NB; e += 256) {
         int cl = e / NB;
         int nl = e - cl * NB;
@@ -1905,7 +1913,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
         }
     }
     if (do_bias && h == 0) {
-        float* db = p.db + (size_t)grp * p.bias_gs;
+        float* db = p.db + wg_off(p, grp, 3, p.bias_gs);
 #pragma unroll
         for (int b = 0; b < RN; ++b) {
             int n = n0 + b * 32 + i;
@@ -1974,8 +1982,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
     const int kk0 = kkb * CB;
     const int n0 = nb * NB;
     const int grp = blockIdx.z;
-    const float* gin = p.gathered + (size_t)grp * p.in_gs;
-    const float* din = p.dense + (size_t)grp * p.out_gs;
+    const float* gin = p.gathered + wg_off(p, grp, 0, p.in_gs);
+    const float* din = p.dense + wg_off(p, grp, 1, p.out_gs);
     const bool do_bias = (p.db != nullptr) && (kkb == 0);
     const int tap_u = kk0 / g.C;
     const int c_u = kk0 - tap_u * g.C;
@@ -2110,7 +2118,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
                 red[wave * CB * NB + cl * NB + nl] = acc[a][b][e];
             }
     __syncthreads();
-    float* dw = p.dw + (size_t)grp * p.w_gs;
+    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
     for (int e = tid; e < CB * NB; e += 256) {
         int cl = e / NB;
         int nl = e - cl * NB;
@@ -2125,7 +2133,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
         }
     }
     if (do_bias && h == 0) {
-        float* db = p.db + (size_t)grp * p.bias_gs;
+        float* db = p.db + wg_off(p, grp, 3, p.bias_gs);
 #pragma unroll
         for (int b = 0; b < RN; ++b) {
             int n = n0 + b * 32 + i;
@@ -2165,8 +2173,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     const int kk0 = kkb * CB;
     const int n0 = nb * NB;
     const int grp = blockIdx.z;
-    const float* gin = p.gathered + (size_t)grp * p.in_gs;
-    const float* din = p.dense + (size_t)grp * p.out_gs;
+    const float* gin = p.gathered + wg_off(p, grp, 0, p.in_gs);
+    const float* din = p.dense + wg_off(p, grp, 1, p.out_gs);
     const bool do_bias = (p.db != nullptr) && (kkb == 0) && (wc == 0);
     const int tap_u = kk0 / g.C;
     const int c_u = kk0 - tap_u * g.C;
@@ -2259,7 +2267,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     }
 
     // flush straight from the C/D layout: col = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * h (k index)
-    float* dw = p.dw + (size_t)grp * p.w_gs;
+    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
     const int n = n0 + 32 * wn + i;
     if (n < g.N) {
 #pragma unroll
@@ -2271,7 +2279,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
             const int wtap = (tap / g.KW) * g.kws + tap % g.KW;
             atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[e]);
         }
-        if (do_bias && h == 0) atomicAdd(p.db + (size_t)grp * p.bias_gs + n, accb[0]);
+        if (do_bias && h == 0) atomicAdd(p.db + wg_off(p, grp, 3, p.bias_gs) + n, accb[0]);
     }
 }
 
@@ -2656,14 +2664,14 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
     return pm_check_launch("pm_gather_gemm");
 }
 
-extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, const float* gathered,
-                               const float* dense, float* dw, float* db) {
+static int gather_wgrad_impl(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
+                             float* dw, float* db, const long long* gtab, bool tab_aligned) {
     WgradArgs a;
     if (!fill_geom(d, a.g, false) || !gathered || !dense || !dw) return PM_EINVAL;
-    a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db;
+    a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db; a.gtab = gtab;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
-    const bool vec4 = (d->C % 4 == 0) && aligned16(gathered) && (d->in_gs % 4 == 0);
-    const bool dvec4 = (d->N % 4 == 0) && aligned16(dense) && (d->out_gs % 4 == 0);
+    const bool vec4 = (d->C % 4 == 0) && aligned16(gathered) && (gtab ? tab_aligned : d->in_gs % 4 == 0);
+    const bool dvec4 = (d->N % 4 == 0) && aligned16(dense) && (gtab ? tab_aligned : d->out_gs % 4 == 0);
     const WgradPlan p = plan_wgrad(a.g, d->groups, vec4, dvec4);
     a.chunks_per_split = p.chunks_per_split;
     const int hw = a.g.OH * a.g.OW;
@@ -2677,6 +2685,11 @@ extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, cons
     else if (p.rn == 2) launch_wgrad<1, 2>(s, a, grid, p.mode, dvec4);
     else launch_wgrad<1, 1>(s, a, grid, p.mode, dvec4);
     return pm_check_launch("pm_gather_wgrad");
+}
+
+extern "C" int pm_gather_wgrad(pm_stream_t stream, const pm_gather_desc* d, const float* gathered,
+                               const float* dense, float* dw, float* db) {
+    return gather_wgrad_impl(stream, d, gathered, dense, dw, db, nullptr, false);
 }
 
 // Which kernel instantiation a problem dispatches to (bench.py names its roofline row with it).
@@ -2802,13 +2815,14 @@ extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* o
     return pm_check_launch("pm_split_weights");
 }
 
-extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d, const float* gathered,
-                                    const float* dense, float* dw, float* db) {
+static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
+                                  float* dw, float* db, const long long* gtab, bool tab_aligned) {
     WgradArgs a;
     if (!fill_geom(d, a.g, false) || !gathered || !dense || !dw) return PM_EINVAL;
     if (d->C % 32 != 0 || d->N % 4 != 0 || (d->d != 1 && d->d != 2)) return PM_EINVAL;
-    if (!aligned16(gathered) || !aligned16(dense) || d->in_gs % 4 != 0 || d->out_gs % 4 != 0) return PM_EINVAL;
-    a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db;
+    if (!aligned16(gathered) || !aligned16(dense)) return PM_EINVAL;
+    if (gtab ? !tab_aligned : (d->in_gs % 4 != 0 || d->out_gs % 4 != 0)) return PM_EINVAL;
+    a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db; a.gtab = gtab;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     {   // stride-1 problems with 32 gathered channels on grids >= 12 wide: patch-staged persistent form
         static const bool patch_off = getenv("PM_NO_PATCH_WGRAD") != nullptr;
@@ -2889,4 +2903,18 @@ extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d,
     else PM_WB(1, 1);
 #undef PM_WB
     return pm_check_launch("pm_gather_wgrad_bf16");
+}
+
+extern "C" int pm_gather_wgrad_bf16(pm_stream_t stream, const pm_gather_desc* d, const float* gathered,
+                                    const float* dense, float* dw, float* db) {
+    return gather_wgrad_bf16_impl(stream, d, gathered, dense, dw, db, nullptr, false);
+}
+
+// d->groups weight gradients of ONE geometry whose operands are separately allocated: group g reads gathered + table[4g],
+// dense + table[4g+1] and accumulates into dw + table[4g+2] (and db + table[4g+3]); table lives in device memory.
+extern "C" int pm_gather_wgrad_table(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
+                                     float* dw, float* db, const long long* table, int all_aligned16, int use_bf16) {
+    if (!table || d->groups < 1) return PM_EINVAL;
+    if (use_bf16) return gather_wgrad_bf16_impl(stream, d, gathered, dense, dw, db, table, all_aligned16 != 0);
+    return gather_wgrad_impl(stream, d, gathered, dense, dw, db, table, all_aligned16 != 0);
 }

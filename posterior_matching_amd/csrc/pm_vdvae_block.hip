@@ -131,12 +131,57 @@ __device__ __forceinline__ Pos decode(const Dims a, int img0, const Stage& s, in
 // the zero halo columns
 __device__ __forceinline__ int band_off(int il, int yl, int x, int rows, int W) { return ((il * rows + yl) * (W + 2) + x + 1) * PS; }
 
+// ---- the weight feeder --------------------------------------------------------------------------------------------------
+// Every wave of the workgroup multiplies by the SAME B block in a k-step, so the block (<= 8 KB: [2 planes][<= 64 columns][32 k])
+// is brought in ONCE by all 512 threads (16 bytes each) instead of by every wave for itself, through a two-slot LDS ring;
+// each thread keeps the pieces of the next PD k-steps in registers (4 VGPRs per k-step), so the L2 round trip (~1 us) of a
+// k-step is covered by the PD - 1 steps in front of it.  One workgroup barrier per k-step: slot (ks & 1) is rewritten
+// only after every wave has passed the barrier of step ks - 1, i.e. has finished multiplying step ks - 2.
+constexpr int PD = 6;            // k-steps of weights in flight per thread
+constexpr int BROWP = 40;        // ring row: 32 bf16 + 16 B pad (80-byte pitch: conflict-free 16-byte fragment reads)
+constexpr int RING_SLOT = 2 * 64 * BROWP;   // bf16 elements of one slot (2 planes x 64 columns)
+
+struct Feeder {
+    const __bf16* w;             // split weights of the stage
+    long long plane;
+    int npad;                    // columns per k-chunk in the global layout
+    int ncols;                   // columns brought in per step (<= 64)
+    int pc_plane, pc_n, pc_q;    // this thread's piece: plane, column, 16-byte quarter of the 32-k row (pc_plane < 0: idle)
+};
+
+__device__ __forceinline__ Feeder make_feeder(const __bf16* w, long long plane, int npad, int ncols, int tid) {
+    Feeder f{w, plane, npad, ncols, -1, 0, 0};
+    if (tid < 2 * ncols * 4) {
+        f.pc_plane = tid / (ncols * 4);
+        f.pc_n = (tid >> 2) % ncols;
+        f.pc_q = tid & 3;
+    }
+    return f;
+}
+// piece of (k-chunk kc, first column n0) -> registers
+__device__ __forceinline__ vb_u32x4 feed_load(const Feeder& f, int kc, int n0) {
+    vb_u32x4 v = {0u, 0u, 0u, 0u};
+    if (f.pc_plane >= 0)
+        v = *reinterpret_cast<const vb_u32x4*>(f.w + (size_t)f.pc_plane * f.plane + ((size_t)kc * f.npad + n0 + f.pc_n) * 32 + 8 * f.pc_q);
+    return v;
+}
+__device__ __forceinline__ void feed_store(const Feeder& f, __bf16* slot, const vb_u32x4& v) {
+    if (f.pc_plane >= 0) *reinterpret_cast<vb_u32x4*>(slot + (f.pc_plane * 64 + f.pc_n) * BROWP + 8 * f.pc_q) = v;
+}
+// B fragment of n-tile nt from a ring slot
+__device__ __forceinline__ void ring_b(const __bf16* slot, int nt, int lane, vb_bf16x8& bh, vb_bf16x8& bl) {
+    const int o = (16 * nt + (lane & 15)) * BROWP + 8 * (lane >> 4);
+    bh = *reinterpret_cast<const vb_bf16x8*>(slot + o);
+    bl = *reinterpret_cast<const vb_bf16x8*>(slot + 64 * BROWP + o);
+}
+
 // ---- 1x1 stage with A from GLOBAL memory: C[p][n] = sum_k A[p][k] W[k][n],  N <= 48 (mid-wide) ------------------------------
-// A rows are [K] floats at ain + ((img*H + y)*W + x) * K; rows outside the image contribute zeros.
+// A rows are [K] floats at ain + ((img*H + y)*W + x) * K; rows outside the image contribute zeros.  A rows are prefetched three
+// k-steps ahead in registers (each wave reads its own rows).
 template <int NT>
 __device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __restrict__ ain, int K, const __bf16* w,
-                                                long long plane, int img0, const Stage& s, int M, int wave, int lane,
-                                                f32x4 (&acc)[MAXMT][NT]) {
+                                                long long plane, __bf16* ring, int img0, const Stage& s, int M, int wave, int lane,
+                                                int tid, f32x4 (&acc)[MAXMT][NT]) {
     const int kch = (K + 31) / 32;
     const int npad = (a.mid + 31) / 32 * 32;               // the split layout pads N to whole 32s
     const int nmt = (M + 15) / 16;
@@ -152,60 +197,59 @@ __device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __res
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int kg = 8 * (lane >> 4);
-    // two explicit register sets (B fragments and A rows of the next k-step are in flight while the current one is multiplied);
-    // indexing ONE array with kc & 1 would put it in scratch memory
-    vb_bf16x8 bh0[NT], bl0[NT], bh1[NT], bl1[NT];
-    f32x4 xa0[MAXMT][2], xa1[MAXMT][2];
-    auto load_a = [&](int kc, f32x4 (&xa)[MAXMT][2]) {
-        const bool kin = 32 * kc + kg + 8 <= K;             // K % 8 == 0: a lane's 8 channels are all inside or all outside
+    const Feeder fd = make_feeder(w, plane, npad, npad, tid);
+    vb_u32x4 pre[PD];
+    f32x4 xa[3][MAXMT][2];                                  // A rows of k-steps ks, ks + 1, ks + 2 (static indices below)
+    auto load_a = [&](int kc, f32x4 (&x)[MAXMT][2]) {
+        const bool kin = kc < kch && 32 * kc + kg + 8 <= K;  // K % 8 == 0: a lane's 8 channels are all inside or all outside
 #pragma unroll
         for (int t = 0; t < MAXMT; ++t) {
-            xa[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            xa[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            x[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            x[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (rok[t] && kin) {
-                xa[t][0] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc);
-                xa[t][1] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc + 4);
+                x[t][0] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc);
+                x[t][1] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc + 4);
             }
         }
     };
-    auto load_bs = [&](int kc, vb_bf16x8 (&bh)[NT], vb_bf16x8 (&bl)[NT]) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) load_b(w, plane, npad, kc, n, lane, bh[n], bl[n]);
-    };
-    auto step = [&](const f32x4 (&xa)[MAXMT][2], const vb_bf16x8 (&bh)[NT], const vb_bf16x8 (&bl)[NT]) {
+    for (int j = 0; j < PD; ++j) pre[j] = j < kch ? feed_load(fd, j, 0) : vb_u32x4{0u, 0u, 0u, 0u};
+    load_a(0, xa[0]);
+    load_a(1, xa[1]);
+    load_a(2, xa[2]);
+    for (int ks0 = 0; ks0 < kch; ks0 += PD) {
 #pragma unroll
-        for (int t = 0; t < MAXMT; ++t) {
-            if (wave + NW * t >= nmt) continue;              // wave-uniform
-            vb_bf16x8 ah, al;
-            vb_split8(xa[t][0], xa[t][1], ah, al);
+        for (int j = 0; j < PD; ++j) {
+            const int ks = ks0 + j;
+            if (ks >= kch) break;
+            __bf16* slot = ring + (ks & 1) * RING_SLOT;
+            feed_store(fd, slot, pre[j]);
+            if (ks + PD < kch) pre[j] = feed_load(fd, ks + PD, 0);
+            __syncthreads();
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[n], bl[n], acc[t][n]);
-        }
-    };
-    load_bs(0, bh0, bl0);
-    load_a(0, xa0);
-    for (int kc = 0; kc < kch; kc += 2) {
-        if (kc + 1 < kch) {
-            load_bs(kc + 1, bh1, bl1);
-            load_a(kc + 1, xa1);
-        }
-        step(xa0, bh0, bl0);
-        if (kc + 1 < kch) {
-            if (kc + 2 < kch) {
-                load_bs(kc + 2, bh0, bl0);
-                load_a(kc + 2, xa0);
+            for (int t = 0; t < MAXMT; ++t) {
+                if (wave + NW * t >= nmt) continue;          // wave-uniform
+                vb_bf16x8 ah, al;
+                vb_split8(xa[j % 3][t][0], xa[j % 3][t][1], ah, al);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    vb_bf16x8 bh, bl;
+                    ring_b(slot, n, lane, bh, bl);
+                    acc[t][n] = mma3(ah, al, bh, bl, acc[t][n]);
+                }
             }
-            step(xa1, bh1, bl1);
+            load_a(ks + 3, xa[j % 3]);                       // refill the set just consumed
         }
     }
+    __syncthreads();                                        // the ring is free for the next stage
 }
 
 // ---- k3 x k3 stage with A from an LDS band: C[p][n] = sum_{tap, c} band[p + tap][c] W[tap][c][n] --------------------------------
 // `sign` = +1 forward (source = p + (tap - centre)), -1 data gradient (source = p - (tap - centre)).
 template <int NT>
 __device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
-                                              const __bf16* w, long long plane, int img0, const Stage& s, int M, int sign,
-                                              int wave, int lane, f32x4 (&acc)[MAXMT][NT]) {
+                                              const __bf16* w, long long plane, __bf16* ring, int img0, const Stage& s, int M,
+                                              int sign, int wave, int lane, int tid, f32x4 (&acc)[MAXMT][NT]) {
     const int npad = (a.mid + 31) / 32 * 32, cch = (a.mid + 31) / 32;   // 32-channel chunks per tap (zero-padded past mid)
     const int nmt = (M + 15) / 16;
     const int taps = a.k3 * a.k3, ctr = a.k3 / 2;
@@ -224,43 +268,47 @@ __device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, c
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nk = taps * cch;
-    vb_bf16x8 bh0[NT], bl0[NT], bh1[NT], bl1[NT];
-    auto load_bs = [&](int ks, vb_bf16x8 (&bh)[NT], vb_bf16x8 (&bl)[NT]) {
+    const Feeder fd = make_feeder(w, plane, npad, npad, tid);
+    vb_u32x4 pre[PD];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) load_b(w, plane, npad, ks, n, lane, bh[n], bl[n]);
-    };
-    auto step = [&](int ks, const vb_bf16x8 (&bh)[NT], const vb_bf16x8 (&bl)[NT]) {
-        const int tap = ks / cch, cc = ks - tap * cch;
-        const int ky = tap / a.k3, kx = tap - ky * a.k3;
-        const int shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
+    for (int j = 0; j < PD; ++j) pre[j] = j < nk ? feed_load(fd, j, 0) : vb_u32x4{0u, 0u, 0u, 0u};
+    for (int ks0 = 0; ks0 < nk; ks0 += PD) {
 #pragma unroll
-        for (int t = 0; t < MAXMT; ++t) {
-            if (wave + NW * t >= nmt) continue;
-            const vb_bf16x8 ah = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + shift);
-            const vb_bf16x8 al = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + shift);
+        for (int j = 0; j < PD; ++j) {
+            const int ks = ks0 + j;
+            if (ks >= nk) break;
+            __bf16* slot = ring + (ks & 1) * RING_SLOT;
+            feed_store(fd, slot, pre[j]);
+            if (ks + PD < nk) pre[j] = feed_load(fd, ks + PD, 0);
+            __syncthreads();
+            const int tap = ks / cch, cc = ks - tap * cch;
+            const int ky = tap / a.k3, kx = tap - ky * a.k3;
+            const int shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[t][n] = mma3(ah, al, bh[n], bl[n], acc[t][n]);
-        }
-    };
-    load_bs(0, bh0, bl0);
-    for (int ks = 0; ks < nk; ks += 2) {
-        if (ks + 1 < nk) load_bs(ks + 1, bh1, bl1);
-        step(ks, bh0, bl0);
-        if (ks + 1 < nk) {
-            if (ks + 2 < nk) load_bs(ks + 2, bh0, bl0);
-            step(ks + 1, bh1, bl1);
+            for (int t = 0; t < MAXMT; ++t) {
+                if (wave + NW * t >= nmt) continue;
+                const vb_bf16x8 ah = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + shift);
+                const vb_bf16x8 al = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + shift);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    vb_bf16x8 bh, bl;
+                    ring_b(slot, n, lane, bh, bl);
+                    acc[t][n] = mma3(ah, al, bh, bl, acc[t][n]);
+                }
+            }
         }
     }
+    __syncthreads();
 }
 
-// ---- wide 1x1 stage with A from an LDS band (mid channels) and N = Nout columns in chunks of NT n-tiles: the last layer --------
-// epi(t, e, n, value) is called for every element: row (wave + 4t)*16 + 4*(lane >> 4) + e, column n
+// ---- wide 1x1 stage with A from an LDS band (mid channels) and N = Nout columns, 32 columns (two n-tiles) per step: the last layer --------
+// epi(t, e, n, value) is called for every element: row (wave + NW t)*16 + 4*(lane >> 4) + e, column n
 template <typename Epi>
 __device__ __forceinline__ void gemm_band_wide(const Dims a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
-                                               const __bf16* w, long long plane, int Nout, int img0, const Stage& s, int M,
-                                               int wave, int lane, Epi epi) {
+                                               const __bf16* w, long long plane, __bf16* ring, int Nout, int img0, const Stage& s,
+                                               int M, int wave, int lane, int tid, Epi epi) {
     const int npad = (Nout + 31) / 32 * 32, cch = (a.mid + 31) / 32;
-    const int nmt = (M + 15) / 16, nnt = (Nout + 15) / 16;
+    const int nmt = (M + 15) / 16, nsteps = npad / 32;       // 32 columns per step
     int base[MAXMT];
 #pragma unroll
     for (int t = 0; t < MAXMT; ++t) {
@@ -272,7 +320,7 @@ __device__ __forceinline__ void gemm_band_wide(const Dims a, const __bf16* bh_, 
         const int yl = rem / a.W, x = rem - yl * a.W;
         base[t] = band_off(il, yl + (s.ys - in_ys), x, in_rows, a.W) + 8 * (lane >> 4);
     }
-    vb_bf16x8 ah[MAXMT][2], al[MAXMT][2];                    // the A fragments (K = 64) are loaded once and reused for every n-tile
+    vb_bf16x8 ah[MAXMT][2], al[MAXMT][2];                    // the A fragments (K <= 64) are loaded once and reused for every column
 #pragma unroll
     for (int t = 0; t < MAXMT; ++t)
 #pragma unroll
@@ -280,33 +328,59 @@ __device__ __forceinline__ void gemm_band_wide(const Dims a, const __bf16* bh_, 
             ah[t][cc] = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + 32 * cc);
             al[t][cc] = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + 32 * cc);
         }
-    vb_bf16x8 bh0[2], bl0[2], bh1[2], bl1[2];                // two register sets x [k-chunk]
-    auto load_bs = [&](int nt, vb_bf16x8 (&bh)[2], vb_bf16x8 (&bl)[2]) {
-        load_b(w, plane, npad, 0, nt, lane, bh[0], bl[0]);
-        load_b(w, plane, npad, cch - 1, nt, lane, bh[1], bl[1]);   // cch == 1: the second chunk is never multiplied
+    // a step brings in [2 planes][cch chunks][32 columns][32 k]: the ring slot is used as [plane][chunk * 32 + column]
+    // (the slot has 64 rows per plane: cch <= 2 chunks of 32 columns)
+    Feeder fd{w, plane, npad, 32, -1, 0, 0};
+    int pc_chunk = 0;
+    if (tid < 2 * cch * 32 * 4) {
+        fd.pc_plane = tid / (cch * 32 * 4);
+        pc_chunk = (tid / (32 * 4)) % cch;
+        fd.pc_n = (tid >> 2) & 31;
+        fd.pc_q = tid & 3;
+    }
+    auto wload = [&](int st) {
+        vb_u32x4 v = {0u, 0u, 0u, 0u};
+        if (fd.pc_plane >= 0)
+            v = *reinterpret_cast<const vb_u32x4*>(w + (size_t)fd.pc_plane * plane + ((size_t)pc_chunk * npad + 32 * st + fd.pc_n) * 32 + 8 * fd.pc_q);
+        return v;
     };
-    auto step = [&](int nt, const vb_bf16x8 (&bh)[2], const vb_bf16x8 (&bl)[2]) {
+    vb_u32x4 pre[PD];
 #pragma unroll
-        for (int t = 0; t < MAXMT; ++t) {
-            if (wave + NW * t >= nmt) continue;
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < PD; ++j) pre[j] = j < nsteps ? wload(j) : vb_u32x4{0u, 0u, 0u, 0u};
+    for (int st0 = 0; st0 < nsteps; st0 += PD) {
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-                if (cc < cch) c = mma3(ah[t][cc], al[t][cc], bh[cc], bl[cc], c);
-            const int n = 16 * nt + (lane & 15);
+        for (int j = 0; j < PD; ++j) {
+            const int st = st0 + j;
+            if (st >= nsteps) break;
+            __bf16* slot = ring + (st & 1) * RING_SLOT;
+            if (fd.pc_plane >= 0)
+                *reinterpret_cast<vb_u32x4*>(slot + (fd.pc_plane * 64 + pc_chunk * 32 + fd.pc_n) * BROWP + 8 * fd.pc_q) = pre[j];
+            if (st + PD < nsteps) pre[j] = wload(st + PD);
+            __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) epi(t, e, n, c[e]);
-        }
-    };
-    load_bs(0, bh0, bl0);
-    for (int nt = 0; nt < nnt; nt += 2) {
-        if (nt + 1 < nnt) load_bs(nt + 1, bh1, bl1);
-        step(nt, bh0, bl0);
-        if (nt + 1 < nnt) {
-            if (nt + 2 < nnt) load_bs(nt + 2, bh0, bl0);
-            step(nt + 1, bh1, bl1);
+            for (int half = 0; half < 2; ++half) {           // the step's two n-tiles
+                const int nt = 2 * st + half;
+                if (16 * nt >= Nout) continue;
+#pragma unroll
+                for (int t = 0; t < MAXMT; ++t) {
+                    if (wave + NW * t >= nmt) continue;
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        if (cc >= cch) continue;
+                        const int o = (cc * 32 + 16 * half + (lane & 15)) * BROWP + 8 * (lane >> 4);
+                        const vb_bf16x8 bh = *reinterpret_cast<const vb_bf16x8*>(slot + o);
+                        const vb_bf16x8 bl = *reinterpret_cast<const vb_bf16x8*>(slot + 64 * BROWP + o);
+                        c = mma3(ah[t][cc], al[t][cc], bh, bl, c);
+                    }
+                    const int n = 16 * nt + (lane & 15);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) epi(t, e, n, c[e]);
+                }
+            }
         }
     }
+    __syncthreads();
 }
 
 // zero the band buffers (halo columns, rows outside the image and the padding channels stay zero afterwards)
@@ -339,13 +413,14 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
     const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
     const float* __restrict__ xin = ka.xin;
     const float* __restrict__ resp = ka.res;
-    const float* __restrict__ xpre = ka.xpre;
+    [[maybe_unused]] const float* __restrict__ xpre = ka.xpre;
     float* __restrict__ outp = ka.out;
     float* const hh0 = ka.hh[0]; float* const hh1 = ka.hh[1]; float* const hh2 = ka.hh[2];
     float* const gg0 = ka.gg[0]; float* const gg1 = ka.gg[1]; float* const gg2 = ka.gg[2];
     const __bf16* const w0 = ka.w[0]; const __bf16* const w1 = ka.w[1]; const __bf16* const w2 = ka.w[2]; const __bf16* const w3 = ka.w[3];
     const long long pl0 = ka.plane[0], pl1 = ka.plane[1], pl2 = ka.plane[2], pl3 = ka.plane[3];
-    const float* const bs0 = ka.bias[0]; const float* const bs1 = ka.bias[1]; const float* const bs2 = ka.bias[2]; const float* const bs3 = ka.bias[3];
+    [[maybe_unused]] const float* const bs0 = ka.bias[0]; [[maybe_unused]] const float* const bs1 = ka.bias[1];
+    [[maybe_unused]] const float* const bs2 = ka.bias[2]; [[maybe_unused]] const float* const bs3 = ka.bias[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = a.k3 / 2;                                // 1 for 3x3 middle convs, 0 for 1x1
     const int band = blockIdx.x % abands, img0 = (blockIdx.x / abands) * aNI;
@@ -358,12 +433,13 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
     __bf16* b1l = b1h + e1 + PS;
     __bf16* b2h = b1l + e1 + PS;
     __bf16* b2l = b2h + e2 + PS;
+    __bf16* ring = b2l + e2;                                  // two slots of the weight feeder
     zero_lds(reinterpret_cast<__bf16*>(smem_raw), 2 * (e1 + PS) + 2 * (e2 + PS), tid);
     __syncthreads();
 
     f32x4 acc[MAXMT][MAXNT];
     // ---- stage 1: h1 = c1(xg) on the rows of s1 -> g1 band ----
-    gemm_global_mid<MAXNT>(a, xin, aCin, w0, pl0, img0, s1, M1, wave, lane, acc);
+    gemm_global_mid<MAXNT>(a, xin, aCin, w0, pl0, ring, img0, s1, M1, wave, lane, tid, acc);
     int ro[MAXMT][4], bo[MAXMT][4], yy[MAXMT][4];
     // (pointers are passed explicitly: indexing the kernel-argument arrays with a runtime layer number would force the whole
     // argument block into scratch memory)
@@ -398,11 +474,11 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
     epilogue_mid(s1, M1, bs0, hh0, gg0, b1h, b1l, y0, own_hi);
     __syncthreads();
     // ---- stage 2: h2 = c2(g1) on the rows of s2 -> g2 band ----
-    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w1, pl1, img0, s2, M2, +1, wave, lane, acc);
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w1, pl1, ring, img0, s2, M2, +1, wave, lane, tid, acc);
     epilogue_mid(s2, M2, bs1, hh1, gg1, b2h, b2l, y0, own_hi);
     __syncthreads();
     // ---- stage 3: h3 = c3(g2) on the owned rows -> g3 into band 1 (g1 is dead) ----
-    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w2, pl2, img0, s3, M3, +1, wave, lane, acc);
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w2, pl2, ring, img0, s3, M3, +1, wave, lane, tid, acc);
     __syncthreads();                                          // every wave is done reading band 1's successor inputs (band 2 only)
     {   // g3 goes into band 1 laid out with s3's rows; stale g1 there is overwritten or unread (c4 is 1x1: no halo, and
         // the padding channels mid..63 of every slot were zeroed once and are never written)
@@ -411,7 +487,7 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
     __syncthreads();
     // ---- stage 4: out = c4(g3) + bias + res ----
     row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
-    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w3, pl3, aCout, img0, s3, M3, wave, lane,
+    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w3, pl3, ring, aCout, img0, s3, M3, wave, lane, tid,
                    [&](int t, int e, int n, float v) {
                        if (ro[t][e] < 0 || n >= aCout) return;
                        const size_t o = (size_t)ro[t][e] * aCout + n;
@@ -432,13 +508,14 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
     const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
     const float* __restrict__ xin = ka.xin;
     const float* __restrict__ resp = ka.res;
-    const float* __restrict__ xpre = ka.xpre;
+    [[maybe_unused]] const float* __restrict__ xpre = ka.xpre;
     float* __restrict__ outp = ka.out;
     float* const hh0 = ka.hh[0]; float* const hh1 = ka.hh[1]; float* const hh2 = ka.hh[2];
     float* const gg0 = ka.gg[0]; float* const gg1 = ka.gg[1]; float* const gg2 = ka.gg[2];
     const __bf16* const w0 = ka.w[0]; const __bf16* const w1 = ka.w[1]; const __bf16* const w2 = ka.w[2]; const __bf16* const w3 = ka.w[3];
     const long long pl0 = ka.plane[0], pl1 = ka.plane[1], pl2 = ka.plane[2], pl3 = ka.plane[3];
-    const float* const bs0 = ka.bias[0]; const float* const bs1 = ka.bias[1]; const float* const bs2 = ka.bias[2]; const float* const bs3 = ka.bias[3];
+    [[maybe_unused]] const float* const bs0 = ka.bias[0]; [[maybe_unused]] const float* const bs1 = ka.bias[1];
+    [[maybe_unused]] const float* const bs2 = ka.bias[2]; [[maybe_unused]] const float* const bs3 = ka.bias[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = a.k3 / 2;
     const int band = blockIdx.x % abands, img0 = (blockIdx.x / abands) * aNI;
@@ -450,6 +527,7 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
     __bf16* b1l = b1h + e1 + PS;
     __bf16* b2h = b1l + e1 + PS;
     __bf16* b2l = b2h + e2 + PS;
+    __bf16* ring = b2l + e2;                                  // two slots of the weight feeder
     zero_lds(reinterpret_cast<__bf16*>(smem_raw), 2 * (e1 + PS) + 2 * (e2 + PS), tid);
     __syncthreads();
 
@@ -478,18 +556,18 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
             }
         }
     };
-    gemm_global_mid<MAXNT>(a, xin, aCout, w3, pl3, img0, s1, M1, wave, lane, acc);
+    gemm_global_mid<MAXNT>(a, xin, aCout, w3, pl3, ring, img0, s1, M1, wave, lane, tid, acc);
     epilogue_mid(s1, M1, hh2, gg2, b1h, b1l);
     __syncthreads();
-    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w2, pl2, img0, s2, M2, -1, wave, lane, acc);
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w2, pl2, ring, img0, s2, M2, -1, wave, lane, tid, acc);
     epilogue_mid(s2, M2, hh1, gg1, b2h, b2l);
     __syncthreads();
-    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w1, pl1, img0, s3, M3, -1, wave, lane, acc);
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w1, pl1, ring, img0, s3, M3, -1, wave, lane, tid, acc);
     __syncthreads();
     epilogue_mid(s3, M3, hh0, gg0, b1h, b1l);
     __syncthreads();
     row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
-    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w0, pl0, aCin, img0, s3, M3, wave, lane,
+    gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w0, pl0, ring, aCin, img0, s3, M3, wave, lane, tid,
                    [&](int t, int e, int n, float v) {
                        if (ro[t][e] < 0 || n >= aCin) return;
                        const size_t o = (size_t)ro[t][e] * aCin + n;
@@ -514,8 +592,8 @@ bool plan_block(int B, int H, int W, int k3, BandPlan& bp) {
         while (NI < B && (NI + 1) * (H + 4 * halo) * W <= MAXM && (B + NI) / (NI + 1) >= 128) ++NI;
     bp.R = R; bp.NI = NI; bp.bands = (H + R - 1) / R;
     const size_t e1 = (size_t)NI * (R + 4 * halo) * (W + 2) * PS, e2 = (size_t)NI * (R + 2 * halo) * (W + 2) * PS;
-    bp.lds = (2 * (e1 + PS) + 2 * (e2 + PS)) * sizeof(__bf16);
-    return bp.lds <= 150 * 1024;
+    bp.lds = (2 * (e1 + PS) + 2 * (e2 + PS) + 2 * RING_SLOT) * sizeof(__bf16);
+    return bp.lds <= 158 * 1024;
 }
 
 int launch_block(hipStream_t stream, bool backward, BlockArgs& a) {
@@ -525,8 +603,8 @@ int launch_block(hipStream_t stream, bool backward, BlockArgs& a) {
     const unsigned grid = (unsigned)(((a.B + a.NI - 1) / a.NI) * a.bands);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         attr_set = true;
     }
     if (backward) hipLaunchKernelGGL(vdvae_block_bwd_kernel, dim3(grid), dim3(NTHR), bp.lds, stream, a);

@@ -187,6 +187,7 @@ class Workspace:
         self._aux_streams: Dict[int, "torch.cuda.Stream"] = {}
         self._aux_pool: list = []
         self._aux_next = -1
+        self.wgrad_batch = None      # ops.WgradBatch while a backward pass defers its weight gradients to ONE launch per geometry
         self.overlap_wgrad = False   # measured on MI355X: 4 streams (3.23 ms/step) lose to 2 (2.93 ms/step)
         self.wgrad_stream = None     # set by a model while a chain whose weight gradients should run elsewhere is issued
 

@@ -132,6 +132,10 @@ class Block(Module):
             cur, aux = torch.cuda.current_stream(self.ws.device), self.ws.aux_stream()
             pairs = ((self.c4, self._g[2], dout), (self.c3, self._g[1], dhs[2]), (self.c2, self._g[0], dhs[1]),
                      (self.c1, self._xg, dhs[0]))
+            if self.ws.wgrad_batch is not None:     # launched at the end of the backward pass, one launch per geometry
+                for L, xin, dy in pairs:
+                    self.ws.wgrad_batch.add(L.g, xin, dy, self.store.g[L.w], self.store.g[L.b], self.store.use_bf16)
+                return
             if aux is not cur and aux != cur:
                 ops.wait_stream(aux, cur)           # ONE dependency per Block: its four weight gradients share a stream
             with torch.cuda.stream(aux):
@@ -693,6 +697,13 @@ class PosteriorMatchingVDVAE(Module):
         B, H, W_, _ = self._x.shape
         width, nm = c["width"], c["num_mixtures"]
         g = grad_scale / B
+        import os
+
+        batched = self.store.use_bf16 and not os.environ.get("PM_NO_WGRAD_BATCH") and not os.environ.get("PM_NO_VDVAE_FUSED")
+        if batched:
+            if getattr(self, "_wgrad_batch", None) is None:
+                self._wgrad_batch = ops.WgradBatch()
+            self.ws.wgrad_batch = self._wgrad_batch
         dparams = self.ws.get("decoder/d_dmol_params", tuple(self._params.shape))
         ops.dmol_ll_bwd(self._params, self._x, -g, dparams, nm, H * W_)
         self.wgrad(self.out_net.g, self._px_z, dparams, self.store.g[self.out_net.w], self.store.g[self.out_net.b])
@@ -718,7 +729,7 @@ class PosteriorMatchingVDVAE(Module):
             blk = self.dec_blocks[i]
             r = blk.base
             dxin = blk.backward(dxs[r], dacts[r], dmacts[r], g, g, streams=streams)
-            if self.store.reducer is not None:          # data-parallel: block i's weight gradients are final once the
+            if self.store.reducer is not None and self.ws.wgrad_batch is None:   # data-parallel: block i's weight gradients are final once the
                 self.ws.join_all_aux()                  # main chain and the masked-posterior chain (streams[1]) got here
                 self.store.grads_ready([f"decoder/block_{i}"], streams=None if streams is None else (main, streams[1]))
             if blk.mixin is not None:
@@ -742,6 +753,10 @@ class PosteriorMatchingVDVAE(Module):
         else:
             self.encoder.backward(dacts)
             self.masked_encoder.backward(dmacts)
+        if self.ws.wgrad_batch is not None:
+            # every Block has left its operands in HBM: their weight gradients, one launch per (resolution, layer shape)
+            self.ws.wgrad_batch.flush()
+            self.ws.wgrad_batch = None
         self.ws.join_all_aux()
 
     def zero_grad(self) -> None:

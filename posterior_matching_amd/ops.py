@@ -540,6 +540,51 @@ def layer_wgrad(g: LayerGeom, x, dy, dw, db, in_act=ACT_NONE, bf16: bool = True,
         colsum(dy, db)
 
 
+class WgradBatch:
+    """Weight gradients collected during a backward pass and launched at its end, ONE launch per geometry
+    (pm_gather_wgrad_table): the weight / bias gradients of a layer only feed the optimizer, and a model made of many
+    same-shaped small layers (the VDVAE's 100 bottleneck Blocks: 400 weight-gradient launches of ~25 us, a third of its
+    step) pays one launch per (resolution, layer shape) instead.  Every operand is a static workspace / parameter buffer,
+    so the per-geometry offset tables are built once and a recorded launch plan replays the same launches."""
+
+    def __init__(self):
+        self.items = {}          # key -> [(geom, x, dy, dw, db)]
+        self._tables = {}        # (key, pointer tuple) -> (device table, aligned flag)
+
+    def add(self, g: LayerGeom, x, dy, dw, db, bf16: bool) -> None:
+        if g.kind == "convT":
+            raise NotImplementedError("deferred weight gradients of transposed convolutions")
+        B = x.shape[0]
+        d = g._desc(B, "wgrad")
+        use_bf16 = bool(bf16 and USE_BF16_WGRAD and d.C % 32 == 0 and d.N % 4 == 0 and d.d in (1, 2))
+        key = (B, g.IH, g.IW, g.CI, g.OH, g.OW, g.CO, g.KH, g.KW, g.s, g.pad, g.full_kh, g.full_kw, use_bf16, db is not None)
+        self.items.setdefault(key, []).append((g, x, dy, dw, db))
+
+    def flush(self) -> None:
+        for key, lst in self.items.items():
+            g0, x0, dy0, dw0, db0 = lst[0]
+            ptrs = tuple(t.data_ptr() for it in lst for t in it[1:] if t is not None)
+            cached = self._tables.get((key, ptrs))
+            if cached is None:
+                rows = []
+                for _, x, dy, dw, db in lst:
+                    rows += [(x.data_ptr() - x0.data_ptr()) // 4, (dy.data_ptr() - dy0.data_ptr()) // 4,
+                             (dw.data_ptr() - dw0.data_ptr()) // 4,
+                             ((db.data_ptr() - db0.data_ptr()) // 4) if db is not None else 0]
+                aligned = all(x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 for _, x, dy, _, _ in lst)
+                cached = (torch.tensor(rows, dtype=torch.int64, device=x0.device), int(aligned))
+                self._tables[(key, ptrs)] = cached
+            table, aligned = cached
+            d = g0._desc(key[0], "wgrad", groups=len(lst))
+            tag = work = None
+            if _timer is not None:
+                tag = "gather_wgrad_table"
+                work = {"flops": _algorithmic_flops(d), "bytes": len(lst) * _nbytes(x0, dy0, dw0), "detail": _detail(d)}
+            _call("pm_gather_wgrad_table", C.byref(d), _ptr(x0), _ptr(dy0), _ptr(dw0), _ptr(db0), table.data_ptr(), aligned,
+                  int(key[-2]), tag=tag, work=work)
+        self.items = {}
+
+
 # ------------------------------------------------------------------------------------------
 # heads / loss / optimizer
 # ------------------------------------------------------------------------------------------
