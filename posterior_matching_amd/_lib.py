@@ -187,7 +187,7 @@ SIGNATURES = {
     "pm_random_indices": [_P, _P, _I, _I, C.c_ulonglong, _P, _I],
     "pm_gather_u8_rows": [_P, _P, _P, _P, _I, _LL, _F],
     "pm_vdvae_block_fwd": [_P, _P, _P, C.POINTER(_P), C.POINTER(_LL), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P,
-                           _I, _I, _I, _I, _I, _I, _I],
+                           _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "pm_vdvae_block_bwd": [_P, _P, _P, _P, C.POINTER(_P), C.POINTER(_LL), C.POINTER(_P), C.POINTER(_P), _P,
                            _I, _I, _I, _I, _I, _I, _I],
     "pm_graph_begin": [_P],

@@ -29,7 +29,10 @@ constexpr int MAXM = 256;        // positions a workgroup may own per stage (16 
 
 struct BlockArgs {
     // tensors
-    const float* xin;            // forward: xg [B,H,W,Cin];  backward: dout [B,H,W,Cout]
+    const float* xin;            // forward: xg [B,H,W,Cin] (or the raw first source when gelu_in);  backward: dout [B,H,W,Cout]
+    const float* xin2;           // forward, gelu_in: second raw source (channels Ca..Cin), may be NULL
+    float* xg_out;               // forward, gelu_in: gelu([xin | xin2]) is stored here for the weight gradient
+    int Ca, gelu_in;
     const float* res;            // forward: residual added to out (may be NULL);  backward: added to dxg (may be NULL)
     const float* xpre;           // backward only: dxg *= gelu'(xpre) (may be NULL)
     float* hh[3];                // h1, h2, h3 [B,H,W,mid]       (backward: read)
@@ -60,13 +63,20 @@ __device__ __forceinline__ void vb_split8(const f32x4& x0, const f32x4& x1, vb_b
 
 // jax.nn.gelu(approximate=True) and its derivative through ONE exponential each: tanh(u) = 1 - 2 / (1 + e^(2u)).
 // (tanhf expands to a long polynomial / branch sequence; inlined 72 times it alone overflowed the instruction cache)
-__device__ __forceinline__ float vb_tanh(float u) { return 1.f - 2.f / (1.f + __expf(2.f * u)); }
+__device__ __forceinline__ float vb_tanh(float u) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * u)); }
 __device__ __forceinline__ float vb_gelu(float x) {
     return 0.5f * x * (1.f + vb_tanh(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
 __device__ __forceinline__ float vb_gelu_d(float x) {
     const float t = vb_tanh(0.7978845608028654f * (x + 0.044715f * x * x * x));
     return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 0.134145f * x * x);
+}
+
+// keeps a value materialised HERE: without it the compiler sinks "acc + bias" (and with it the wait for the bias load)
+// into every conditional store block, behind the stores of the previous element
+__device__ __forceinline__ float vb_pin(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
 __device__ __forceinline__ void vb_store_split(__bf16* hi, __bf16* lo, int off, float v) {
@@ -159,11 +169,11 @@ __device__ __forceinline__ Feeder make_feeder(const __bf16* w, long long plane, 
     return f;
 }
 // piece of (k-chunk kc, first column n0) -> registers
+// (branch-free: a load under an `if` makes the compiler wait for EVERY outstanding load - s_waitcnt vmcnt(0) - at the join, which
+// serialises the whole prefetch ring; threads without a piece re-read piece 0 and never store it)
 __device__ __forceinline__ vb_u32x4 feed_load(const Feeder& f, int kc, int n0) {
-    vb_u32x4 v = {0u, 0u, 0u, 0u};
-    if (f.pc_plane >= 0)
-        v = *reinterpret_cast<const vb_u32x4*>(f.w + (size_t)f.pc_plane * f.plane + ((size_t)kc * f.npad + n0 + f.pc_n) * 32 + 8 * f.pc_q);
-    return v;
+    const int pl = f.pc_plane >= 0 ? f.pc_plane : 0;
+    return *reinterpret_cast<const vb_u32x4*>(f.w + (size_t)pl * f.plane + ((size_t)kc * f.npad + n0 + f.pc_n) * 32 + 8 * f.pc_q);
 }
 __device__ __forceinline__ void feed_store(const Feeder& f, __bf16* slot, const vb_u32x4& v) {
     if (f.pc_plane >= 0) *reinterpret_cast<vb_u32x4*>(slot + (f.pc_plane * 64 + f.pc_n) * BROWP + 8 * f.pc_q) = v;
@@ -178,64 +188,94 @@ __device__ __forceinline__ void ring_b(const __bf16* slot, int nt, int lane, vb_
 // ---- 1x1 stage with A from GLOBAL memory: C[p][n] = sum_k A[p][k] W[k][n],  N <= 48 (mid-wide) ------------------------------
 // A rows are [K] floats at ain + ((img*H + y)*W + x) * K; rows outside the image contribute zeros.  A rows are prefetched three
 // k-steps ahead in registers (each wave reads its own rows).
-template <int NT>
-__device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __restrict__ ain, int K, const __bf16* w,
-                                                long long plane, __bf16* ring, int img0, const Stage& s, int M, int wave, int lane,
-                                                int tid, f32x4 (&acc)[MAXMT][NT]) {
+// GELU_IN (forward stage 1): the rows are the Block's raw input x = [ain | ain2] (Ca channels from ain, K - Ca from ain2, Ca a
+// multiple of 32 when there are two sources); gelu is applied as the rows arrive and gelu(x) of the rows the band owns
+// ([own_lo, own_hi)) is stored to xg_out for the weight gradient - the separate gelu launch in front of every Block is gone.
+template <int NT, bool GELU_IN>
+__device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __restrict__ ain, const float* __restrict__ ain2,
+                                                int Ca, float* __restrict__ xg_out, int own_lo, int own_hi, int K,
+                                                const __bf16* w, long long plane, __bf16* ring, int img0, const Stage& s, int M,
+                                                int wave, int lane, int tid, f32x4 (&acc)[MAXMT][NT]) {
     const int kch = (K + 31) / 32;
     const int npad = (a.mid + 31) / 32 * 32;               // the split layout pads N to whole 32s
     const int nmt = (M + 15) / 16;
     const float* rowp[MAXMT];
+    const float* rowp2[MAXMT];
+    float* xgp[MAXMT];
     bool rok[MAXMT];
+    const int Cb = K - Ca;
 #pragma unroll
     for (int t = 0; t < MAXMT; ++t) {
         const int mt = wave + NW * t;
         const Pos q = decode(a, img0, s, mt * 16 + (lane & 15), M);
         rok[t] = mt < nmt && q.ok;
-        rowp[t] = ain + (rok[t] ? ((size_t)(q.img * a.H + q.y) * a.W + q.x) * K : 0) + 8 * (lane >> 4);
+        const size_t row = rok[t] ? (size_t)(q.img * a.H + q.y) * a.W + q.x : 0;
+        rowp[t] = ain + row * (GELU_IN ? Ca : K) + 8 * (lane >> 4);
+        rowp2[t] = (GELU_IN && ain2) ? ain2 + row * Cb + 8 * (lane >> 4) : nullptr;
+        xgp[t] = (GELU_IN && rok[t] && q.y >= own_lo && q.y < own_hi) ? xg_out + row * K + 8 * (lane >> 4) : nullptr;
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int kg = 8 * (lane >> 4);
     const Feeder fd = make_feeder(w, plane, npad, npad, tid);
+    // register rings indexed by compile-time constants (the k-loop is unrolled PD times, every load is unconditional and its
+    // index clamped): the body is straight-line code, so the compiler counts the loads in flight exactly (s_waitcnt vmcnt(N))
+    // instead of draining them all at a control-flow join
     vb_u32x4 pre[PD];
-    f32x4 xa[3][MAXMT][2];                                  // A rows of k-steps ks, ks + 1, ks + 2 (static indices below)
+    f32x4 xa[3][MAXMT][2];
     auto load_a = [&](int kc, f32x4 (&x)[MAXMT][2]) {
-        const bool kin = kc < kch && 32 * kc + kg + 8 <= K;  // K % 8 == 0: a lane's 8 channels are all inside or all outside
+        kc = kc < kch ? kc : kch - 1;
+        const bool kin = 32 * kc + kg + 8 <= K;              // K % 8 == 0: a lane's 8 channels are all inside or all outside
 #pragma unroll
         for (int t = 0; t < MAXMT; ++t) {
-            x[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            x[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rok[t] && kin) {
-                x[t][0] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc);
-                x[t][1] = *reinterpret_cast<const f32x4*>(rowp[t] + 32 * kc + 4);
-            }
+            const float* src = (GELU_IN && 32 * kc >= Ca) ? rowp2[t] + (32 * kc - Ca) : rowp[t] + (kin ? 32 * kc : 0);
+            x[t][0] = *reinterpret_cast<const f32x4*>(src);
+            x[t][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
     };
+    auto kclamp = [&](int k) { return k < kch ? k : kch - 1; };
 #pragma unroll
-    for (int j = 0; j < PD; ++j) pre[j] = j < kch ? feed_load(fd, j, 0) : vb_u32x4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < PD; ++j) pre[j] = feed_load(fd, kclamp(j), 0);
     load_a(0, xa[0]);
     load_a(1, xa[1]);
     load_a(2, xa[2]);
     for (int ks0 = 0; ks0 < kch; ks0 += PD) {
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
-            const int ks = ks0 + j;
-            if (ks >= kch) break;
-            __bf16* slot = ring + (ks & 1) * RING_SLOT;
+            const int ks = ks0 + j;                          // steps past the end only move (clamped) data around
+            __bf16* slot = ring + (j & 1) * RING_SLOT;       // PD is even: ks & 1 == j & 1
             feed_store(fd, slot, pre[j]);
-            if (ks + PD < kch) pre[j] = feed_load(fd, ks + PD, 0);
+            pre[j] = feed_load(fd, kclamp(ks + PD), 0);
             __syncthreads();
+            if (ks < kch) {                                  // uniform
+                const bool kin = 32 * ks + kg + 8 <= K;
 #pragma unroll
-            for (int t = 0; t < MAXMT; ++t) {
-                if (wave + NW * t >= nmt) continue;          // wave-uniform
-                vb_bf16x8 ah, al;
-                vb_split8(xa[j % 3][t][0], xa[j % 3][t][1], ah, al);
+                for (int t = 0; t < MAXMT; ++t) {
+                    if (wave + NW * t >= nmt) continue;      // wave-uniform
+                    f32x4 v0 = xa[j % 3][t][0], v1 = xa[j % 3][t][1];
+                    if (!(rok[t] && kin)) {
+                        v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (GELU_IN) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    vb_bf16x8 bh, bl;
-                    ring_b(slot, n, lane, bh, bl);
-                    acc[t][n] = mma3(ah, al, bh, bl, acc[t][n]);
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] = vb_gelu(v0[e]);
+                            v1[e] = vb_gelu(v1[e]);
+                        }
+                        if (xgp[t] && kin) {
+                            *reinterpret_cast<f32x4*>(xgp[t] + 32 * ks) = v0;
+                            *reinterpret_cast<f32x4*>(xgp[t] + 32 * ks + 4) = v1;
+                        }
+                    }
+                    vb_bf16x8 ah, al;
+                    vb_split8(v0, v1, ah, al);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        vb_bf16x8 bh, bl;
+                        ring_b(slot, n, lane, bh, bl);
+                        acc[t][n] = mma3(ah, al, bh, bl, acc[t][n]);
+                    }
                 }
             }
             load_a(ks + 3, xa[j % 3]);                       // refill the set just consumed
@@ -270,30 +310,32 @@ __device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, c
     const int nk = taps * cch;
     const Feeder fd = make_feeder(w, plane, npad, npad, tid);
     vb_u32x4 pre[PD];
+    auto kclamp = [&](int k) { return k < nk ? k : nk - 1; };
 #pragma unroll
-    for (int j = 0; j < PD; ++j) pre[j] = j < nk ? feed_load(fd, j, 0) : vb_u32x4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < PD; ++j) pre[j] = feed_load(fd, kclamp(j), 0);
     for (int ks0 = 0; ks0 < nk; ks0 += PD) {
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
             const int ks = ks0 + j;
-            if (ks >= nk) break;
-            __bf16* slot = ring + (ks & 1) * RING_SLOT;
+            __bf16* slot = ring + (j & 1) * RING_SLOT;
             feed_store(fd, slot, pre[j]);
-            if (ks + PD < nk) pre[j] = feed_load(fd, ks + PD, 0);
+            pre[j] = feed_load(fd, kclamp(ks + PD), 0);
             __syncthreads();
-            const int tap = ks / cch, cc = ks - tap * cch;
-            const int ky = tap / a.k3, kx = tap - ky * a.k3;
-            const int shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
+            if (ks < nk) {                                   // uniform
+                const int tap = ks / cch, cc = ks - tap * cch;
+                const int ky = tap / a.k3, kx = tap - ky * a.k3;
+                const int shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
 #pragma unroll
-            for (int t = 0; t < MAXMT; ++t) {
-                if (wave + NW * t >= nmt) continue;
-                const vb_bf16x8 ah = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + shift);
-                const vb_bf16x8 al = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + shift);
+                for (int t = 0; t < MAXMT; ++t) {
+                    if (wave + NW * t >= nmt) continue;
+                    const vb_bf16x8 ah = *reinterpret_cast<const vb_bf16x8*>(bh_ + base[t] + shift);
+                    const vb_bf16x8 al = *reinterpret_cast<const vb_bf16x8*>(bl_ + base[t] + shift);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    vb_bf16x8 bh, bl;
-                    ring_b(slot, n, lane, bh, bl);
-                    acc[t][n] = mma3(ah, al, bh, bl, acc[t][n]);
+                    for (int n = 0; n < NT; ++n) {
+                        vb_bf16x8 bh, bl;
+                        ring_b(slot, n, lane, bh, bl);
+                        acc[t][n] = mma3(ah, al, bh, bl, acc[t][n]);
+                    }
                 }
             }
         }
@@ -303,10 +345,13 @@ __device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, c
 
 // ---- wide 1x1 stage with A from an LDS band (mid channels) and N = Nout columns, 32 columns (two n-tiles) per step: the last layer --------
 // epi(t, e, n, value) is called for every element: row (wave + NW t)*16 + 4*(lane >> 4) + e, column n
-template <typename Epi>
+// pre_fn(t, e, n, a, b) loads what the element's epilogue needs (bias / residual / gelu' argument) BEFORE the step's MFMAs are
+// issued; comb(value, a, b) folds them in once the MFMAs are done; fin(t, e, n, result) only stores.  Loads and stores interleaved element by element make every load wait
+// for the stores in front of it (vmcnt counts both): 16 round trips per step instead of one.
+template <typename Pre, typename Comb, typename Fin>
 __device__ __forceinline__ void gemm_band_wide(const Dims a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
                                                const __bf16* w, long long plane, __bf16* ring, int Nout, int img0, const Stage& s,
-                                               int M, int wave, int lane, int tid, Epi epi) {
+                                               int M, int wave, int lane, int tid, Pre pre_fn, Comb comb, Fin fin) {
     const int npad = (Nout + 31) / 32 * 32, cch = (a.mid + 31) / 32;
     const int nmt = (M + 15) / 16, nsteps = npad / 32;       // 32 columns per step
     int base[MAXMT];
@@ -338,45 +383,68 @@ __device__ __forceinline__ void gemm_band_wide(const Dims a, const __bf16* bh_, 
         fd.pc_n = (tid >> 2) & 31;
         fd.pc_q = tid & 3;
     }
+    const int wpl = fd.pc_plane >= 0 ? fd.pc_plane : 0;
     auto wload = [&](int st) {
-        vb_u32x4 v = {0u, 0u, 0u, 0u};
-        if (fd.pc_plane >= 0)
-            v = *reinterpret_cast<const vb_u32x4*>(w + (size_t)fd.pc_plane * plane + ((size_t)pc_chunk * npad + 32 * st + fd.pc_n) * 32 + 8 * fd.pc_q);
-        return v;
+        st = st < nsteps ? st : nsteps - 1;
+        return *reinterpret_cast<const vb_u32x4*>(w + (size_t)wpl * plane + ((size_t)pc_chunk * npad + 32 * st + fd.pc_n) * 32 + 8 * fd.pc_q);
     };
     vb_u32x4 pre[PD];
 #pragma unroll
-    for (int j = 0; j < PD; ++j) pre[j] = j < nsteps ? wload(j) : vb_u32x4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < PD; ++j) pre[j] = wload(j);
     for (int st0 = 0; st0 < nsteps; st0 += PD) {
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
             const int st = st0 + j;
-            if (st >= nsteps) break;
-            __bf16* slot = ring + (st & 1) * RING_SLOT;
+            __bf16* slot = ring + (j & 1) * RING_SLOT;
             if (fd.pc_plane >= 0)
                 *reinterpret_cast<vb_u32x4*>(slot + (fd.pc_plane * 64 + pc_chunk * 32 + fd.pc_n) * BROWP + 8 * fd.pc_q) = pre[j];
-            if (st + PD < nsteps) pre[j] = wload(st + PD);
+            pre[j] = wload(st + PD);
             __syncthreads();
+            if (st < nsteps) {                               // uniform
+                float ea[2][MAXMT][4], eb[2][MAXMT][4];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {           // the step's two n-tiles
-                const int nt = 2 * st + half;
-                if (16 * nt >= Nout) continue;
+                for (int half = 0; half < 2; ++half)
 #pragma unroll
-                for (int t = 0; t < MAXMT; ++t) {
-                    if (wave + NW * t >= nmt) continue;
-                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    for (int t = 0; t < MAXMT; ++t)
 #pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        if (cc >= cch) continue;
-                        const int o = (cc * 32 + 16 * half + (lane & 15)) * BROWP + 8 * (lane >> 4);
-                        const vb_bf16x8 bh = *reinterpret_cast<const vb_bf16x8*>(slot + o);
-                        const vb_bf16x8 bl = *reinterpret_cast<const vb_bf16x8*>(slot + 64 * BROWP + o);
-                        c = mma3(ah[t][cc], al[t][cc], bh, bl, c);
+                        for (int e = 0; e < 4; ++e) {
+                            ea[half][t][e] = 0.f;
+                            eb[half][t][e] = 0.f;
+                            if (wave + NW * t < nmt) pre_fn(t, e, 16 * (2 * st + half) + (lane & 15), ea[half][t][e], eb[half][t][e]);
+                        }
+                f32x4 cacc[2][MAXMT];
+#pragma unroll
+                for (int half = 0; half < 2; ++half)         // the step's two n-tiles
+#pragma unroll
+                    for (int t = 0; t < MAXMT; ++t) {
+                        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                        if (16 * (2 * st + half) < Nout && wave + NW * t < nmt) {
+#pragma unroll
+                            for (int cc = 0; cc < 2; ++cc) {
+                                if (cc >= cch) continue;
+                                const int o = (cc * 32 + 16 * half + (lane & 15)) * BROWP + 8 * (lane >> 4);
+                                const vb_bf16x8 bh = *reinterpret_cast<const vb_bf16x8*>(slot + o);
+                                const vb_bf16x8 bl = *reinterpret_cast<const vb_bf16x8*>(slot + 64 * BROWP + o);
+                                c = mma3(ah[t][cc], al[t][cc], bh, bl, c);
+                            }
+                        }
+                        cacc[half][t] = c;
                     }
-                    const int n = 16 * nt + (lane & 15);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) epi(t, e, n, c[e]);
-                }
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int t = 0; t < MAXMT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            cacc[half][t][e] = vb_pin(comb(cacc[half][t][e], ea[half][t][e], eb[half][t][e]));
+                        }
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int t = 0; t < MAXMT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (wave + NW * t < nmt) fin(t, e, 16 * (2 * st + half) + (lane & 15), cacc[half][t][e]);
             }
         }
     }
@@ -439,7 +507,12 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
 
     f32x4 acc[MAXMT][MAXNT];
     // ---- stage 1: h1 = c1(xg) on the rows of s1 -> g1 band ----
-    gemm_global_mid<MAXNT>(a, xin, aCin, w0, pl0, ring, img0, s1, M1, wave, lane, tid, acc);
+    const int own_hi = y0 + aR < a.H ? y0 + aR : a.H;
+    if (ka.gelu_in)
+        gemm_global_mid<MAXNT, true>(a, xin, ka.xin2, ka.Ca, ka.xg_out, y0, own_hi, aCin, w0, pl0, ring, img0, s1, M1, wave, lane,
+                                     tid, acc);
+    else
+        gemm_global_mid<MAXNT, false>(a, xin, nullptr, aCin, nullptr, 0, 0, aCin, w0, pl0, ring, img0, s1, M1, wave, lane, tid, acc);
     int ro[MAXMT][4], bo[MAXMT][4], yy[MAXMT][4];
     // (pointers are passed explicitly: indexing the kernel-argument arrays with a runtime layer number would force the whole
     // argument block into scratch memory)
@@ -447,18 +520,31 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
                             float* __restrict__ gdst, __bf16* oh, __bf16* ol, int own_lo, int own_hi) {
         const int nmt = (M + 15) / 16;
         row_offsets(a, img0, s, M, wave, lane, ro, bo, yy);
+        // pass 1: the only loads (three bias values) are consumed before any store is issued - a load behind a store waits
+        // for that store too (vmcnt counts both), once per element in the interleaved form
+#pragma unroll
+        for (int n = 0; n < MAXNT; ++n) {
+            const int col = 16 * n + (lane & 15);
+            const float bv = col < a.mid ? biasp[col] : 0.f;
+#pragma unroll
+            for (int t = 0; t < MAXMT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[t][n][e] = vb_pin(acc[t][n][e] + bv);
+                }
+        }
+        // pass 2: stores only
 #pragma unroll
         for (int n = 0; n < MAXNT; ++n) {
             const int col = 16 * n + (lane & 15);
             if (col >= a.mid) continue;
-            const float bv = biasp[col];
 #pragma unroll
             for (int t = 0; t < MAXMT; ++t) {
                 if (wave + NW * t >= nmt) continue;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (ro[t][e] < 0) continue;                 // outside the image: the band keeps its zeros (SAME padding)
-                    const float v = acc[t][n][e] + bv;
+                    const float v = acc[t][n][e];
                     const float gv = vb_gelu(v);
                     vb_store_split(oh, ol, bo[t][e] + col, gv);
                     if (yy[t][e] >= own_lo && yy[t][e] < own_hi) {   // rows this band owns: stored for the backward pass
@@ -470,7 +556,6 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
             }
         }
     };
-    const int own_hi = y0 + aR < a.H ? y0 + aR : a.H;
     epilogue_mid(s1, M1, bs0, hh0, gg0, b1h, b1l, y0, own_hi);
     __syncthreads();
     // ---- stage 2: h2 = c2(g1) on the rows of s2 -> g2 band ----
@@ -488,12 +573,15 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
     // ---- stage 4: out = c4(g3) + bias + res ----
     row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
     gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w3, pl3, ring, aCout, img0, s3, M3, wave, lane, tid,
+                   [&](int t, int e, int n, float& ea, float& eb) {
+                       if (ro[t][e] < 0 || n >= aCout) return;
+                       ea = bs3[n];
+                       if (resp) eb = resp[(size_t)ro[t][e] * aCout + n];
+                   },
+                   [&](float v, float ea, float eb) { return v + ea + eb; },
                    [&](int t, int e, int n, float v) {
                        if (ro[t][e] < 0 || n >= aCout) return;
-                       const size_t o = (size_t)ro[t][e] * aCout + n;
-                       v += bs3[n];
-                       if (resp) v += resp[o];
-                       outp[o] = v;
+                       outp[(size_t)ro[t][e] * aCout + n] = v;
                    });
 }
 
@@ -538,6 +626,25 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
                             __bf16* ol) {
         const int nmt = (M + 15) / 16;
         row_offsets(a, img0, s, M, wave, lane, ro, bo, yy);
+        // pass 1: every h the gelu' factors need, loaded back to back and multiplied in before the first store
+        float hv[MAXMT][MAXNT][4];
+#pragma unroll
+        for (int n = 0; n < MAXNT; ++n) {
+            const int col = 16 * n + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < MAXMT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {        // unconditional (clamped) loads: 24 in flight, ONE wait
+                    const bool ok = col < a.mid && ro[t][e] >= 0;
+                    hv[t][n][e] = hsrc[ok ? (size_t)ro[t][e] * a.mid + col : 0];
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < MAXNT; ++n)
+#pragma unroll
+            for (int t = 0; t < MAXMT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][n][e] = vb_pin(acc[t][n][e] * vb_gelu_d(hv[t][n][e]));
 #pragma unroll
         for (int n = 0; n < MAXNT; ++n) {
             const int col = 16 * n + (lane & 15);
@@ -549,14 +656,14 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
                 for (int e = 0; e < 4; ++e) {
                     if (ro[t][e] < 0) continue;
                     const size_t o = (size_t)ro[t][e] * a.mid + col;
-                    const float v = acc[t][n][e] * vb_gelu_d(hsrc[o]);
+                    const float v = acc[t][n][e];
                     vb_store_split(oh, ol, bo[t][e] + col, v);
                     if (yy[t][e] >= y0 && yy[t][e] < own_hi) dhdst[o] = v;
                 }
             }
         }
     };
-    gemm_global_mid<MAXNT>(a, xin, aCout, w3, pl3, ring, img0, s1, M1, wave, lane, tid, acc);
+    gemm_global_mid<MAXNT, false>(a, xin, nullptr, aCout, nullptr, 0, 0, aCout, w3, pl3, ring, img0, s1, M1, wave, lane, tid, acc);
     epilogue_mid(s1, M1, hh2, gg2, b1h, b1l);
     __syncthreads();
     gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w2, pl2, ring, img0, s2, M2, -1, wave, lane, tid, acc);
@@ -568,12 +675,16 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
     __syncthreads();
     row_offsets(a, img0, s3, M3, wave, lane, ro, bo, yy);
     gemm_band_wide(a, b1h, b1l, s3.rows, s3.ys, w0, pl0, ring, aCin, img0, s3, M3, wave, lane, tid,
-                   [&](int t, int e, int n, float v) {
+                   [&](int t, int e, int n, float& ea, float& eb) {
                        if (ro[t][e] < 0 || n >= aCin) return;
                        const size_t o = (size_t)ro[t][e] * aCin + n;
-                       if (xpre) v *= vb_gelu_d(xpre[o]);
-                       if (resp) v += resp[o];
-                       outp[o] = v;
+                       if (xpre) ea = xpre[o];
+                       if (resp) eb = resp[o];
+                   },
+                   [&](float v, float ea, float eb) { return (xpre ? v * vb_gelu_d(ea) : v) + eb; },
+                   [&](int t, int e, int n, float v) {
+                       if (ro[t][e] < 0 || n >= aCin) return;
+                       outp[(size_t)ro[t][e] * aCin + n] = v;
                    });
 }
 
@@ -621,10 +732,13 @@ bool block_shape_ok(int B, int H, int W, int Cin, int Cout, int mid, int k3) {
 
 extern "C" int pm_vdvae_block_fwd(pm_stream_t stream, const float* xg, const float* res, const void* const* wsplit,
                                   const long long* planes, const float* const* bias, float* const* h, float* const* g, float* out,
-                                  int B, int H, int W, int Cin, int Cout, int mid, int k3) {
+                                  int B, int H, int W, int Cin, int Cout, int mid, int k3, const float* x2, int Ca, float* xg_out) {
     if (!xg || !wsplit || !planes || !bias || !h || !g || !out || !block_shape_ok(B, H, W, Cin, Cout, mid, k3)) return PM_EINVAL;
+    // xg_out != NULL: `xg` (and x2) are the RAW inputs, Ca channels from xg and Cin - Ca from x2; gelu is applied on load
+    if (xg_out && (Ca <= 0 || Ca > Cin || Ca % 8 != 0 || (Ca < Cin && (!x2 || Ca % 32 != 0)))) return PM_EINVAL;
     BlockArgs a;
     a.xin = xg; a.res = res; a.xpre = nullptr; a.out = out;
+    a.xin2 = xg_out && Ca < Cin ? x2 : nullptr; a.xg_out = xg_out; a.Ca = xg_out ? Ca : Cin; a.gelu_in = xg_out ? 1 : 0;
     for (int i = 0; i < 3; ++i) { a.hh[i] = h[i]; a.gg[i] = g[i]; if (!h[i] || !g[i]) return PM_EINVAL; }
     for (int i = 0; i < 4; ++i) {
         a.w[i] = reinterpret_cast<const __bf16*>(wsplit[i]); a.plane[i] = planes[i]; a.bias[i] = bias[i];
@@ -641,6 +755,7 @@ extern "C" int pm_vdvae_block_bwd(pm_stream_t stream, const float* dout, const f
     if (!dout || !wsplit_dgrad || !planes || !h || !dh || !dxg || !block_shape_ok(B, H, W, Cin, Cout, mid, k3)) return PM_EINVAL;
     BlockArgs a;
     a.xin = dout; a.res = res; a.xpre = xpre; a.out = dxg;
+    a.xin2 = nullptr; a.xg_out = nullptr; a.Ca = Cout; a.gelu_in = 0;
     for (int i = 0; i < 3; ++i) { a.hh[i] = h[i]; a.gg[i] = dh[i]; if (!h[i] || !dh[i]) return PM_EINVAL; }
     for (int i = 0; i < 4; ++i) {
         a.w[i] = reinterpret_cast<const __bf16*>(wsplit_dgrad[i]); a.plane[i] = planes[i]; a.bias[i] = nullptr;

@@ -89,6 +89,25 @@ class Block(Module):
             return None
         return f, d
 
+    def forward_raw(self, x: torch.Tensor, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """the Block applied to the RAW input [x | x2] (reference :283: `x_hat = self.c1(jax.nn.gelu(x))`): in the one-launch form
+        the gelu runs inside the kernel as the rows are loaded and gelu([x | x2]) is written out for the weight gradient;
+        otherwise a gelu launch builds it first"""
+        B, H, W = x.shape[0], self.H, self.W
+        fused = self._fused()
+        xg = self.buf("xg", (B, H, W, self.cin))
+        if fused is None or (x2 is not None and x.shape[-1] % 32 != 0):
+            ops.gelu_fwd(x, x2, xg)
+            return self.forward(xg, res=res)
+        sh = lambda c: (B, H, W, c)   # noqa: E731
+        self._xg = xg
+        self._h = [self.buf(f"h{i + 1}", sh(self.mid)) for i in range(3)]
+        self._g = [self.buf(f"g{i + 1}", sh(self.mid)) for i in range(3)]
+        out = self.buf("out", sh(self.cout))
+        biases = [self.store.p[L.b] for L in (self.c1, self.c2, self.c3, self.c4)]
+        ops.vdvae_block_fwd(x, res, fused[0], biases, self._h, self._g, out, self.c2.g.k, x2=x2, xg_out=xg)
+        return out
+
     def forward(self, xg: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, H, W = xg.shape[0], self.H, self.W
         self._xg = xg
@@ -194,9 +213,7 @@ class Encoder(Module):
         acts = {h.shape[1]: h}
         self._ins, self._outs = [], []
         for i, (blk, down, res) in enumerate(self.blocks):
-            xg = self.buf(f"block_{i}/xg", tuple(h.shape))
-            ops.gelu_fwd(h, None, xg)
-            out = blk.forward(xg, res=h)
+            out = blk.forward_raw(h, None, res=h)
             self._ins.append(h)
             if down is not None:
                 pooled = self.buf(f"block_{i}/pooled", (B, res // down, res // down, self.width))
@@ -266,16 +283,10 @@ class PosteriorMatchingDecoderBlock(Module):
             ops.wait_stream(s1, main)
             ops.wait_stream(s2, main)
         with torch.cuda.stream(s1):
-            am = self.buf("am", sh(2 * W))
-            ops.gelu_fwd(x_in, macts, am)                  # stop_gradient(x): handled in backward (:536-538)
-            self._mp = self.masked_posterior.forward(am)
+            self._mp = self.masked_posterior.forward_raw(x_in, macts)   # stop_gradient(x): handled in backward (:536-538)
         with torch.cuda.stream(s2):
-            ap = self.buf("ap", sh(W))
-            ops.gelu_fwd(x_in, None, ap)
-            self._pr = self.prior.forward(ap)
-        a = self.buf("a", sh(2 * W))
-        ops.gelu_fwd(x_in, acts, a)
-        self._pp = self.posterior.forward(a)
+            self._pr = self.prior.forward_raw(x_in)
+        self._pp = self.posterior.forward_raw(x_in, acts)
         if streams is not None:
             ops.wait_stream(main, s1)
             ops.wait_stream(main, s2)
@@ -288,9 +299,7 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.layer_forward(self.z_proj.g, self._z, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
                           wsplit=self.store.split_view(self.z_proj.ws_f))
         self._x2 = x2
-        x2g = self.buf("x2g", sh(W))
-        ops.gelu_fwd(x2, None, x2g)
-        return self.resnet.forward(x2g, res=x2)
+        return self.resnet.forward_raw(x2, None, res=x2)
 
     def forward_partial(self, x_in: torch.Tensor, macts: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
         """forward_partial_posterior / sample_partial_posterior (reference :689-703, :573-590): z is drawn from the

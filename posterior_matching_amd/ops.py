@@ -972,14 +972,16 @@ def vdvae_block_fused_ok(B: int, H: int, W: int, cin: int, cout: int, mid: int, 
     return cin % 8 == 0 and cout % 8 == 0 and mid % 8 == 0 and mid <= 48 and W <= 62 and k3 in (1, 3)
 
 
-def vdvae_block_fwd(xg, res, wsplits, biases, hs, gs, out, k3: int) -> None:
-    """csrc/pm_vdvae_block.hip: c1..c4 of a Block in one launch (wsplits: the four layers' forward split views)"""
-    B, H, W, cin = xg.shape
+def vdvae_block_fwd(xg, res, wsplits, biases, hs, gs, out, k3: int, x2=None, xg_out=None) -> None:
+    """csrc/pm_vdvae_block.hip: c1..c4 of a Block in one launch (wsplits: the four layers' forward split views).
+    xg_out given: `xg` (and `x2`) are the RAW inputs [x | x2]; gelu runs inside the kernel and gelu([x | x2]) lands in xg_out."""
+    B, H, W, ca = xg.shape
+    cin = ca + (x2.shape[-1] if x2 is not None else 0)
     cout, mid = out.shape[-1], hs[0].shape[-1]
     planes = (C.c_longlong * 4)(*[w.numel() // 2 for w in wsplits])
     flops = 2.0 * B * H * W * (cin * mid + 2 * k3 * k3 * mid * mid + mid * cout)
     _call("pm_vdvae_block_fwd", _ptr(xg), _ptr(res), _ptr_array(wsplits), planes, _ptr_array(biases), _ptr_array(hs),
-          _ptr_array(gs), _ptr(out), B, H, W, cin, cout, mid, k3, tag="vdvae_block_fwd_kernel",
+          _ptr_array(gs), _ptr(out), B, H, W, cin, cout, mid, k3, _ptr(x2), ca, _ptr(xg_out), tag="vdvae_block_fwd_kernel",
           work={"flops": flops, "bytes": _nbytes(xg, res, out, *hs, *gs), "detail": f"B{B} {H}x{W} {cin}->{mid}->{cout} k{k3}"})
 
 

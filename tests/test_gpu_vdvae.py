@@ -289,16 +289,27 @@ def test_fused_block_matches_oracle_and_layerwise_path(B, H, cin, cout, mid, res
     grads = torch.autograd.grad((want * dout).sum(), [xr] + list(leaves.values()))
     want_dx, want_g = grads[0], dict(zip(leaves, grads[1:]))
 
+    two_sources = cin == 384                      # posterior / masked posterior: gelu([x | activations])
+
     def run():
         xd = f32d(x)
-        xg = torch.empty_like(xd)
-        ops.gelu_fwd(xd, None, xg)
-        out = blk.forward(xg, res=xd if residual and cin == cout else None).clone()
+        res_f = xd if residual and cin == cout else None
+        if two_sources:                           # the raw-input form: gelu inside the kernel, gelu(x) written out
+            out = blk.forward_raw(xd[..., :192].contiguous(), xd[..., 192:].contiguous(), res=res_f).clone()
+        else:
+            out = blk.forward_raw(xd, None, res=res_f).clone()
+        xg_want = torch.empty_like(xd)
+        ops.gelu_fwd(xd, None, xg_want)
+        torch.cuda.synchronize()
+        assert rel_err(blk._xg, xg_want) < 1e-6
         inter = [t.clone() for t in blk._h + blk._g]
         ops.fill_zero(store.flat_g)
         dx = torch.empty_like(xd)
         dd = f32d(dout)
-        blk.backward(dd, dx, x_pre=xd, res=dd if residual and cin == cout else None)
+        if two_sources:                           # gradient w.r.t. gelu([x | acts]); the caller's gelu_bwd splits it
+            blk.backward(dd, dx)
+        else:
+            blk.backward(dd, dx, x_pre=xd, res=dd if residual and cin == cout else None)
         torch.cuda.synchronize()
         dhs = [ws.get(f"blk/dh{i}", (B, H, H, mid)).clone() for i in (1, 2, 3)]
         return out, inter, dx.clone(), dhs, {n: t.clone() for n, t in store.to_dict("g").items()}
@@ -311,7 +322,11 @@ def test_fused_block_matches_oracle_and_layerwise_path(B, H, cin, cout, mid, res
         plain = run()
     finally:
         del os.environ["PM_NO_VDVAE_FUSED"]
-    assert rel_err(fused[0], want) < 2e-5 and rel_err(fused[2], want_dx) < 2e-5
+    assert rel_err(fused[0], want) < 2e-5 and (two_sources or rel_err(fused[2], want_dx) < 2e-5)
+    if two_sources:                               # chain rule by hand: d/dx = d/dgelu(x) * gelu'(x)
+        xr2 = x.clone().requires_grad_(True)
+        (DO.gelu(xr2) * fused[2].double().cpu()).sum().backward()
+        assert rel_err(xr2.grad, want_dx) < 2e-5
     assert rel_err(fused[0], plain[0]) < 2e-5 and rel_err(fused[2], plain[2]) < 2e-5
     for a, b_ in zip(fused[1] + fused[3], plain[1] + plain[3]):
         assert rel_err(a, b_) < 2e-5
