@@ -56,6 +56,46 @@ __device__ __forceinline__ float pm_epilogue(float v, const float* __restrict__ 
     return pm_act(v, out_act, slope);
 }
 
+// The same epilogue for one 32-column accumulator tile of a GEMM-class kernel: 16 elements per lane at output offsets
+// ro[e] + n (ro[e] < 0: no such row).  Phase 1 issues every aux / res load (16 + 16 in flight, clamped addresses for the
+// missing rows), phase 2 does the arithmetic, phase 3 only stores.  Written element by element, every load waits for the
+// stores in front of it (vmcnt counts loads and stores alike, and the compiler sinks the arithmetic into the conditional
+// store blocks): 16 memory round trips at the end of every data-gradient kernel.
+typedef float pm_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void pm_epilogue_tile(const pm_f32x16& acc, const int (&ro)[16], int n, float bv,
+                                                 const float* __restrict__ aux, const float* __restrict__ res,
+                                                 float* __restrict__ out, float* __restrict__ out2, int act2, int aux_act,
+                                                 int out_act, float slope) {
+    float av[16], rv[16], v[16];
+    if (aux) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) av[e] = aux[(size_t)(ro[e] >= 0 ? ro[e] : 0) + n];
+    }
+    if (res) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = res[(size_t)(ro[e] >= 0 ? ro[e] : 0) + n];
+    }
+    const bool after = (aux_act & PM_AUX_AFTER_RES) != 0;
+    const int dact = aux_act & (PM_AUX_AFTER_RES - 1);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float x = acc[e] + bv;
+        if (res && after) x += rv[e];
+        if (aux) x *= pm_dact(av[e], dact, slope);
+        if (res && !after) x += rv[e];
+        x = pm_act(x, out_act, slope);
+        asm volatile("" : "+v"(x));          // materialised here, not inside the conditional store blocks below
+        v[e] = x;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (ro[e] < 0) continue;
+        const size_t o = (size_t)ro[e] + n;
+        out[o] = v[e];
+        if (out2) out2[o] = pm_act(v[e], act2, slope);
+    }
+}
+
 __device__ __forceinline__ float pm_softplus(float x) {  // logaddexp(x, 0)
     return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
 }

@@ -543,23 +543,21 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
     const float* aux = p.aux ? p.aux + (size_t)grp * p.out_gs : nullptr;
     const float* res = p.res ? p.res + (size_t)grp * p.out_gs : nullptr;
     float* out = p.out + (size_t)grp * p.out_gs;
+    int ro[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ro[e] = rowoff32[wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
 #pragma unroll
     for (int r = 0; r < RN; ++r) {
         int n = n0 + (wn * RN + r) * 32 + i;
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
+        if (p.ksplit > 1) {  // partial sum of a K slice: the epilogue kernel finishes the tile
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            int ro = rowoff32[wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
-            if (ro < 0) continue;
-            size_t o = (size_t)ro + n;
-            if (p.ksplit > 1) {  // partial sum of a K slice: the epilogue kernel finishes the tile
-                atomicAdd(out + o, acc[r][e]);
-                continue;
-            }
-            float v = acc[r][e] + bv;
-            out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
+            for (int e = 0; e < 16; ++e)
+                if (ro[e] >= 0) atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+            continue;
         }
+        pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, nullptr, PM_ACT_NONE, g.aux_act, g.out_act, g.slope);
     }
 }
 
@@ -817,17 +815,13 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
         int n = n0 + r * 32 + i;
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
+        if (p.ksplit > 1) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (ro[e] < 0) continue;
-            size_t o = (size_t)ro[e] + n;
-            if (p.ksplit > 1) {
-                atomicAdd(out + o, acc[r][e]);
-                continue;
-            }
-            float v = acc[r][e] + bv;
-            out[o] = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
+            for (int e = 0; e < 16; ++e)
+                if (ro[e] >= 0) atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+            continue;
         }
+        pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, nullptr, PM_ACT_NONE, g.aux_act, g.out_act, g.slope);
     }
 }
 
@@ -1108,19 +1102,14 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
         int n = n0 + r * 32 + i;
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
+        if (p.ksplit > 1) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (ro[e] < 0) continue;
-            size_t o = (size_t)ro[e] + n;
-            if (p.ksplit > 1) {
-                atomicAdd(out + o, acc[r][e]);
-                continue;
-            }
-            float v = acc[r][e] + bv;
-            v = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
-            out[o] = v;
-            if (p.out2) p.out2[(size_t)grp * p.out_gs + o] = pm_act(v, p.act2, g.slope);
+            for (int e = 0; e < 16; ++e)
+                if (ro[e] >= 0) atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+            continue;
         }
+        pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, p.out2 ? p.out2 + (size_t)grp * p.out_gs : nullptr, p.act2, g.aux_act,
+                         g.out_act, g.slope);
     }
 }
 
@@ -1320,14 +1309,7 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
         int n = n0 + r * 32 + i;
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (ro[e] < 0) continue;
-            size_t o = (size_t)ro[e] + n;
-            const float v = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
-            out[o] = v;
-            if (p.out2) p.out2[o] = pm_act(v, p.act2, g.slope);
-        }
+        pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
     }
 }
 
@@ -1595,14 +1577,7 @@ __global__ __launch_bounds__(256) void patch_d2_bf16_kernel(GemmArgs p, const __
             const int n = n0 + r * 32 + i;
             if (n >= g.N) continue;
             const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if (ro[e] < 0) continue;
-                const size_t o = (size_t)ro[e] + n;
-                const float v = pm_epilogue(acc[r][e] + bv, aux, res, o, g.aux_act, g.out_act, g.slope);
-                out[o] = v;
-                if (p.out2) p.out2[o] = pm_act(v, p.act2, g.slope);
-            }
+            pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
         }
         __syncthreads();             // stage buffers are rewritten by the next class
     }
