@@ -68,6 +68,17 @@ class MaskComponent(C.Structure):
     ]
 
 
+class VdvaeBlockIO(C.Structure):
+    """struct pm_vdvae_block_io (include/pmhip.h)."""
+
+    _fields_ = [
+        ("x", C.c_void_p), ("x2", C.c_void_p), ("res", C.c_void_p), ("xpre", C.c_void_p), ("xg_out", C.c_void_p),
+        ("h", C.c_void_p * 3), ("g", C.c_void_p * 3), ("out", C.c_void_p),
+        ("w", C.c_void_p * 4), ("plane", C.c_longlong * 4), ("bias", C.c_void_p * 4),
+        ("Cin", C.c_int), ("Cout", C.c_int), ("Ca", C.c_int),
+    ]
+
+
 class SplitJob(C.Structure):
     """struct pm_split_job (include/pmhip.h)."""
 
@@ -186,10 +197,8 @@ SIGNATURES = {
     "pm_relu_mask_bwd": [_P, _P, _P, _P, _P, _LL],
     "pm_random_indices": [_P, _P, _I, _I, C.c_ulonglong, _P, _I],
     "pm_gather_u8_rows": [_P, _P, _P, _P, _I, _LL, _F],
-    "pm_vdvae_block_fwd": [_P, _P, _P, C.POINTER(_P), C.POINTER(_LL), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P,
-                           _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "pm_vdvae_block_bwd": [_P, _P, _P, _P, C.POINTER(_P), C.POINTER(_LL), C.POINTER(_P), C.POINTER(_P), _P,
-                           _I, _I, _I, _I, _I, _I, _I],
+    "pm_vdvae_blocks_fwd": [_P, C.POINTER(VdvaeBlockIO), _I, _I, _I, _I, _I, _I],
+    "pm_vdvae_blocks_bwd": [_P, C.POINTER(VdvaeBlockIO), _I, _I, _I, _I, _I, _I],
     "pm_graph_begin": [_P],
     "pm_graph_end": [_P, C.POINTER(_P)],
     "pm_graph_launch": [_P, _P],

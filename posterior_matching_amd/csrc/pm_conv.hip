@@ -1172,6 +1172,64 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
         }
         kd[s] = k;
     }
+    // weight stages: the pre-split K-contiguous copy, PDGS k-steps per LDS stage, two LDS stages.  A stage's pieces are
+    // loaded into registers THREE stages before it is consumed (4 rotating register sets, one 16-byte piece per thread and
+    // k-step for 32 columns): a stage is 0.16 us of MFMA work and an L2 round trip 0.5 - 0.8 us, so with one stage in flight
+    // (the first form of this kernel) every workgroup waited for the weights once per stage.  Loads are unconditional with a
+    // clamped stage index - a load under a branch makes the compiler drain vmcnt at the join.
+    constexpr int PIECES = 2 * NB * 4;
+    constexpr int PPT = (PIECES + 255) / 256;
+    constexpr int NSET = 4;
+    const __bf16* wg = wsplit;
+    const int nstages = (nsteps + PDGS - 1) / PDGS;
+    u32x4 breg[NSET][PDGS][PPT];
+    auto load_b = [&](int stg, u32x4 (&r)[PDGS][PPT]) {
+        const int s0 = (stg < nstages ? stg : nstages - 1) * PDGS;
+#pragma unroll
+        for (int st = 0; st < PDGS; ++st) {
+            const int sc = s0 + st < nsteps ? s0 + st : nsteps - 1;
+            const size_t wo = (size_t)sc * npad * BK;                   // = kd[sc].woff
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                const int nrow = n0 + row < npad ? n0 + row : 0;
+                r[st][j] = *reinterpret_cast<const u32x4*>(wg + (size_t)pl * plane + wo + nrow * BK + qtr * 8);
+            }
+        }
+    };
+    auto store_b = [&](__bf16* dst, const u32x4 (&r)[PDGS][PPT]) {
+#pragma unroll
+        for (int st = 0; st < PDGS; ++st)
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pc = tid + 256 * j;
+                const int pl = pc / (NB * 4);
+                const int row = (pc / 4) % NB;
+                const int qtr = pc & 3;
+                *reinterpret_cast<u32x4*>(dst + st * STEP_E + (pl * NB + row) * BROW + qtr * 8) = r[st][j];
+            }
+    };
+
+    // this lane's tile position and its A-fragment base inside the patch
+    const int ml = wave * 32 + i;
+    const int ty = ml >> tw_log2, tx = ml & (TW - 1);
+    const int abase = (ty * PW + tx) * PS + 8 * h;
+    const int gy = y0 + ty, gx = x0 + tx;
+    const int rowoff = (gy < g.OH && gx < g.OW) ? ((b * g.OH + gy) * g.OW + gx) * g.N : -1;
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    load_b(0, breg[0]);
+    load_b(1, breg[1]);
+    load_b(2, breg[2]);
+    // (the first three weight stages are in flight while the patch is staged)
     {   // the patch: f32 -> hi / lo bf16, zero outside the image.  Loads are issued in batches of 8 per thread so
         // that a workgroup pays ~2 global latencies for its patch instead of one per 16 bytes
         const float* img = p.in + (size_t)b * g.IH * g.IW * g.C;
@@ -1204,56 +1262,8 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
             }
         }
     }
-
-    // weight stages (identical to the direct form)
-    constexpr int PIECES = 2 * NB * 4;
-    constexpr int PPT = (PIECES + 255) / 256;
-    const __bf16* wg = wsplit;
-    u32x4 breg[PDGS][PPT];
-    auto load_b = [&](int s0) {
-#pragma unroll
-        for (int st = 0; st < PDGS; ++st) {
-            const int wo = kd[s0 + st].woff;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const int pc = tid + 256 * j;
-                const int pl = pc / (NB * 4);
-                const int row = (pc / 4) % NB;
-                const int qtr = pc & 3;
-                const int nrow = n0 + row < npad ? n0 + row : 0;
-                breg[st][j] = *reinterpret_cast<const u32x4*>(wg + (size_t)pl * plane + wo + nrow * BK + qtr * 8);
-            }
-        }
-    };
-    auto store_b = [&](__bf16* dst) {
-#pragma unroll
-        for (int st = 0; st < PDGS; ++st)
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const int pc = tid + 256 * j;
-                const int pl = pc / (NB * 4);
-                const int row = (pc / 4) % NB;
-                const int qtr = pc & 3;
-                *reinterpret_cast<u32x4*>(dst + st * STEP_E + (pl * NB + row) * BROW + qtr * 8) = breg[st][j];
-            }
-    };
-
-    // this lane's tile position and its A-fragment base inside the patch
-    const int ml = wave * 32 + i;
-    const int ty = ml >> tw_log2, tx = ml & (TW - 1);
-    const int abase = (ty * PW + tx) * PS + 8 * h;
-    const int gy = y0 + ty, gx = x0 + tx;
-    const int rowoff = (gy < g.OH && gx < g.OW) ? ((b * g.OH + gy) * g.OW + gx) * g.N : -1;
-
-    f32x16 acc[RN];
-#pragma unroll
-    for (int r = 0; r < RN; ++r)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-
     __syncthreads();                 // kd table visible
-    load_b(0);
-    store_b(Bs);
+    store_b(Bs, breg[0]);
     __syncthreads();                 // patch + first weight stage visible
 
     bf16x8 ah[2][2], al[2][2];       // [register set][k16 half]
@@ -1279,22 +1289,23 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
             }
     };
 
-    read_a(0, 0);
-    int stage = 0;
-    for (int s0 = 0; s0 < nsteps; s0 += PDGS) {
-        const __bf16* bcur = Bs + stage * BTILE;
-        const bool more = s0 + PDGS < nsteps;
-        if (more) load_b(s0 + PDGS);                    // in flight during the MFMAs below
+    static_assert(PDGS == 2, "the A-fragment register sets below alternate per k-step of a 2-step stage");
+    read_a(0, 0);                    // kd[] is padded by PDGS zero entries: reads one step past the end stay inside it
+    for (int t0 = 0; t0 < nstages; t0 += NSET) {
 #pragma unroll
-        for (int st = 0; st < PDGS; ++st) {
-            if (s0 + st < nsteps) {
-                if (s0 + st + 1 < nsteps) read_a(s0 + st + 1, (st + 1) & 1);   // next step's fragments
-                mma(bcur + st * STEP_E, st & 1);
-            }
+        for (int u = 0; u < NSET; ++u) {
+            const int t = t0 + u;
+            if (t >= nstages) break;
+            const int s0 = t * PDGS;
+            const __bf16* bcur = Bs + (u & 1) * BTILE;
+            load_b(t + 3, breg[(u + 3) & 3]);               // consumed three stages from now
+            read_a(s0 + 1, 1);
+            mma(bcur, 0);
+            read_a(s0 + 2, 0);                              // first step of the next stage (a padding entry after the last)
+            if (s0 + 1 < nsteps) mma(bcur + STEP_E, 1);
+            store_b(Bs + ((u + 1) & 1) * BTILE, breg[(u + 1) & 3]);   // stage t+1, loaded two stages ago
+            __syncthreads();
         }
-        if (more) store_b(Bs + (stage ^ 1) * BTILE);
-        __syncthreads();
-        stage ^= 1;
     }
 
     const float* bias = p.bias;

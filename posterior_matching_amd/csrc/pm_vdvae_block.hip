@@ -85,6 +85,11 @@ __device__ __forceinline__ void vb_store_split(__bf16* hi, __bf16* lo, int off, 
     lo[off] = (__bf16)(v - (float)h);
 }
 
+constexpr int MAXBLK = 4;        // Blocks of one geometry (same B, H, W, mid, k3) per launch: blockIdx.y picks one
+struct MultiArgs {
+    BlockArgs b[MAXBLK];
+};
+
 // the few integers the helpers need, copied out of the kernel-argument block into registers (handing the by-value argument
 // struct itself to the helpers made the compiler spill it to scratch memory: every field read became a private-memory load)
 struct Dims {
@@ -475,8 +480,9 @@ __device__ __forceinline__ void row_offsets(const Dims a, int img0, const Stage&
 }
 
 // =================================================== forward ===================================================================
-__global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
+__global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(MultiArgs multi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const BlockArgs& ka = multi.b[blockIdx.y];               // independent Blocks of one geometry share a launch
     const Dims a{ka.B, ka.H, ka.W, ka.mid, ka.k3};
     const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
     const float* __restrict__ xin = ka.xin;
@@ -590,8 +596,9 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(BlockArgs ka) {
 // stage T2: dg2 = c3^T(dh3) on s2 rows, dh2 = dg2 * gelu'(h2) -> band 2
 // stage T3: dg1 = c2^T(dh2) on s3 rows, dh1 = dg1 * gelu'(h1) -> band 1
 // stage T4: dxg = dh1 W1^T (N = Cin) [* gelu'(xpre)] [+ res]
-__global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(BlockArgs ka) {
+__global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(MultiArgs multi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const BlockArgs& ka = multi.b[blockIdx.y];               // independent Blocks of one geometry share a launch
     const Dims a{ka.B, ka.H, ka.W, ka.mid, ka.k3};
     const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
     const float* __restrict__ xin = ka.xin;
@@ -707,20 +714,24 @@ bool plan_block(int B, int H, int W, int k3, BandPlan& bp) {
     return bp.lds <= 158 * 1024;
 }
 
-int launch_block(hipStream_t stream, bool backward, BlockArgs& a) {
+int launch_blocks(hipStream_t stream, bool backward, MultiArgs& m, int n) {
     BandPlan bp;
-    if (!plan_block(a.B, a.H, a.W, a.k3, bp)) return PM_EINVAL;
-    a.R = bp.R; a.NI = bp.NI; a.bands = bp.bands;
-    const unsigned grid = (unsigned)(((a.B + a.NI - 1) / a.NI) * a.bands);
+    const BlockArgs& a0 = m.b[0];
+    if (n < 1 || n > MAXBLK || !plan_block(a0.B, a0.H, a0.W, a0.k3, bp)) return PM_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        if (m.b[i].B != a0.B || m.b[i].H != a0.H || m.b[i].W != a0.W || m.b[i].mid != a0.mid || m.b[i].k3 != a0.k3) return PM_EINVAL;
+        m.b[i].R = bp.R; m.b[i].NI = bp.NI; m.b[i].bands = bp.bands;
+    }
+    const unsigned grid = (unsigned)(((a0.B + bp.NI - 1) / bp.NI) * bp.bands);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdvae_block_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         attr_set = true;
     }
-    if (backward) hipLaunchKernelGGL(vdvae_block_bwd_kernel, dim3(grid), dim3(NTHR), bp.lds, stream, a);
-    else hipLaunchKernelGGL(vdvae_block_fwd_kernel, dim3(grid), dim3(NTHR), bp.lds, stream, a);
-    return pm_check_launch(backward ? "pm_vdvae_block_bwd" : "pm_vdvae_block_fwd");
+    if (backward) hipLaunchKernelGGL(vdvae_block_bwd_kernel, dim3(grid, n), dim3(NTHR), bp.lds, stream, m);
+    else hipLaunchKernelGGL(vdvae_block_fwd_kernel, dim3(grid, n), dim3(NTHR), bp.lds, stream, m);
+    return pm_check_launch(backward ? "pm_vdvae_blocks_bwd" : "pm_vdvae_blocks_fwd");
 }
 
 bool block_shape_ok(int B, int H, int W, int Cin, int Cout, int mid, int k3) {
@@ -730,38 +741,53 @@ bool block_shape_ok(int B, int H, int W, int Cin, int Cout, int mid, int k3) {
 
 }  // namespace
 
-extern "C" int pm_vdvae_block_fwd(pm_stream_t stream, const float* xg, const float* res, const void* const* wsplit,
-                                  const long long* planes, const float* const* bias, float* const* h, float* const* g, float* out,
-                                  int B, int H, int W, int Cin, int Cout, int mid, int k3, const float* x2, int Ca, float* xg_out) {
-    if (!xg || !wsplit || !planes || !bias || !h || !g || !out || !block_shape_ok(B, H, W, Cin, Cout, mid, k3)) return PM_EINVAL;
-    // xg_out != NULL: `xg` (and x2) are the RAW inputs, Ca channels from xg and Cin - Ca from x2; gelu is applied on load
-    if (xg_out && (Ca <= 0 || Ca > Cin || Ca % 8 != 0 || (Ca < Cin && (!x2 || Ca % 32 != 0)))) return PM_EINVAL;
-    BlockArgs a;
-    a.xin = xg; a.res = res; a.xpre = nullptr; a.out = out;
-    a.xin2 = xg_out && Ca < Cin ? x2 : nullptr; a.xg_out = xg_out; a.Ca = xg_out ? Ca : Cin; a.gelu_in = xg_out ? 1 : 0;
-    for (int i = 0; i < 3; ++i) { a.hh[i] = h[i]; a.gg[i] = g[i]; if (!h[i] || !g[i]) return PM_EINVAL; }
+static bool fill_fwd(BlockArgs& a, const pm_vdvae_block_io& io, int B, int H, int W, int mid, int k3) {
+    if (!io.x || !io.out || !block_shape_ok(B, H, W, io.Cin, io.Cout, mid, k3)) return false;
+    // xg_out != NULL: x (and x2) are the RAW inputs, Ca channels from x and Cin - Ca from x2; gelu is applied on load
+    if (io.xg_out && (io.Ca <= 0 || io.Ca > io.Cin || io.Ca % 8 != 0 || (io.Ca < io.Cin && (!io.x2 || io.Ca % 32 != 0)))) return false;
+    a.xin = io.x; a.res = io.res; a.xpre = nullptr; a.out = io.out;
+    a.xin2 = io.xg_out && io.Ca < io.Cin ? io.x2 : nullptr; a.xg_out = io.xg_out; a.Ca = io.xg_out ? io.Ca : io.Cin;
+    a.gelu_in = io.xg_out ? 1 : 0;
+    for (int i = 0; i < 3; ++i) { a.hh[i] = io.h[i]; a.gg[i] = io.g[i]; if (!io.h[i] || !io.g[i]) return false; }
     for (int i = 0; i < 4; ++i) {
-        a.w[i] = reinterpret_cast<const __bf16*>(wsplit[i]); a.plane[i] = planes[i]; a.bias[i] = bias[i];
-        if (!wsplit[i] || !bias[i]) return PM_EINVAL;
+        a.w[i] = reinterpret_cast<const __bf16*>(io.w[i]); a.plane[i] = io.plane[i]; a.bias[i] = io.bias[i];
+        if (!io.w[i] || !io.bias[i]) return false;
     }
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.mid = mid; a.k3 = k3;
-    PM_KTAG("vdvae_block_fwd_kernel");
-    return launch_block((hipStream_t)stream, false, a);
+    a.B = B; a.H = H; a.W = W; a.Cin = io.Cin; a.Cout = io.Cout; a.mid = mid; a.k3 = k3;
+    return true;
 }
 
-extern "C" int pm_vdvae_block_bwd(pm_stream_t stream, const float* dout, const float* res, const float* xpre,
-                                  const void* const* wsplit_dgrad, const long long* planes, float* const* h, float* const* dh,
-                                  float* dxg, int B, int H, int W, int Cin, int Cout, int mid, int k3) {
-    if (!dout || !wsplit_dgrad || !planes || !h || !dh || !dxg || !block_shape_ok(B, H, W, Cin, Cout, mid, k3)) return PM_EINVAL;
-    BlockArgs a;
-    a.xin = dout; a.res = res; a.xpre = xpre; a.out = dxg;
-    a.xin2 = nullptr; a.xg_out = nullptr; a.Ca = Cout; a.gelu_in = 0;
-    for (int i = 0; i < 3; ++i) { a.hh[i] = h[i]; a.gg[i] = dh[i]; if (!h[i] || !dh[i]) return PM_EINVAL; }
+static bool fill_bwd(BlockArgs& a, const pm_vdvae_block_io& io, int B, int H, int W, int mid, int k3) {
+    if (!io.x || !io.out || !block_shape_ok(B, H, W, io.Cin, io.Cout, mid, k3)) return false;
+    a.xin = io.x; a.res = io.res; a.xpre = io.xpre; a.out = io.out;       // x = dout, out = dxg
+    a.xin2 = nullptr; a.xg_out = nullptr; a.Ca = io.Cout; a.gelu_in = 0;
+    for (int i = 0; i < 3; ++i) { a.hh[i] = io.h[i]; a.gg[i] = io.g[i]; if (!io.h[i] || !io.g[i]) return false; }
     for (int i = 0; i < 4; ++i) {
-        a.w[i] = reinterpret_cast<const __bf16*>(wsplit_dgrad[i]); a.plane[i] = planes[i]; a.bias[i] = nullptr;
-        if (!wsplit_dgrad[i]) return PM_EINVAL;
+        a.w[i] = reinterpret_cast<const __bf16*>(io.w[i]); a.plane[i] = io.plane[i]; a.bias[i] = nullptr;
+        if (!io.w[i]) return false;
     }
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.mid = mid; a.k3 = k3;
+    a.B = B; a.H = H; a.W = W; a.Cin = io.Cin; a.Cout = io.Cout; a.mid = mid; a.k3 = k3;
+    return true;
+}
+
+extern "C" int pm_vdvae_blocks_fwd(pm_stream_t stream, const pm_vdvae_block_io* blocks, int nblocks, int B, int H, int W, int mid,
+                                   int k3) {
+    if (!blocks || nblocks < 1 || nblocks > MAXBLK) return PM_EINVAL;
+    MultiArgs m;
+    for (int i = 0; i < nblocks; ++i)
+        if (!fill_fwd(m.b[i], blocks[i], B, H, W, mid, k3)) return PM_EINVAL;
+    for (int i = nblocks; i < MAXBLK; ++i) m.b[i] = m.b[0];
+    PM_KTAG("vdvae_block_fwd_kernel");
+    return launch_blocks((hipStream_t)stream, false, m, nblocks);
+}
+
+extern "C" int pm_vdvae_blocks_bwd(pm_stream_t stream, const pm_vdvae_block_io* blocks, int nblocks, int B, int H, int W, int mid,
+                                   int k3) {
+    if (!blocks || nblocks < 1 || nblocks > MAXBLK) return PM_EINVAL;
+    MultiArgs m;
+    for (int i = 0; i < nblocks; ++i)
+        if (!fill_bwd(m.b[i], blocks[i], B, H, W, mid, k3)) return PM_EINVAL;
+    for (int i = nblocks; i < MAXBLK; ++i) m.b[i] = m.b[0];
     PM_KTAG("vdvae_block_bwd_kernel");
-    return launch_block((hipStream_t)stream, true, a);
+    return launch_blocks((hipStream_t)stream, true, m, nblocks);
 }

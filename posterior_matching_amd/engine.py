@@ -343,8 +343,18 @@ class PMVQVAETrainStep(_PlannedStep):
         s = self.store
         self.forward(True)
         ops.fill_zero(s.flat_g)
+        # the 4 x num_resnet gated blocks repeat a handful of layer shapes: their weight gradients (and the partial encoder's)
+        # are collected and launched at the end, one table-driven grouped launch per geometry (ops.WgradBatch)
+        batched = s.use_bf16 and not os.environ.get("PM_NO_WGRAD_BATCH")
+        if batched:
+            if getattr(self, "_wgrad_batch", None) is None:
+                self._wgrad_batch = ops.WgradBatch()
+            self.ws.wgrad_batch = self._wgrad_batch
         dcond = self.pcnn.backward(self.g_ll)
         self.penc.backward(dcond)
+        if batched:
+            self.ws.wgrad_batch.flush()
+            self.ws.wgrad_batch = None
         self.ws.join_aux()
         if self.world_size > 1:
             self.reducer.finish()

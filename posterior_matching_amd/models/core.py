@@ -259,9 +259,15 @@ class Module:
     def wgrad(self, *args, **kw) -> None:
         """ops.layer_wgrad on the companion stream of the current stream (ordered after everything
         enqueued so far on the current stream)."""
+        kw.setdefault("bf16", self.store.use_bf16)
+        batch = self.ws.wgrad_batch
+        if batch is not None and len(args) == 5 and set(kw) <= {"bf16", "in_act"}:
+            g, x, dy, dw, db = args
+            if ops.WgradBatch.eligible(g, g._desc(x.shape[0], "wgrad")):     # joins the end-of-backward launch of its geometry
+                batch.add(g, x, dy, dw, db, kw["bf16"], kw.get("in_act", ACT_NONE))
+                return
         cur = torch.cuda.current_stream(self.ws.device)
         aux = self.ws.aux_stream()
-        kw.setdefault("bf16", self.store.use_bf16)
         if aux is cur or aux == cur:
             ops.layer_wgrad(*args, **kw)
             return

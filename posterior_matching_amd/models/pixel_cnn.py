@@ -276,8 +276,9 @@ class PixelCNN(Module):
         dlogits = self.buf("dlogits", sh(K))
         ops.categorical_ll_bwd(self._logits.view(R, K), self._value.reshape(-1), self._lse, g_ll, dlogits.view(R, K), P)
         self._wg(self.out_conv, self.buf("x_out", sh(F)), dlogits)
-        self.ws.join_aux()
-        self.store.grads_ready([f"{self.prefix}/out_conv"])
+        if self.ws.wgrad_batch is None:
+            self.ws.join_aux()
+            self.store.grads_ready([f"{self.prefix}/out_conv"])
         dx_out = self.buf("dx_out", sh(F))
         self._dg(self.out_conv, dlogits, dx_out)
 
@@ -332,7 +333,7 @@ class PixelCNN(Module):
             dce1 = self.buf(f"{n}/dce1", sh(2 * F))
             self._dg(blk.conv1, dx1, dce1)
             ops.concat_elu_bwd(input_x, None, None, dce1, d_in, None, accumulate=True)
-            if self.store.reducer is not None:          # data-parallel: this block's weight gradients are final
+            if self.store.reducer is not None and self.ws.wgrad_batch is None:   # data-parallel: this block's weight gradients are final
                 self.ws.join_aux()
                 self.store.grads_ready([f"{self.prefix}/{n}/{leaf}" for leaf in ("conv1", "linear", "conv2")])
 

@@ -89,36 +89,67 @@ class Block(Module):
             return None
         return f, d
 
+    # -- the one-launch form: operands of this Block for ops.vdvae_blocks_fwd / _bwd (several independent Blocks of one
+    #    geometry - the three Blocks of a decoder block, the same Block of the two encoders - share a launch) ---------------
+    def fwd_io(self, x: torch.Tensor, x2: Optional[torch.Tensor], res: Optional[torch.Tensor], raw: bool):
+        B, H, W = x.shape[0], self.H, self.W
+        sh = lambda c: (B, H, W, c)   # noqa: E731
+        fused = self._fused()
+        if raw:
+            self._xg = self.buf("xg", sh(self.cin))
+        else:
+            self._xg = x
+        self._h = [self.buf(f"h{i + 1}", sh(self.mid)) for i in range(3)]
+        self._g = [self.buf(f"g{i + 1}", sh(self.mid)) for i in range(3)]
+        out = self.buf("out", sh(self.cout))
+        biases = [self.store.p[L.b] for L in (self.c1, self.c2, self.c3, self.c4)]
+        return ops.vdvae_block_io(x, self._h, self._g, out, fused[0], biases, x2=x2, res=res,
+                                  xg_out=self._xg if raw else None), out
+
+    def bwd_io(self, dout: torch.Tensor, dx: torch.Tensor, x_pre: Optional[torch.Tensor], res: Optional[torch.Tensor]):
+        B = dout.shape[0]
+        self._dhs = [self.buf(f"dh{i + 1}", (B, self.H, self.W, self.mid)) for i in range(3)]
+        self._dout = dout
+        return ops.vdvae_block_io(dout, self._h, self._dhs, dx, self._fused()[1], None, res=res if x_pre is not None else None,
+                                  xpre=x_pre, backward=True)
+
+    def weight_grads(self) -> None:
+        """the four weight / bias gradients after bwd_io's launch: deferred to the end of the backward pass (one launch per
+        geometry) when the model collects them, else launched now"""
+        dhs, dout = self._dhs, self._dout
+        pairs = ((self.c4, self._g[2], dout), (self.c3, self._g[1], dhs[2]), (self.c2, self._g[0], dhs[1]),
+                 (self.c1, self._xg, dhs[0]))
+        if self.ws.wgrad_batch is not None:
+            for L, xin, dy in pairs:
+                self.ws.wgrad_batch.add(L.g, xin, dy, self.store.g[L.w], self.store.g[L.b], self.store.use_bf16)
+            return
+        cur, aux = torch.cuda.current_stream(self.ws.device), self.ws.aux_stream()
+        if aux is not cur and aux != cur:
+            ops.wait_stream(aux, cur)               # ONE dependency per Block: its four weight gradients share a stream
+        with torch.cuda.stream(aux):
+            for L, xin, dy in pairs:
+                ops.layer_wgrad(L.g, xin, dy, self.store.g[L.w], self.store.g[L.b], bf16=self.store.use_bf16)
+
     def forward_raw(self, x: torch.Tensor, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         """the Block applied to the RAW input [x | x2] (reference :283: `x_hat = self.c1(jax.nn.gelu(x))`): in the one-launch form
         the gelu runs inside the kernel as the rows are loaded and gelu([x | x2]) is written out for the weight gradient;
         otherwise a gelu launch builds it first"""
         B, H, W = x.shape[0], self.H, self.W
-        fused = self._fused()
-        xg = self.buf("xg", (B, H, W, self.cin))
-        if fused is None or (x2 is not None and x.shape[-1] % 32 != 0):
+        if self._fused() is None or (x2 is not None and x.shape[-1] % 32 != 0):
+            xg = self.buf("xg", (B, H, W, self.cin))
             ops.gelu_fwd(x, x2, xg)
             return self.forward(xg, res=res)
-        sh = lambda c: (B, H, W, c)   # noqa: E731
-        self._xg = xg
-        self._h = [self.buf(f"h{i + 1}", sh(self.mid)) for i in range(3)]
-        self._g = [self.buf(f"g{i + 1}", sh(self.mid)) for i in range(3)]
-        out = self.buf("out", sh(self.cout))
-        biases = [self.store.p[L.b] for L in (self.c1, self.c2, self.c3, self.c4)]
-        ops.vdvae_block_fwd(x, res, fused[0], biases, self._h, self._g, out, self.c2.g.k, x2=x2, xg_out=xg)
+        io, out = self.fwd_io(x, x2, res, raw=True)
+        ops.vdvae_blocks_fwd([io], B, H, W, self.mid, self.c2.g.k)
         return out
 
     def forward(self, xg: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, H, W = xg.shape[0], self.H, self.W
         self._xg = xg
         sh = lambda c: (B, H, W, c)   # noqa: E731
-        fused = self._fused()
-        if fused is not None:            # the four convolutions and the three gelus between them in ONE launch
-            self._h = [self.buf(f"h{i + 1}", sh(self.mid)) for i in range(3)]
-            self._g = [self.buf(f"g{i + 1}", sh(self.mid)) for i in range(3)]
-            out = self.buf("out", sh(self.cout))
-            biases = [self.store.p[L.b] for L in (self.c1, self.c2, self.c3, self.c4)]
-            ops.vdvae_block_fwd(xg, res, fused[0], biases, self._h, self._g, out, self.c2.g.k)
+        if self._fused() is not None:    # the four convolutions and the three gelus between them in ONE launch
+            io, out = self.fwd_io(xg, None, res, raw=False)
+            ops.vdvae_blocks_fwd([io], B, H, W, self.mid, self.c2.g.k)
             return out
         self._h, self._g = [], []
         x = xg
@@ -142,24 +173,11 @@ class Block(Module):
         sh = lambda c: (B, self.H, self.W, c)   # noqa: E731
         d = dout
         layers = (self.c1, self.c2, self.c3, self.c4)
-        fused = self._fused()
-        if fused is not None:
+        if self._fused() is not None:
             # the four data gradients (with the gelu' factors between them) in ONE launch; the four weight gradients follow:
             # they read the stored g1..g3 / dh1..dh3 and only feed the optimizer
-            dhs = [self.buf(f"dh{i + 1}", sh(self.mid)) for i in range(3)]
-            ops.vdvae_block_bwd(dout, res if x_pre is not None else None, x_pre, fused[1], self._h, dhs, dx, self.c2.g.k)
-            cur, aux = torch.cuda.current_stream(self.ws.device), self.ws.aux_stream()
-            pairs = ((self.c4, self._g[2], dout), (self.c3, self._g[1], dhs[2]), (self.c2, self._g[0], dhs[1]),
-                     (self.c1, self._xg, dhs[0]))
-            if self.ws.wgrad_batch is not None:     # launched at the end of the backward pass, one launch per geometry
-                for L, xin, dy in pairs:
-                    self.ws.wgrad_batch.add(L.g, xin, dy, self.store.g[L.w], self.store.g[L.b], self.store.use_bf16)
-                return
-            if aux is not cur and aux != cur:
-                ops.wait_stream(aux, cur)           # ONE dependency per Block: its four weight gradients share a stream
-            with torch.cuda.stream(aux):
-                for L, xin, dy in pairs:
-                    ops.layer_wgrad(L.g, xin, dy, self.store.g[L.w], self.store.g[L.b], bf16=self.store.use_bf16)
+            ops.vdvae_blocks_bwd([self.bwd_io(dout, dx, x_pre, res)], B, self.H, self.W, self.mid, self.c2.g.k)
+            self.weight_grads()
             return
         for i in (3, 2, 1):
             L = layers[i]
@@ -203,53 +221,107 @@ class Encoder(Module):
             if down is not None:
                 res = res // down
 
-    def __call__(self, x: torch.Tensor) -> Dict[int, torch.Tensor]:
+    # The pass is written as steps (stem, per-Block operands, per-Block bookkeeping) so that the two encoders of the model can
+    # walk their Blocks in lockstep and share ONE launch per Block index (run_encoders / run_encoders_backward below).
+    def _begin(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0]
         self._x = x
         g = self.stem.g
         h = self.buf("stem_out", (B, g.OH, g.OW, g.CO))
         ops.layer_forward(g, x, self.store.p[self.stem.w], self.store.p[self.stem.b], h,
                           wsplit=self.store.split_view(self.stem.ws_f))
-        acts = {h.shape[1]: h}
+        self._acts = {h.shape[1]: h}
         self._ins, self._outs = [], []
+        return h
+
+    def _after_block(self, i: int, h: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        blk, down, res = self.blocks[i]
+        self._ins.append(h)
+        if down is not None:
+            pooled = self.buf(f"block_{i}/pooled", (h.shape[0], res // down, res // down, self.width))
+            ops.avgpool_fwd(out, pooled, down)
+            out = pooled
+        self._outs.append(out)
+        self._acts[out.shape[1]] = out
+        return out
+
+    def __call__(self, x: torch.Tensor) -> Dict[int, torch.Tensor]:
+        h = self._begin(x)
         for i, (blk, down, res) in enumerate(self.blocks):
-            out = blk.forward_raw(h, None, res=h)
-            self._ins.append(h)
-            if down is not None:
-                pooled = self.buf(f"block_{i}/pooled", (B, res // down, res // down, self.width))
-                ops.avgpool_fwd(out, pooled, down)
-                out = pooled
-            self._outs.append(out)
-            h = out
-            acts[h.shape[1]] = h
-        self._acts = acts
-        return acts
+            h = self._after_block(i, h, blk.forward_raw(h, None, res=h))
+        return self._acts
+
+    def _bwd_begin(self, dacts: Dict[int, torch.Tensor]) -> None:
+        self._exported = {t.data_ptr(): r for r, t in self._acts.items()}
+        self._dacts, self._dh = dacts, None
+
+    def _bwd_block_args(self, i: int):
+        """-> (dout, dx, x_pre) of Block i: the gradient arriving at its output (exported-activation gradients and the
+        pooling undone), where its input gradient goes, its raw input"""
+        blk, down, res = self.blocks[i]
+        out = self._outs[i]
+        r_out = self._exported.get(out.data_ptr())
+        dh = self._dh
+        if r_out is not None:
+            if dh is None:
+                dh = self._dacts[r_out]
+            else:
+                ops.axpy1(self._dacts[r_out], dh)
+        if down is not None:
+            dfull = self.buf(f"block_{i}/dfull", tuple(blk._xg.shape[:3]) + (self.width,))
+            ops.avgpool_bwd(dh, dfull, down)
+            dh = dfull
+        dprev = self.buf(f"block_{i}/dx", tuple(self._ins[i].shape))
+        self._dh = dprev
+        return dh, dprev, self._ins[i]
+
+    def _bwd_end(self) -> None:
+        dh = self._dh
+        r0 = self._exported.get(self._ins[0].data_ptr())
+        if r0 is not None:
+            ops.axpy1(self._dacts[r0], dh)
+        self.wgrad(self.stem.g, self._x, dh, self.store.g[self.stem.w], self.store.g[self.stem.b])
 
     def backward(self, dacts: Dict[int, torch.Tensor]) -> None:
         """dacts[res]: gradient w.r.t. the exported activation of each resolution (from the decoder)."""
-        exported = {t.data_ptr(): r for r, t in self._acts.items()}
-        dh = None
+        self._bwd_begin(dacts)
         for i in reversed(range(len(self.blocks))):
-            blk, down, res = self.blocks[i]
-            out = self._outs[i]
-            r_out = exported.get(out.data_ptr())
-            if r_out is not None:
-                if dh is None:
-                    dh = dacts[r_out]
-                else:
-                    ops.axpy1(dacts[r_out], dh)
-            if down is not None:
-                dfull = self.buf(f"block_{i}/dfull", tuple(blk._xg.shape[:3]) + (self.width,))
-                ops.avgpool_bwd(dh, dfull, down)
-                dh = dfull
-            dprev = self.buf(f"block_{i}/dx", tuple(self._ins[i].shape))
-            blk.backward(dh, dprev, x_pre=self._ins[i], res=dh)
-            dh = dprev
-        stem_out = self._ins[0]
-        r0 = exported.get(stem_out.data_ptr())
-        if r0 is not None:
-            ops.axpy1(dacts[r0], dh)
-        self.wgrad(self.stem.g, self._x, dh, self.store.g[self.stem.w], self.store.g[self.stem.b])
+            dout, dx, x_pre = self._bwd_block_args(i)
+            self.blocks[i][0].backward(dout, dx, x_pre=x_pre, res=dout)
+        self._bwd_end()
+
+
+def _pairable(e: "Encoder", m: "Encoder") -> bool:
+    return (len(e.blocks) == len(m.blocks) and all(be._fused() is not None and bm._fused() is not None and be.H == bm.H
+                                                   for (be, _, _), (bm, _, _) in zip(e.blocks, m.blocks)))
+
+
+def run_encoders(e: "Encoder", m: "Encoder", x: torch.Tensor, xm: torch.Tensor):
+    """both encoders of the model (reference vdvae.py:77-80) walked in lockstep: Block i of the two is ONE launch"""
+    he, hm = e._begin(x), m._begin(xm)
+    B = x.shape[0]
+    for i in range(len(e.blocks)):
+        be, bm = e.blocks[i][0], m.blocks[i][0]
+        io_e, oe = be.fwd_io(he, None, he, raw=True)
+        io_m, om = bm.fwd_io(hm, None, hm, raw=True)
+        ops.vdvae_blocks_fwd([io_e, io_m], B, be.H, be.W, be.mid, be.c2.g.k)
+        he, hm = e._after_block(i, he, oe), m._after_block(i, hm, om)
+    return e._acts, m._acts
+
+
+def run_encoders_backward(e: "Encoder", m: "Encoder", dacts, dmacts) -> None:
+    e._bwd_begin(dacts)
+    m._bwd_begin(dmacts)
+    for i in reversed(range(len(e.blocks))):
+        be, bm = e.blocks[i][0], m.blocks[i][0]
+        de, dxe, xe = e._bwd_block_args(i)
+        dm, dxm, xm = m._bwd_block_args(i)
+        ops.vdvae_blocks_bwd([be.bwd_io(de, dxe, xe, de), bm.bwd_io(dm, dxm, xm, dm)], de.shape[0], be.H, be.W, be.mid,
+                             be.c2.g.k)
+        be.weight_grads()
+        bm.weight_grads()
+    e._bwd_end()
+    m._bwd_end()
 
 
 class PosteriorMatchingDecoderBlock(Module):
@@ -278,15 +350,24 @@ class PosteriorMatchingDecoderBlock(Module):
         sh = lambda c: (B, r, r, c)   # noqa: E731
         self._x_in, self._acts, self._macts, self._eps = x_in, acts, macts, eps
         main = torch.cuda.current_stream(x_in.device)
+        self._grouped = all(b._fused() is not None for b in (self.posterior, self.masked_posterior, self.prior)) and W % 32 == 0
+        if self._grouped:
+            # the three Blocks only share x_in: ONE launch (blockIdx.y picks the Block), no companion streams
+            io_p, self._pp = self.posterior.fwd_io(x_in, acts, None, raw=True)
+            io_m, self._mp = self.masked_posterior.fwd_io(x_in, macts, None, raw=True)   # stop_gradient(x): see backward
+            io_r, self._pr = self.prior.fwd_io(x_in, None, None, raw=True)
+            ops.vdvae_blocks_fwd([io_p, io_m, io_r], B, r, r, self.posterior.mid, self.posterior.c2.g.k)
+            streams = None
         s1, s2 = streams if streams is not None else (main, main)
         if streams is not None:
             ops.wait_stream(s1, main)
             ops.wait_stream(s2, main)
-        with torch.cuda.stream(s1):
-            self._mp = self.masked_posterior.forward_raw(x_in, macts)   # stop_gradient(x): handled in backward (:536-538)
-        with torch.cuda.stream(s2):
-            self._pr = self.prior.forward_raw(x_in)
-        self._pp = self.posterior.forward_raw(x_in, acts)
+        if not self._grouped:
+            with torch.cuda.stream(s1):
+                self._mp = self.masked_posterior.forward_raw(x_in, macts)   # stop_gradient(x): handled in backward (:536-538)
+            with torch.cuda.stream(s2):
+                self._pr = self.prior.forward_raw(x_in)
+            self._pp = self.posterior.forward_raw(x_in, acts)
         if streams is not None:
             ops.wait_stream(main, s1)
             ops.wait_stream(main, s2)
@@ -405,6 +486,16 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.copy_cols(dx2, dpr, 2 * Z)                                            # d h = d x1
         dmp = self.buf("dmp", tuple(self._mp.shape))
         ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, P)
+        if getattr(self, "_grouped", False):
+            da, dam, dxin = self.buf("da", sh(2 * W)), self.buf("dam", sh(2 * W)), self.buf("dxin", sh(W))
+            ios = [self.posterior.bwd_io(dpp, da, None, None), self.masked_posterior.bwd_io(dmp, dam, None, None),
+                   self.prior.bwd_io(dpr, dxin, self._x_in, dx2)]           # prior: + the direct x1 = x_in + h path
+            ops.vdvae_blocks_bwd(ios, B, r, r, self.posterior.mid, self.posterior.c2.g.k)
+            for blk in (self.posterior, self.masked_posterior, self.prior):
+                blk.weight_grads()
+            ops.gelu_bwd(self._x_in, self._macts, dam, None, dmacts, accumulate=True)   # no gradient into stop_gradient(x)
+            ops.gelu_bwd(self._x_in, self._acts, da, dxin, dacts, accumulate=True)
+            return dxin
         if streams is not None:
             ops.wait_stream(s1, main)
             ops.wait_stream(s2, main)
@@ -509,7 +600,10 @@ class PosteriorMatchingVDVAE(Module):
         ops.mask_concat(xn, b, xob)
         streams = self._branch_streams(x.device)
         main = torch.cuda.current_stream(x.device)
-        if streams is not None:
+        self._paired = _pairable(self.encoder, self.masked_encoder)
+        if self._paired:
+            acts, macts = run_encoders(self.encoder, self.masked_encoder, xn, xob)
+        elif streams is not None:
             ops.wait_stream(streams[0], main)
             with torch.cuda.stream(streams[0]):
                 macts = self.masked_encoder(xob)
@@ -750,7 +844,12 @@ class PosteriorMatchingVDVAE(Module):
                 # x_in was the previous block of this resolution's output, and this block its only consumer (mix-in
                 # sources are always the LAST state of a coarser resolution): hand dxin over as that block's dx3
                 dxs[r] = dxin
-        if streams is not None:
+        if getattr(self, "_paired", False):
+            if streams is not None:
+                ops.wait_stream(main, streams[0])
+                ops.wait_stream(main, streams[1])
+            run_encoders_backward(self.encoder, self.masked_encoder, dacts, dmacts)
+        elif streams is not None:
             s1, s2 = streams
             ops.wait_stream(s1, s2)                       # dmacts were accumulated on s2
             ops.wait_stream(s1, main)

@@ -551,14 +551,20 @@ class WgradBatch:
         self.items = {}          # key -> [(geom, x, dy, dw, db)]
         self._tables = {}        # (key, pointer tuple) -> (device table, aligned flag)
 
-    def add(self, g: LayerGeom, x, dy, dw, db, bf16: bool) -> None:
+    def add(self, g: LayerGeom, x, dy, dw, db, bf16: bool, in_act: int = ACT_NONE) -> None:
         if g.kind == "convT":
             raise NotImplementedError("deferred weight gradients of transposed convolutions")
         B = x.shape[0]
         d = g._desc(B, "wgrad")
         use_bf16 = bool(bf16 and USE_BF16_WGRAD and d.C % 32 == 0 and d.N % 4 == 0 and d.d in (1, 2))
-        key = (B, g.IH, g.IW, g.CI, g.OH, g.OW, g.CO, g.KH, g.KW, g.s, g.pad, g.full_kh, g.full_kw, use_bf16, db is not None)
+        key = (B, g.kind, g.IH, g.IW, g.CI, g.OH, g.OW, g.CO, g.KH, g.KW, g.s, g.pad, g.pad_x, g.full_kh, g.full_kw, in_act,
+               use_bf16, db is not None)
         self.items.setdefault(key, []).append((g, x, dy, dw, db))
+
+    @staticmethod
+    def eligible(g: LayerGeom, d: GatherDesc) -> bool:
+        """shapes the grouped kernels serve: the MFMA weight-gradient forms (not the 1- / 2-channel lane kernels)"""
+        return g.kind != "convT" and not _lane_form(d)
 
     def flush(self) -> None:
         for key, lst in self.items.items():
@@ -576,6 +582,7 @@ class WgradBatch:
                 self._tables[(key, ptrs)] = cached
             table, aligned = cached
             d = g0._desc(key[0], "wgrad", groups=len(lst))
+            d.in_act = key[-3]
             tag = work = None
             if _timer is not None:
                 tag = "gather_wgrad_table"
@@ -972,28 +979,49 @@ def vdvae_block_fused_ok(B: int, H: int, W: int, cin: int, cout: int, mid: int, 
     return cin % 8 == 0 and cout % 8 == 0 and mid % 8 == 0 and mid <= 48 and W <= 62 and k3 in (1, 3)
 
 
-def vdvae_block_fwd(xg, res, wsplits, biases, hs, gs, out, k3: int, x2=None, xg_out=None) -> None:
-    """csrc/pm_vdvae_block.hip: c1..c4 of a Block in one launch (wsplits: the four layers' forward split views).
-    xg_out given: `xg` (and `x2`) are the RAW inputs [x | x2]; gelu runs inside the kernel and gelu([x | x2]) lands in xg_out."""
-    B, H, W, ca = xg.shape
-    cin = ca + (x2.shape[-1] if x2 is not None else 0)
-    cout, mid = out.shape[-1], hs[0].shape[-1]
-    planes = (C.c_longlong * 4)(*[w.numel() // 2 for w in wsplits])
-    flops = 2.0 * B * H * W * (cin * mid + 2 * k3 * k3 * mid * mid + mid * cout)
-    _call("pm_vdvae_block_fwd", _ptr(xg), _ptr(res), _ptr_array(wsplits), planes, _ptr_array(biases), _ptr_array(hs),
-          _ptr_array(gs), _ptr(out), B, H, W, cin, cout, mid, k3, _ptr(x2), ca, _ptr(xg_out), tag="vdvae_block_fwd_kernel",
-          work={"flops": flops, "bytes": _nbytes(xg, res, out, *hs, *gs), "detail": f"B{B} {H}x{W} {cin}->{mid}->{cout} k{k3}"})
+def _dp(t):
+    return t.data_ptr() if t is not None else None
 
 
-def vdvae_block_bwd(dout, res, xpre, wsplits_d, hs, dhs, dxg, k3: int) -> None:
-    """the four data gradients of a Block in one launch (wsplits_d: the layers' data-gradient split views, c1..c4)"""
-    B, H, W, cout = dout.shape
-    cin, mid = dxg.shape[-1], hs[0].shape[-1]
-    planes = (C.c_longlong * 4)(*[w.numel() // 2 for w in wsplits_d])
-    flops = 2.0 * B * H * W * (cin * mid + 2 * k3 * k3 * mid * mid + mid * cout)
-    _call("pm_vdvae_block_bwd", _ptr(dout), _ptr(res), _ptr(xpre), _ptr_array(wsplits_d), planes, _ptr_array(hs),
-          _ptr_array(dhs), _ptr(dxg), B, H, W, cin, cout, mid, k3, tag="vdvae_block_bwd_kernel",
-          work={"flops": flops, "bytes": _nbytes(dout, res, xpre, dxg, *hs, *dhs), "detail": f"B{B} {H}x{W} {cin}<-{mid}<-{cout} k{k3}"})
+def vdvae_block_io(x, hs, gs, out, wsplits, biases=None, x2=None, res=None, xpre=None, xg_out=None, backward: bool = False):
+    """one Block's operands for vdvae_blocks_fwd / _bwd (struct pm_vdvae_block_io).  fwd: x = gelu(input) (or the raw input
+    with xg_out), gs = g1..g3, out = Block output;  bwd: x = dout, gs = dh1..dh3, out = dxg."""
+    io = _lib.VdvaeBlockIO()
+    io._keep = (x, x2, res, xpre, xg_out, hs, gs, out, wsplits, biases)      # the tensors outlive the launch plan entry
+    if backward:
+        io.Cin, io.Cout, io.Ca = out.shape[-1], x.shape[-1], x.shape[-1]
+    else:
+        io.Ca = x.shape[-1]
+        io.Cin, io.Cout = io.Ca + (x2.shape[-1] if x2 is not None else 0), out.shape[-1]
+    io.x, io.x2, io.res, io.xpre, io.xg_out = _ptr(x), _ptr(x2), _ptr(res), _ptr(xpre), _ptr(xg_out)
+    for i in range(3):
+        io.h[i], io.g[i] = _ptr(hs[i]), _ptr(gs[i])
+    io.out = _ptr(out)
+    for i in range(4):
+        io.w[i] = wsplits[i].data_ptr()
+        io.plane[i] = wsplits[i].numel() // 2
+        io.bias[i] = _ptr(biases[i]) if biases is not None else None
+    return io
+
+
+def _blocks_call(fname, ios, B, H, W, mid, k3, tag, flops, nbytes):
+    arr = (_lib.VdvaeBlockIO * len(ios))(*ios)
+    _call(fname, arr, len(ios), B, H, W, mid, k3, tag=tag,
+          work={"flops": flops, "bytes": nbytes, "detail": f"B{B} {H}x{W} mid{mid} k{k3} x{len(ios)}"})
+
+
+def vdvae_blocks_fwd(ios, B: int, H: int, W: int, mid: int, k3: int) -> None:
+    """csrc/pm_vdvae_block.hip: c1..c4 of up to four independent Blocks of one geometry in ONE launch"""
+    flops = sum(2.0 * B * H * W * (io.Cin * mid + 2 * k3 * k3 * mid * mid + mid * io.Cout) for io in ios)
+    nbytes = sum(4.0 * B * H * W * (io.Cin + io.Cout + 6 * mid) for io in ios)
+    _blocks_call("pm_vdvae_blocks_fwd", ios, B, H, W, mid, k3, "vdvae_block_fwd_kernel", flops, nbytes)
+
+
+def vdvae_blocks_bwd(ios, B: int, H: int, W: int, mid: int, k3: int) -> None:
+    """the four data gradients of up to four independent Blocks in ONE launch"""
+    flops = sum(2.0 * B * H * W * (io.Cin * mid + 2 * k3 * k3 * mid * mid + mid * io.Cout) for io in ios)
+    nbytes = sum(4.0 * B * H * W * (io.Cin + io.Cout + 6 * mid) for io in ios)
+    _blocks_call("pm_vdvae_blocks_bwd", ios, B, H, W, mid, k3, "vdvae_block_bwd_kernel", flops, nbytes)
 
 
 def diag_sample_kl_fwd(post, prior, eps, z, kl, P: int) -> None:
