@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
     constexpr int STEP_E = 2 * NB * BROW;               // bf16 elements of one k-step in LDS (hi rows, lo rows)
     constexpr int BTILE = DGS * STEP_E;                 // one stage
     constexpr int TL_F = (sizeof(TapList) + 3) / 4;
-    constexpr int KD_F = DMAXSTEPS * (sizeof(KStepB) / 4);
+    constexpr int KD_F = (DMAXSTEPS + 8) * (sizeof(KStepB) / 4);   // + zero entries the prefetches run into
     __shared__ __attribute__((aligned(16))) float smem[BTILE + KD_F + TL_F];   // 2 stages of bf16 = BTILE floats
     __bf16* Bs = reinterpret_cast<__bf16*>(smem);
     KStepB* kd = reinterpret_cast<KStepB*>(smem + BTILE);
@@ -1230,6 +1230,7 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
     load_b(1, breg[1]);
     load_b(2, breg[2]);
     // (the first three weight stages are in flight while the patch is staged)
+#if !(defined(PM_EXP) && PM_EXP == 21)
     {   // the patch: f32 -> hi / lo bf16, zero outside the image.  Loads are issued in batches of 8 per thread so
         // that a workgroup pays ~2 global latencies for its patch instead of one per 16 bytes
         const float* img = p.in + (size_t)b * g.IH * g.IW * g.C;
@@ -1262,6 +1263,7 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
             }
         }
     }
+#endif
     __syncthreads();                 // kd table visible
     store_b(Bs, breg[0]);
     __syncthreads();                 // patch + first weight stage visible
@@ -1290,21 +1292,48 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
     };
 
     static_assert(PDGS == 2, "the A-fragment register sets below alternate per k-step of a 2-step stage");
+    // The patch loads above sit under per-lane branches, so the compiler cannot prove them complete and would drain vmcnt
+    // at the top of the k-loop on every trip; the patch is needed here anyway: one explicit vmcnt(0) settles its bookkeeping.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     read_a(0, 0);                    // kd[] is padded by PDGS zero entries: reads one step past the end stay inside it
-    for (int t0 = 0; t0 < nstages; t0 += NSET) {
-#pragma unroll
-        for (int u = 0; u < NSET; ++u) {
-            const int t = t0 + u;
-            if (t >= nstages) break;
-            const int s0 = t * PDGS;
-            const __bf16* bcur = Bs + (u & 1) * BTILE;
-            load_b(t + 3, breg[(u + 3) & 3]);               // consumed three stages from now
-            read_a(s0 + 1, 1);
-            mma(bcur, 0);
-            read_a(s0 + 2, 0);                              // first step of the next stage (a padding entry after the last)
-            if (s0 + 1 < nsteps) mma(bcur + STEP_E, 1);
-            store_b(Bs + ((u + 1) & 1) * BTILE, breg[(u + 1) & 3]);   // stage t+1, loaded two stages ago
-            __syncthreads();
+    // one stage; u = stage index mod NSET is a compile-time constant at every call site so that the register sets are static
+    auto stage = [&](int t, auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const int s0 = t * PDGS;
+        const __bf16* bcur = Bs + (u & 1) * BTILE;
+#if !(defined(PM_EXP) && PM_EXP == 24)
+        load_b(t + 3, breg[(u + 3) & 3]);                   // consumed three stages from now
+#endif
+        read_a(s0 + 1, 1);
+        mma(bcur, 0);
+        read_a(s0 + 2, 0);                                  // first step of the next stage (a padding entry after the last)
+        if (s0 + 1 < nsteps) mma(bcur + STEP_E, 1);
+#if !(defined(PM_EXP) && PM_EXP == 24)
+        store_b(Bs + ((u + 1) & 1) * BTILE, breg[(u + 1) & 3]);       // stage t+1, loaded two stages ago
+        __syncthreads();
+#endif
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    using U3 = std::integral_constant<int, 3>;
+    // full groups of NSET stages without exits (an early exit inside the group lands in the loop latch, whose merged
+    // wait-count state drains vmcnt at the top of every trip), then the 0 - 3 remaining stages as straight-line code
+    int t0 = 0;
+#if defined(PM_EXP) && PM_EXP == 22
+    t0 = nstages;
+#endif
+    for (; t0 + NSET <= nstages; t0 += NSET) {
+        stage(t0, U0{});
+        stage(t0 + 1, U1{});
+        stage(t0 + 2, U2{});
+        stage(t0 + 3, U3{});
+    }
+    if (t0 < nstages) {
+        stage(t0, U0{});
+        if (t0 + 1 < nstages) {
+            stage(t0 + 1, U1{});
+            if (t0 + 2 < nstages) stage(t0 + 2, U2{});
         }
     }
 
@@ -1320,12 +1349,197 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
         int n = n0 + r * 32 + i;
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
+#if defined(PM_EXP) && PM_EXP == 23
+        if (acc[r][0] == 12345.f)
+#endif
         pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
     }
 }
 
+// The same tile, weights straight to registers.  Dissection of the LDS-staged form above on the 28x28 32->32 5x5 layer
+// (64 us; -DPM_EXP builds): patch staging 14 us, epilogue 9 us, k-loop 36 us of which 12 us are the weight stages (global
+// -> registers -> LDS -> barrier every two k-steps) - for an operand that every wave reads in full anyway (a wave's B
+// fragment of a k-step IS the whole 32-column stage).  Here each wave loads its own B fragments from the pre-split copy
+// (16 bytes per lane and fragment, served by L1 after the first wave), NSET k-steps ahead in static register sets: no LDS
+// stores, no barriers in the k-loop, waves drift freely; LDS holds only the patch, so three workgroups fit a CU.
+template <int RN>
+__global__ __launch_bounds__(256, RN == 1 ? 3 : 2) void patch_conv_bd_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
+                                                                 long long plane, int tw_log2) {
+    constexpr int NSET = 4;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    KStepB* kd = reinterpret_cast<KStepB*>(dsm);
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int n0 = blockIdx.y * 32 * RN;
+    const int TW = 1 << tw_log2, TH = 128 >> tw_log2;
+    const int PH = TH + g.KH - 1, PW = TW + g.KW - 1;
+    const int PS = g.C + 8;                                             // bf16 per patch position (16 B pad)
+    const int cch = g.C / BK;
+    const int nsteps = g.KH * g.KW * cch;
+    __bf16* Ph = reinterpret_cast<__bf16*>(dsm) + (size_t)(nsteps + 2) * (sizeof(KStepB) / 2);
+    __bf16* Pl = Ph + (size_t)PH * PW * PS;
+
+    const int tiles_x = (g.OW + TW - 1) >> tw_log2;
+    const int tiles_y = (g.OH + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = tyi * TH, x0 = txi << tw_log2;
+    const int sy0 = y0 + g.off + (g.cs < 0 ? -(g.KH - 1) : 0);
+    const int sx0 = x0 + g.offx + (g.cs < 0 ? -(g.KW - 1) : 0);
+
+    // B fragment of (k-step s, column tile r, half kk, plane): 16 bytes at ((s * npad + n) * 32 + 16 kk + 8 h); q = 2 kk + plane
+    bf16x8 bq[NSET][RN][4];
+    int ncl[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r) ncl[r] = (n0 + 32 * r + i < npad ? n0 + 32 * r + i : 0) * BK + 8 * h;
+    auto load_b = [&](int s, bf16x8 (&bb)[RN][4]) {
+        const int sc = s < nsteps ? s : nsteps - 1;
+        const __bf16* base = wsplit + (size_t)sc * npad * BK;
+#pragma unroll
+        for (int r = 0; r < RN; ++r) {
+            const __bf16* src = base + ncl[r];
+            bb[r][0] = *reinterpret_cast<const bf16x8*>(src);
+            bb[r][1] = *reinterpret_cast<const bf16x8*>(src + plane);
+            bb[r][2] = *reinterpret_cast<const bf16x8*>(src + 16);
+            bb[r][3] = *reinterpret_cast<const bf16x8*>(src + plane + 16);
+        }
+    };
+    load_b(0, bq[0]);
+    load_b(1, bq[1]);
+    load_b(2, bq[2]);
+    load_b(3, bq[3]);
+    float bvr[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r) bvr[r] = p.bias ? p.bias[n0 + 32 * r + i < g.N ? n0 + 32 * r + i : 0] : 0.f;
+
+    for (int s = tid; s < nsteps + 2; s += 256) {
+        KStepB k{0, 0, 0, 0};
+        if (s < nsteps) {
+            const int tap = s / cch, cc = s - tap * cch;
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            k.dy = g.cs > 0 ? ky : g.KH - 1 - ky;
+            k.dx = g.cs > 0 ? kx : g.KW - 1 - kx;
+            k.c0 = cc * BK;
+        }
+        kd[s] = k;
+    }
+    {   // the patch: f32 -> hi / lo bf16, zero outside the image; 12 loads per thread in flight: one round trip for the
+        // patches of the 28x28 layers (9 per thread), two for 64-channel ones
+        const float* img = p.in + (size_t)b * g.IH * g.IW * g.C;
+        const int c4n = g.C >> 2;
+        const int total = PH * PW * c4n;
+        constexpr int PB = 12;
+        for (int e0 = tid; e0 < total; e0 += 256 * PB) {
+            f32x4 v[PB];
+            int dst[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int e = e0 + 256 * j;
+                const int ee = e < total ? e : total - 1;
+                const int pos = ee / c4n, c4 = ee - pos * c4n;
+                const int py = pos / PW, px = pos - py * PW;
+                const int gy = sy0 + py, gx = sx0 + px;
+                const bool ok = e < total && (unsigned)gy < (unsigned)g.IH && (unsigned)gx < (unsigned)g.IW;
+                const size_t so = ok ? ((size_t)gy * g.IW + gx) * g.C + 4 * c4 : 0;
+                v[j] = *reinterpret_cast<const f32x4*>(img + so);
+                if (!ok) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dst[j] = e < total ? pos * PS + 4 * c4 : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                if (dst[j] < 0) continue;
+                u32x2 h2, l2;
+                split4(v[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + dst[j]) = h2;
+                *reinterpret_cast<u32x2*>(Pl + dst[j]) = l2;
+            }
+        }
+    }
+
+    const int ml = wave * 32 + i;
+    const int ty = ml >> tw_log2, tx = ml & (TW - 1);
+    const int abase = (ty * PW + tx) * PS + 8 * h;
+    const int gy = y0 + ty, gx = x0 + tx;
+    const int rowoff = (gy < g.OH && gx < g.OW) ? ((b * g.OH + gy) * g.OW + gx) * g.N : -1;
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    // the patch loads sit under per-lane branches: one explicit vmcnt(0) (the patch is needed here anyway) keeps the
+    // compiler from draining vmcnt inside the k-loop
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();                 // patch + kd visible; the only barrier of the kernel
+
+    bf16x8 ah[2][2], al[2][2];       // [register set][k16 half]
+    auto read_a = [&](int s, int set) {
+        const KStepB k = kd[s];
+        const int o = abase + (k.dy * PW + k.dx) * PS + k.c0;
+        ah[set][0] = *reinterpret_cast<const bf16x8*>(Ph + o);
+        ah[set][1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
+        al[set][0] = *reinterpret_cast<const bf16x8*>(Pl + o);
+        al[set][1] = *reinterpret_cast<const bf16x8*>(Pl + o + 16);
+    };
+    auto step = [&](int s, auto uc) {
+        constexpr int u = decltype(uc)::value;
+        read_a(s + 1, (u + 1) & 1);                         // kd[] has two zero entries past the end
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u & 1][kk], bq[u][r][2 * kk + 1], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
+            }
+        load_b(s + NSET, bq[u]);                            // NSET k-steps ahead (clamped at the end)
+        __builtin_amdgcn_sched_barrier(0);                  // or the scheduler sinks the loads until the distance is gone
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    using U3 = std::integral_constant<int, 3>;
+    read_a(0, 0);
+    int s0 = 0;
+    for (; s0 + NSET <= nsteps; s0 += NSET) {               // exit-free groups, then 0 - 3 steps as straight-line code
+        step(s0, U0{});
+        step(s0 + 1, U1{});
+        step(s0 + 2, U2{});
+        step(s0 + 3, U3{});
+    }
+    if (s0 < nsteps) {
+        step(s0, U0{});
+        if (s0 + 1 < nsteps) {
+            step(s0 + 1, U1{});
+            if (s0 + 2 < nsteps) step(s0 + 2, U2{});
+        }
+    }
+
+    const float* aux = p.aux;
+    const float* res = p.res;
+    float* out = p.out;
+    int ro[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ro[e] = __shfl(rowoff, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
+#pragma unroll
+    for (int r = 0; r < RN; ++r) {
+        int n = n0 + r * 32 + i;
+        if (n >= g.N) continue;
+        pm_epilogue_tile(acc[r], ro, n, bvr[r], aux, res, out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
+    }
+}
+
 // host-side plan of the patch form: tile shape and dynamic LDS size; returns false when the problem does not qualify
-struct PatchPlan { int tw_log2; size_t lds; dim3 grid; };
+struct PatchPlan { int tw_log2; size_t lds, lds_bd; dim3 grid; };
 bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
     if (groups != 1 || g.a != 1 || g.d != 1 || g.C % BK != 0 || g.in_act != PM_ACT_NONE) return false;
     if (g.KH * g.KW < 4 || g.OW < 12 || g.OH < 4) return false;        // 1x1 / tiny grids: the direct form is fine
@@ -1340,9 +1554,232 @@ bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
     const size_t kdb = (size_t)(nsteps + PDGS) * sizeof(KStepB);
     const size_t patch = (size_t)(TH + g.KH - 1) * (TW + g.KW - 1) * (g.C + 8) * 2 * 2;
     pp.lds = bt + kdb + patch;
+    pp.lds_bd = (size_t)(nsteps + 2) * sizeof(KStepB) + patch;          // weights-to-registers form: no weight stages
     if (pp.lds > 150 * 1024) return false;
     pp.grid = dim3((unsigned)(g.B * tiles_y * tiles_x), (g.N + NB - 1) / NB, 1);
     return true;
+}
+
+// ------------------- d = 1 convolutions with the WHOLE input image of a workgroup resident in LDS (bf16x3) -------------------
+// The patch form above re-stages halos (a 4 x 32 output tile of a 5x5 layer loads an 8 x 36 patch: 2.25x the input), cuts
+// the batch into 1792 tiles for 512 - 768 workgroup slots (a 3.5-round grid runs 4 rounds) and has no stride-2 form at all
+// (those layers re-gather their rows from L2 once per tap in the direct form: 2.9x the operand bytes).  The images of this
+// path are small - 28 x 28 x 32 floats are 125 KB as hi / lo bf16 planes with the 16-byte position pad - so ONE workgroup
+// stages ONE image once (a plain linear, fully coalesced read), and B = 256 images are one round on 256 CUs:
+//  * any stride a (src = dst * a + tap * cs + off): an A fragment is a 16-byte LDS read at the tap's input position; taps that
+//    fall outside the image read a zero slot (one select on the address), so there is no padded border in LDS;
+//  * output positions are walked in flat order (32 consecutive positions = one MFMA row tile - no 2-D tile shape is needed
+//    when the whole image is resident); a wave owns one 32-column tile and up to T row tiles, and a B fragment - loaded
+//    straight from the pre-split weights, four k-steps ahead, like patch_conv_bd - feeds all T of them;
+//  * one barrier (after staging); waves run the k-loop and their epilogues independently.
+template <int NW, int T>
+__global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
+                                                                     long long plane, int nct) {
+    constexpr int NSET = 4;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int b = blockIdx.x;
+    const int PS = g.C + 8;                                             // bf16 per input position (16 B pad)
+    const int cch = g.C / BK;
+    const int nsteps = g.KH * g.KW * cch;
+    const int npos = g.IH * g.IW;
+    KStepB* kd = reinterpret_cast<KStepB*>(dsm);                        // [nsteps + 2]
+    __bf16* Ph = reinterpret_cast<__bf16*>(dsm) + (size_t)(nsteps + 2) * (sizeof(KStepB) / 2);
+    __bf16* Pl = Ph + (size_t)npos * PS + 64;                           // 64 zero elements (128 B) behind each plane
+    const int zoff = npos * PS;                                         // the zero slot of a plane
+
+    // this wave: column tile ct, row tiles rt0 + j * wct
+    const int wct = NW / nct;                                           // waves per column tile
+    const int ct = wave / wct, rt0 = wave - ct * wct;
+    const int Mi = g.OH * g.OW;
+    const int n = ct * 32 + i;
+    const int ncl = (n < npad ? n : 0) * BK + 8 * h;
+
+    bf16x8 bq[NSET][4];                                                 // [set][2 kk + plane]
+    auto load_b = [&](int s, bf16x8 (&bb)[4]) {
+        const int sc = s < nsteps ? s : nsteps - 1;
+        const __bf16* src = wsplit + (size_t)sc * npad * BK + ncl;
+        bb[0] = *reinterpret_cast<const bf16x8*>(src);
+        bb[1] = *reinterpret_cast<const bf16x8*>(src + plane);
+        bb[2] = *reinterpret_cast<const bf16x8*>(src + 16);
+        bb[3] = *reinterpret_cast<const bf16x8*>(src + plane + 16);
+    };
+    load_b(0, bq[0]);
+    load_b(1, bq[1]);
+    load_b(2, bq[2]);
+    load_b(3, bq[3]);
+    const float bv = p.bias ? p.bias[n < g.N ? n : 0] : 0.f;
+
+    for (int s = tid; s < nsteps + 2; s += 64 * NW) {
+        KStepB k{0, 0, 0, 0};
+        if (s < nsteps) {
+            const int tap = s / cch, cc = s - tap * cch;
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            k.dy = ky * g.cs;
+            k.dx = kx * g.cs;
+            k.c0 = cc * BK;
+        }
+        kd[s] = k;
+    }
+    if (tid < 32) {                                                     // the zero slots
+        reinterpret_cast<unsigned*>(Ph + zoff)[tid] = 0u;
+        reinterpret_cast<unsigned*>(Pl + zoff)[tid] = 0u;
+    }
+    {   // the image: f32 -> in_act -> hi / lo bf16; a linear read, 8 float4 per thread in flight
+        const float* img = p.in + (size_t)b * npos * g.C;
+        const int c4n = g.C >> 2;
+        const int total = npos * c4n;
+        const bool in_relu = g.in_act == PM_ACT_RELU;
+        const float in_ns = g.in_act == PM_ACT_LEAKY ? g.slope : 1.f;
+        constexpr int PB = 8;
+        for (int e0 = tid; e0 < total; e0 += 64 * NW * PB) {
+            f32x4 v[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int e = e0 + 64 * NW * j;
+                v[j] = *reinterpret_cast<const f32x4*>(img + 4 * (size_t)(e < total ? e : total - 1));
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int e = e0 + 64 * NW * j;
+                const int ee = e < total ? e : total - 1;               // the overhang rewrites the last piece: harmless
+                const int pos = ee / c4n, c4 = ee - pos * c4n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = v[j][q];
+                    const float neg = in_relu ? 0.f : x * in_ns;
+                    v[j][q] = x >= 0.f ? x : neg;
+                }
+                u32x2 h2, l2;
+                split4(v[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + pos * PS + 4 * c4) = h2;
+                *reinterpret_cast<u32x2*>(Pl + pos * PS + 4 * c4) = l2;
+            }
+        }
+    }
+
+    // per row tile: this lane's A row = output position m -> top-left input coordinate of its receptive field
+    int py[T], px[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int m = 32 * (rt0 + j * wct) + i;
+        const int oy = m / g.OW, ox = m - oy * g.OW;
+        py[j] = m < Mi ? oy * g.a + g.off : ROW_INVALID;
+        px[j] = ox * g.a + g.offx;
+    }
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    __syncthreads();                 // image + kd visible; the only barrier of the kernel
+
+    bf16x8 a[2][4];                  // [register set][hi kk0, hi kk1, lo kk0, lo kk1]
+    auto read_a = [&](int s, int j, bf16x8 (&aa)[4]) {
+        const KStepB k = kd[s];
+        const int iy = py[j] + k.dy, ix = px[j] + k.dx;
+        const bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+        const int o = (ok ? (iy * g.IW + ix) * PS + k.c0 : zoff) + 8 * h;
+        aa[0] = *reinterpret_cast<const bf16x8*>(Ph + o);
+        aa[1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
+        aa[2] = *reinterpret_cast<const bf16x8*>(Pl + o);
+        aa[3] = *reinterpret_cast<const bf16x8*>(Pl + o + 16);
+    };
+    auto step = [&](int s, auto uc) {
+        constexpr int u = decltype(uc)::value;                          // s mod NSET
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int cur = (u * T + j) & 1;
+            if (j + 1 < T) read_a(s, j + 1, a[cur ^ 1]);
+            else read_a(s + 1, 0, a[cur ^ 1]);                          // kd[] has two zero entries past the end
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], bq[u][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][2], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][3], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][3], bq[u][2], acc[j], 0, 0, 0);
+        }
+        load_b(s + NSET, bq[u]);                                        // NSET k-steps ahead (clamped at the end)
+        __builtin_amdgcn_sched_barrier(0);                              // or the scheduler sinks the loads behind later MFMAs
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    using U3 = std::integral_constant<int, 3>;
+    static_assert((NSET * T) % 2 == 0, "A register sets alternate per (k-step, row tile)");
+    if (rt0 * 32 < Mi) {                                                // wave-uniform: waves without a row tile skip it all
+        read_a(0, 0, a[0]);
+        int s0 = 0;
+        for (; s0 + NSET <= nsteps; s0 += NSET) {                       // exit-free groups, then 0 - 3 steps straight-line
+            step(s0, U0{});
+            step(s0 + 1, U1{});
+            step(s0 + 2, U2{});
+            step(s0 + 3, U3{});
+        }
+        if (s0 < nsteps) {
+            step(s0, U0{});
+            if (s0 + 1 < nsteps) {
+                step(s0 + 1, U1{});
+                if (s0 + 2 < nsteps) step(s0 + 2, U2{});
+            }
+        }
+        if (n < g.N) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                int ro[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = 32 * (rt0 + j * wct) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ro[e] = m < Mi ? (b * Mi + m) * g.N : -1;
+                }
+                pm_epilogue_tile(acc[j], ro, n, bv, p.aux, p.res, p.out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
+            }
+        }
+    }
+}
+
+struct ImagePlan { int nw, t, nct; size_t lds; };
+// qualifies: plain d = 1 problems (any stride a) whose input image fits LDS as hi / lo planes, batches that fill the chip
+bool plan_image(const Geom& g, int groups, ImagePlan& ip) {
+    if (groups != 1 || g.d != 1 || g.C % BK != 0 || g.B < 128) return false;
+    if (g.in_act != PM_ACT_NONE && g.in_act != PM_ACT_RELU && g.in_act != PM_ACT_LEAKY) return false;
+    if (g.KH * g.KW < 4 || g.kws != g.KW) return false;                 // 1x1: the dense form; masked sub-kernels: direct form
+    const int nsteps = g.KH * g.KW * (g.C / BK);
+    if (nsteps > 2048) return false;
+    ip.lds = (size_t)(nsteps + 2) * sizeof(KStepB) + 2 * ((size_t)g.IH * g.IW * (g.C + 8) + 64) * 2;
+    if (ip.lds > 158 * 1024) return false;
+    ip.nct = (g.N + 31) / 32;
+    if (ip.nct > 8 || (8 % ip.nct) != 0) return false;
+    const int rt = (g.OH * g.OW + 31) / 32;
+    ip.nw = rt * ip.nct <= 4 ? 4 : 8;
+    if (ip.nw % ip.nct != 0) return false;
+    const int wct = ip.nw / ip.nct;
+    int t = (rt + wct - 1) / wct;
+    if (t > 4) return false;
+    ip.t = t == 3 ? 4 : t;
+    return true;
+}
+
+template <int NW, int T>
+void launch_image(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const __bf16* ws, int npad, long long plane) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&image_conv_bf16_kernel<NW, T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    PM_KTAG("image_conv_bf16_kernel<%d, %d>", NW, T);
+    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T>), dim3((unsigned)a.g.B), dim3(64 * NW), ip.lds, s, a, ws, npad, plane,
+                       ip.nct);
 }
 
 // ------------- zero-dilated (d = 2) problems, patch-staged with the four residue classes fused -------------
@@ -2726,6 +3163,18 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
         if (rn == 2 && wgs64 < rn2_min) rn = 1;
     }
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
+    ImagePlan ip;
+    static const bool image_off = getenv("PM_NO_IMAGE_CONV") != nullptr;   // A/B switch for measurements
+    if (!image_off && plan_image(a.g, G, ip)) {       // whole input image of a workgroup resident in LDS
+        a.ksplit = 1;
+        if (ip.nw == 8 && ip.t == 4) launch_image<8, 4>(ip, s, a, ws, npad, plane);
+        else if (ip.nw == 8 && ip.t == 2) launch_image<8, 2>(ip, s, a, ws, npad, plane);
+        else if (ip.nw == 8) launch_image<8, 1>(ip, s, a, ws, npad, plane);
+        else if (ip.t == 4) launch_image<4, 4>(ip, s, a, ws, npad, plane);
+        else if (ip.t == 2) launch_image<4, 2>(ip, s, a, ws, npad, plane);
+        else launch_image<4, 1>(ip, s, a, ws, npad, plane);
+        return pm_check_launch("pm_gather_gemm_bf16(image)");
+    }
     PatchPlan pp;
     static const bool patch_off = getenv("PM_NO_PATCH") != nullptr;      // A/B switch for measurements
     if (!patch_off && plan_patch(a.g, G, rn, pp)) {   // stride-1 convs on grids >= 12 wide: patch-staged form
@@ -2737,6 +3186,21 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_bf16_kernel<2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_set = true;
+        }
+        static const bool bd_off = getenv("PM_NO_PATCH_BD") != nullptr;     // A/B switch for measurements
+        if (!bd_off) {
+            static bool attr_bd = false;
+            if (!attr_bd) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_bd_bf16_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_bd_bf16_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                attr_bd = true;
+            }
+            PM_KTAG("patch_conv_bd_bf16_kernel<%d>", rn);
+            if (rn == 1) hipLaunchKernelGGL(patch_conv_bd_bf16_kernel<1>, pp.grid, dim3(256), pp.lds_bd, s, a, ws, npad, plane, pp.tw_log2);
+            else hipLaunchKernelGGL(patch_conv_bd_bf16_kernel<2>, pp.grid, dim3(256), pp.lds_bd, s, a, ws, npad, plane, pp.tw_log2);
+            return pm_check_launch("pm_gather_gemm_bf16(patch_bd)");
         }
         PM_KTAG("patch_conv_bf16_kernel<%d>", rn);
         if (rn == 1) hipLaunchKernelGGL(patch_conv_bf16_kernel<1>, pp.grid, dim3(256), pp.lds, s, a, ws, npad, plane, pp.tw_log2);

@@ -207,6 +207,11 @@ class ResidualMLP(Module):
         return all(self._wsf(f"block_{k}/linear_{j}") is not None and self._wsd(f"block_{k}/linear_{j}") is not None
                    for k in range(self._residual_blocks) for j in range(2))
 
+    def _chain_ok(self, rows: int) -> bool:
+        import os
+
+        return not os.environ.get("PM_NO_MLP_CHAIN") and ops.mlp_chain_ok(rows, self._hidden_units)
+
     def out_grad_buffer(self, rows: int) -> torch.Tensor:
         """where the caller should write the gradient w.r.t. this network's output so that backward() needs no copy"""
         nb, hu = self._residual_blocks, self._hidden_units
@@ -324,6 +329,19 @@ class ResidualMLP(Module):
                           wsplit=self._wsf("linear_0"))
         self._h, self._u = [h], []
         fused = self._pair_fused()
+        if fused and self._chain_ok(rows):
+            # up to two blocks (four layers) per launch, activations of a 64-row tile kept in LDS (pm_mlp_chain_bf16)
+            for k0 in range(0, nb, 2):
+                ks = list(range(k0, min(k0 + 2, nb)))
+                names = [f"block_{k}/linear_{j}" for k in ks for j in range(2)]
+                outs = [xs[2 * k + 1 + j] for k in ks for j in range(2)]
+                ops.mlp_chain_bf16(xs[2 * k0], [self._wsf(n) for n in names], [self.P(n + "/b") for n in names], None, outs,
+                                   ACT_RELU, ACT_RELU, ACT_NONE)
+            for k in range(nb):
+                self._u.append(xs[2 * k + 1])
+                self._h.append(xs[2 * k + 2])
+            h = xs[2 * nb]
+            nb = 0                                      # nothing left for the per-block loop below
         for k in range(nb):
             u = xs[2 * k + 1]
             hn = xs[2 * k + 2]
@@ -358,7 +376,21 @@ class ResidualMLP(Module):
             if grouped and dh.data_ptr() != dys[2 * nb - 1].data_ptr():
                 ops.copy_cols(dh.reshape(rows, hu), dys[2 * nb - 1], 0)   # callers that did not use out_grad_buffer()
                 dh = dys[2 * nb - 1]
-        for k in reversed(range(nb)):
+        nloop = nb
+        if grouped and self._pair_fused() and self._chain_ok(rows):
+            # all data gradients of up to two blocks per launch; outputs land in dys (du_k, dh_k) for the grouped wgrad
+            dh0 = self.buf("dh_0", (rows, hu))
+            k_hi = nb - 1
+            while k_hi >= 0:
+                ks = [k for k in (k_hi, k_hi - 1) if k >= 0]
+                names = [f"block_{k}/linear_{j}" for k in ks for j in (1, 0)]
+                auxs = [t for k in ks for t in (self._u[k], self._h[k])]
+                outs = [t for k in ks for t in (dys[2 * k], dys[2 * k - 1] if k > 0 else dh0)]
+                ops.mlp_chain_bf16(dh, [self._wsd(n) for n in names], None, auxs, outs, ACT_NONE, ACT_NONE, ACT_RELU)
+                dh = outs[-1]
+                k_hi -= 2
+            nloop = 0
+        for k in reversed(range(nloop)):
             h, u = self._h[k], self._u[k]
             if not grouped:
                 self.wgrad(self.g_hid, u, dh, self.G(f"block_{k}/linear_1/w"), self.G(f"block_{k}/linear_1/b"),

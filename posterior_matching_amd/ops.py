@@ -798,6 +798,29 @@ def mlp_pair_bf16(x, w1_split, w2_split, b1, b2, aux1, aux2, out1, out2, in_act,
           work=work)
 
 
+def mlp_chain_ok(rows: int, hidden: int) -> bool:
+    """preconditions of pm_mlp_chain_bf16: hidden width 256, whole 64-row tiles"""
+    return hidden == 256 and rows % 64 == 0
+
+
+def mlp_chain_bf16(x, w_splits, biases, auxs, outs, in_act, mid_act, aux_act) -> None:
+    """csrc/pm_mlp.hip: up to four stacked 256 -> 256 layers of a ResidualMLP (two residual blocks, forward or data
+    gradient) in one launch; biases / auxs may be None (see include/pmhip.h)"""
+    L = len(w_splits)
+    R, hid = x.shape[0], x.shape[1]
+
+    def arr(ts):
+        if ts is None:
+            return None
+        return (C.c_void_p * L)(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+    for t in list(outs) + [a for a in (auxs or []) if a is not None]:
+        _ptr(t)                                                   # contiguity / dtype checks
+    work = {"flops": 2.0 * L * R * hid * hid, "bytes": _nbytes(x, *(auxs or []), *outs), "detail": f"B{R} {L}x({hid}->{hid})"}
+    _call("pm_mlp_chain_bf16", _ptr(x), L, arr(w_splits), arr(biases), arr(auxs), arr(outs), R, hid, in_act, mid_act, aux_act,
+          LEAKY_SLOPE, tag="mlp_chain_bf16_kernel", work=work)
+
+
 def layernorm_fwd(x, res, y, out, rstd, eps: float = 1e-5) -> None:
     """y = LayerNorm(x) over the last axis (no scale / offset); out = y + res when given (csrc/pm_mlp.hip)"""
     H = x.shape[-1]

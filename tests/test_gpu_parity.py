@@ -758,6 +758,73 @@ def test_layernorm_and_relu_dropout_kernels():
         assert torch.equal(dxx.cpu(), (g.float() * mask.float() * (x.float() > 0)))
 
 
+@pytest.mark.parametrize("L,R", [(2, 64), (4, 192), (3, 128)])
+def test_mlp_chain_kernel_matches_float64(L, R):
+    """pm_mlp_chain_bf16 (csrc/pm_mlp.hip): L stacked 256 -> 256 layers with the blocks' residuals, the forward form
+    (relu on load, biases) and the data-gradient form (relu'(aux) multipliers), against float64; and the two-layer
+    launches it replaces (pm_mlp_pair_bf16) must give the same numbers to float32 rounding."""
+    from posterior_matching_amd import ops
+    from posterior_matching_amd.models.core import ParamStore
+    from posterior_matching_amd.ops import ACT_NONE, ACT_RELU, LayerGeom
+
+    d, Hd = dev(), 256
+    gen = torch.Generator().manual_seed(11 + L)
+    g = LayerGeom.dense(Hd, Hd)
+    st = ParamStore()
+    for j in range(L):
+        st.add(f"w{j}", (Hd, Hd), fan_in=Hd)
+    hf = [st.request_split(f"w{j}", g, "fwd") for j in range(L)]
+    hd = [st.request_split(f"w{j}", g, "dgrad") for j in range(L)]
+    st.allocate(d)
+    W = [torch.randn((Hd, Hd), generator=gen, dtype=F64) / 16 for _ in range(L)]
+    st.load_dict({f"w{j}": W[j] for j in range(L)})
+    bias = [torch.randn(Hd, generator=gen, dtype=F64) * 0.1 for _ in range(L)]
+    aux = [torch.randn((R, Hd), generator=gen, dtype=F64) for _ in range(L)]
+    x = torch.randn((R, Hd), generator=gen, dtype=F64)
+    f32 = lambda t: t.float().to(d).contiguous()   # noqa: E731
+
+    # forward form
+    ref, a, res = [], torch.relu(x), x
+    for j in range(L):
+        o = a @ W[j] + bias[j]
+        if j & 1:
+            o = o + res
+            res = o
+        ref.append(o)
+        a = torch.relu(o)
+    outs = [torch.empty((R, Hd), device=d) for _ in range(L)]
+    ops.mlp_chain_bf16(f32(x), [st.split_view(h) for h in hf], [f32(b) for b in bias], None, outs, ACT_RELU, ACT_RELU, ACT_NONE)
+    torch.cuda.synchronize()
+    for j in range(L):
+        assert rel_err(outs[j], ref[j]) < 2e-5, ("fwd", j)
+
+    # data-gradient form: out_j = (A_j W_j^T) * relu'(aux_j) [+ residual], no activations between layers
+    ref, a, res = [], x, x
+    for j in range(L):
+        o = (a @ W[j].T) * (aux[j] > 0)
+        if j & 1:
+            o = o + res
+            res = o
+        ref.append(o)
+        a = o
+    outs_b = [torch.empty((R, Hd), device=d) for _ in range(L)]
+    auxd = [f32(t) for t in aux]
+    ops.mlp_chain_bf16(f32(x), [st.split_view(h) for h in hd], None, auxd, outs_b, ACT_NONE, ACT_NONE, ACT_RELU)
+    torch.cuda.synchronize()
+    for j in range(L):
+        assert rel_err(outs_b[j], ref[j]) < 2e-5, ("bwd", j)
+
+    if L % 2 == 0:      # the same arithmetic as the pair kernel, block by block
+        xin = f32(x)
+        for k in range(L // 2):
+            o1, o2 = torch.empty((R, Hd), device=d), torch.empty((R, Hd), device=d)
+            ops.mlp_pair_bf16(xin, st.split_view(hf[2 * k]), st.split_view(hf[2 * k + 1]), f32(bias[2 * k]),
+                              f32(bias[2 * k + 1]), None, None, o1, o2, ACT_RELU, ACT_RELU, ACT_NONE, ACT_NONE)
+            torch.cuda.synchronize()
+            assert rel_err(o1, outs[2 * k]) < 1e-6 and rel_err(o2, outs[2 * k + 1]) < 1e-6
+            xin = o2
+
+
 def _miniboone(B, seed):
     from tests.ref_configs import pm_vae_miniboone
 
