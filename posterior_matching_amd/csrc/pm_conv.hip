@@ -1588,8 +1588,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     const int cch = g.C / BK;
     const int nsteps = g.KH * g.KW * cch;
     const int npos = g.IH * g.IW;
-    KStepB* kd = reinterpret_cast<KStepB*>(dsm);                        // [nsteps + 2]
-    __bf16* Ph = reinterpret_cast<__bf16*>(dsm) + (size_t)(nsteps + 2) * (sizeof(KStepB) / 2);
+    __bf16* Ph = reinterpret_cast<__bf16*>(dsm);
     __bf16* Pl = Ph + (size_t)npos * PS + 64;                           // 64 zero elements (128 B) behind each plane
     const int zoff = npos * PS;                                         // the zero slot of a plane
 
@@ -1615,28 +1614,17 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     load_b(3, bq[3]);
     const float bv = p.bias ? p.bias[n < g.N ? n : 0] : 0.f;
 
-    for (int s = tid; s < nsteps + 2; s += 64 * NW) {
-        KStepB k{0, 0, 0, 0};
-        if (s < nsteps) {
-            const int tap = s / cch, cc = s - tap * cch;
-            const int ky = tap / g.KW, kx = tap - ky * g.KW;
-            k.dy = ky * g.cs;
-            k.dx = kx * g.cs;
-            k.c0 = cc * BK;
-        }
-        kd[s] = k;
-    }
     if (tid < 32) {                                                     // the zero slots
         reinterpret_cast<unsigned*>(Ph + zoff)[tid] = 0u;
         reinterpret_cast<unsigned*>(Pl + zoff)[tid] = 0u;
     }
-    {   // the image: f32 -> in_act -> hi / lo bf16; a linear read, 8 float4 per thread in flight
+    {   // the image: f32 -> in_act -> hi / lo bf16; a linear read, up to 13 float4 per thread in flight
         const float* img = p.in + (size_t)b * npos * g.C;
         const int c4n = g.C >> 2;
         const int total = npos * c4n;
         const bool in_relu = g.in_act == PM_ACT_RELU;
         const float in_ns = g.in_act == PM_ACT_LEAKY ? g.slope : 1.f;
-        constexpr int PB = 8;
+        constexpr int PB = NW == 8 ? 13 : 8;                             // 28 x 28 x 32 on 512 threads: 12.25 per thread
         for (int e0 = tid; e0 < total; e0 += 64 * NW * PB) {
             f32x4 v[PB];
 #pragma unroll
@@ -1679,11 +1667,26 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    __syncthreads();                 // image + kd visible; the only barrier of the kernel
+    __syncthreads();                 // image visible; the only barrier of the kernel
 
-    bf16x8 a[2][4];                  // [register set][hi kk0, hi kk1, lo kk0, lo kk1]
-    auto read_a = [&](int s, int j, bf16x8 (&aa)[4]) {
-        const KStepB k = kd[s];
+    // A fragments run TWO (k-step, row tile) items ahead of the MFMAs in four static register sets (item index mod 4); the
+    // tap walk (ky, kx, channel chunk) of the three k-steps in flight is kept in scalar registers - with the table lookup
+    // -> address -> fragment chain of the first form (LDS, VALU, LDS: ~300 clocks) one item ahead, every item waited
+    bf16x8 a[4][4];                  // [register set][hi kk0, hi kk1, lo kk0, lo kk1]
+    struct Tap { int dy, dx, c0; };
+    int wky = 0, wkx = 0, wcc = 0;   // the walk's position = the furthest k-step in flight
+    auto advance = [&]() -> Tap {
+        const Tap t{wky * g.cs, wkx * g.cs, wcc * BK};
+        if (++wcc == cch) {
+            wcc = 0;
+            if (++wkx == g.KW) {
+                wkx = 0;
+                ++wky;                                                   // past the last tap: coordinates nobody uses
+            }
+        }
+        return t;
+    };
+    auto read_a = [&](const Tap& k, int j, bf16x8 (&aa)[4]) {
         const int iy = py[j] + k.dy, ix = px[j] + k.dx;
         const bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
         const int o = (ok ? (iy * g.IW + ix) * PS + k.c0 : zoff) + 8 * h;
@@ -1692,15 +1695,14 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         aa[2] = *reinterpret_cast<const bf16x8*>(Pl + o);
         aa[3] = *reinterpret_cast<const bf16x8*>(Pl + o + 16);
     };
+    Tap t0, t1, t2;                  // taps of k-steps s, s+1, s+2
     auto step = [&](int s, auto uc) {
         constexpr int u = decltype(uc)::value;                          // s mod NSET
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int cur = (u * T + j) & 1;
-            if (j + 1 < T) read_a(s, j + 1, a[cur ^ 1]);
-            else read_a(s + 1, 0, a[cur ^ 1]);                          // kd[] has two zero entries past the end
+            const int cur = (u * T + j) & 3;
+            const int jn = j + 2;                                       // the item two ahead: (s + jn / T, jn % T)
+            read_a(jn / T == 0 ? t0 : jn / T == 1 ? t1 : t2, jn % T, a[(cur + 2) & 3]);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][0], acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][1], acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], bq[u][0], acc[j], 0, 0, 0);
@@ -1708,6 +1710,9 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][3], acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][3], bq[u][2], acc[j], 0, 0, 0);
         }
+        t0 = t1;
+        t1 = t2;
+        t2 = advance();
         load_b(s + NSET, bq[u]);                                        // NSET k-steps ahead (clamped at the end)
         __builtin_amdgcn_sched_barrier(0);                              // or the scheduler sinks the loads behind later MFMAs
     };
@@ -1715,9 +1720,13 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     using U1 = std::integral_constant<int, 1>;
     using U2 = std::integral_constant<int, 2>;
     using U3 = std::integral_constant<int, 3>;
-    static_assert((NSET * T) % 2 == 0, "A register sets alternate per (k-step, row tile)");
+    static_assert(T == 1 || T == 2 || T == 4, "item index mod 4 must be static inside a group of NSET k-steps");
     if (rt0 * 32 < Mi) {                                                // wave-uniform: waves without a row tile skip it all
-        read_a(0, 0, a[0]);
+        t0 = advance();
+        t1 = advance();
+        t2 = advance();
+        read_a(t0, 0, a[0]);                                            // items 0 and 1
+        read_a(T == 1 ? t1 : t0, T == 1 ? 0 : 1, a[1]);
         int s0 = 0;
         for (; s0 + NSET <= nsteps; s0 += NSET) {                       // exit-free groups, then 0 - 3 steps straight-line
             step(s0, U0{});
@@ -1753,9 +1762,12 @@ bool plan_image(const Geom& g, int groups, ImagePlan& ip) {
     if (groups != 1 || g.d != 1 || g.C % BK != 0 || g.B < 128) return false;
     if (g.in_act != PM_ACT_NONE && g.in_act != PM_ACT_RELU && g.in_act != PM_ACT_LEAKY) return false;
     if (g.KH * g.KW < 4 || g.kws != g.KW) return false;                 // 1x1: the dense form; masked sub-kernels: direct form
+    // every tap is walked for every position: grids smaller than the kernel (the 7x7 <-> 1x1 layers: 1 valid tap of 49)
+    // stay on the direct form and its tap lists
+    if (g.IH < g.KH || g.IW < g.KW || g.OH * g.OW < 32) return false;
     const int nsteps = g.KH * g.KW * (g.C / BK);
     if (nsteps > 2048) return false;
-    ip.lds = (size_t)(nsteps + 2) * sizeof(KStepB) + 2 * ((size_t)g.IH * g.IW * (g.C + 8) + 64) * 2;
+    ip.lds = 2 * ((size_t)g.IH * g.IW * (g.C + 8) + 64) * 2;
     if (ip.lds > 158 * 1024) return false;
     ip.nct = (g.N + 31) / 32;
     if (ip.nct > 8 || (8 % ip.nct) != 0) return false;
