@@ -61,6 +61,7 @@ struct WgradArgs {
     int chunks_per_split;
     int step_b, step_p, step_q;  // 128 rows = step_b images + step_p rows + step_q pixels
     int ntiles, nsplits, xcd_map;  // bf16 kernel: (k-block, n-block) tiles x m-splits, see the block-id remap there
+    int cpad;                      // sub kernel: 32 < C < 64 - a k-block is ONE tap, its channels zero-padded to 64
     // optional per-group element offsets (gathered, dense, dw, db) relative to the four base pointers, in DEVICE memory:
     // groups whose operands are separately allocated buffers (the weight gradients of many same-shaped layers in one launch)
     const long long* gtab;
@@ -1618,6 +1619,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         reinterpret_cast<unsigned*>(Ph + zoff)[tid] = 0u;
         reinterpret_cast<unsigned*>(Pl + zoff)[tid] = 0u;
     }
+#if !(defined(PM_EXP) && PM_EXP == 31)
     {   // the image: f32 -> in_act -> hi / lo bf16; a linear read, up to 13 float4 per thread in flight
         const float* img = p.in + (size_t)b * npos * g.C;
         const int c4n = g.C >> 2;
@@ -1651,6 +1653,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         }
     }
 
+#endif
     // per row tile: this lane's A row = output position m -> top-left input coordinate of its receptive field
     int py[T], px[T];
 #pragma unroll
@@ -1728,6 +1731,9 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         read_a(t0, 0, a[0]);                                            // items 0 and 1
         read_a(T == 1 ? t1 : t0, T == 1 ? 0 : 1, a[1]);
         int s0 = 0;
+#if defined(PM_EXP) && PM_EXP == 32
+        s0 = nsteps;
+#endif
         for (; s0 + NSET <= nsteps; s0 += NSET) {                       // exit-free groups, then 0 - 3 steps straight-line
             step(s0, U0{});
             step(s0 + 1, U1{});
@@ -1741,6 +1747,9 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
                 if (s0 + 2 < nsteps) step(s0 + 2, U2{});
             }
         }
+#if defined(PM_EXP) && PM_EXP == 33
+        if (acc[0][0] == 12345.f)
+#endif
         if (n < g.N) {
 #pragma unroll
             for (int j = 0; j < T; ++j) {
@@ -2602,7 +2611,10 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     const int h = lane >> 5;
     const int tile = blockIdx.x % p.ntiles;
     const int split = blockIdx.x / p.ntiles;
-    const int nkb = (g.K + CB - 1) / CB;
+    // cpad (32 < C < 64, the 48-channel layers of the VDVAE): a k-block is one tap with its C channels zero-padded to 64 -
+    // 56 % of the MFMA work is real, on a pipe 16x faster than the f32 form these shapes ran on before
+    const bool cpad = p.cpad != 0;
+    const int nkb = cpad ? g.KH * g.KW : (g.K + CB - 1) / CB;
     const int kkb = tile % nkb;
     const int nb = tile / nkb;
     const int kk0 = kkb * CB;
@@ -2611,8 +2623,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     const float* gin = p.gathered + wg_off(p, grp, 0, p.in_gs);
     const float* din = p.dense + wg_off(p, grp, 1, p.out_gs);
     const bool do_bias = (p.db != nullptr) && (kkb == 0) && (wc == 0);
-    const int tap_u = kk0 / g.C;
-    const int c_u = kk0 - tap_u * g.C;
+    const int tap_u = cpad ? kkb : kk0 / g.C;
+    const int c_u = cpad ? 0 : kk0 - tap_u * g.C;
     const int ky_u = tap_u / g.KW;
     const int kx_u = tap_u - ky_u * g.KW;
 
@@ -2623,6 +2635,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
 
     LoaderV4<BMC, CB, DD> lg;
     lg.init(tid);
+    const bool kok_t = !cpad || lg.slot4 < g.C;       // this thread's 4 channels exist
     constexpr int DSLOTS = NB / 4;
     constexpr int DRPP = 256 / DSLOTS;
     constexpr int DNP = BMC / DRPP;
@@ -2671,7 +2684,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
 
     if (c_begin < c_end) {
         lg.set_rows(g, c_begin * BMC);
-        lg.load_tap(g, gin, ky_u, kx_u, c_u, true);
+        lg.load_tap(g, gin, ky_u, kx_u, c_u, kok_t);
         load_d(c_begin * BMC);
     }
     for (int ch = c_begin; ch < c_end; ++ch) {
@@ -2680,7 +2693,7 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
         __syncthreads();
         if (ch + 1 < c_end) {
             lg.advance_rows(g, (ch + 1) * BMC, p.step_b, p.step_p, p.step_q);
-            lg.load_tap(g, gin, ky_u, kx_u, c_u, true);
+            lg.load_tap(g, gin, ky_u, kx_u, c_u, kok_t);
             load_d((ch + 1) * BMC);
         }
 #pragma unroll
@@ -2707,10 +2720,11 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     if (n < g.N) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int kk = kk0 + 32 * wc + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (kk >= g.K) continue;
-            const int tap = kk / g.C;
-            const int c = kk - tap * g.C;
+            const int cl = 32 * wc + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int kk = kk0 + cl;
+            if (cpad ? cl >= g.C : kk >= g.K) continue;
+            const int tap = cpad ? kkb : kk / g.C;
+            const int c = cpad ? cl : kk - tap * g.C;
             const int wtap = (tap / g.KW) * g.kws + tap % g.KW;
             atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[e]);
         }
@@ -3281,7 +3295,8 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
                                   float* dw, float* db, const long long* gtab, bool tab_aligned) {
     WgradArgs a;
     if (!fill_geom(d, a.g, false) || !gathered || !dense || !dw) return PM_EINVAL;
-    if (d->C % 32 != 0 || d->N % 4 != 0 || (d->d != 1 && d->d != 2)) return PM_EINVAL;
+    const bool cpad = d->C % 32 != 0 && d->C > 32 && d->C < 64 && d->C % 4 == 0;      // one zero-padded tap per k-block
+    if ((d->C % 32 != 0 && !cpad) || d->N % 4 != 0 || (d->d != 1 && d->d != 2)) return PM_EINVAL;
     if (!aligned16(gathered) || !aligned16(dense)) return PM_EINVAL;
     if (gtab ? !tab_aligned : (d->in_gs % 4 != 0 || d->out_gs % 4 != 0)) return PM_EINVAL;
     a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db; a.gtab = gtab;
@@ -3328,7 +3343,14 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
             }
         }
     }
-    const WgradPlan p = plan_wgrad(a.g, d->groups, true, true);
+    a.cpad = cpad ? 1 : 0;
+    Geom gplan = a.g;
+    if (cpad) {                 // planned as the 64-channel problem it is executed as
+        gplan.C = 64;
+        gplan.K = a.g.KH * a.g.KW * 64;
+    }
+    WgradPlan p = plan_wgrad(gplan, d->groups, true, true);
+    if (cpad) p.rc = p.rn = 2;  // the sub kernel (64 x 64 tiles) is the only form with the padded-tap mode
     a.chunks_per_split = p.chunks_per_split;
     const int hw = a.g.OH * a.g.OW;
     a.step_b = 128 / hw;
@@ -3341,7 +3363,7 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
     a.xcd_map = (!xcd_off && p.splits % 8 == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int dd = d->d;
-    if (!sub_off && p.rc == 2 && p.rn == 2) {     // 64 x 64 tiles: the occupancy-oriented form, 64-row chunks
+    if ((!sub_off || cpad) && p.rc == 2 && p.rn == 2) {     // 64 x 64 tiles: the occupancy-oriented form, 64-row chunks
         a.chunks_per_split = 2 * p.chunks_per_split;
         a.step_b = 64 / hw;
         a.step_p = (64 - a.step_b * hw) / a.g.OW;

@@ -8,6 +8,7 @@
 //   diag_tril_kl    KL(stop_grad(posterior) || MultivariateNormalTriL(masked posterior)) (:546-569)
 //   affine          final_fn: x * gain + bias (:807-813)
 //   dmol            discretised mixture of logistics log-prob / mean, one channel (:351-435)
+#include <cstdlib>
 #include "pm_common.h"
 
 namespace {
@@ -329,6 +330,150 @@ __global__ __launch_bounds__(256) void diag_tril_kl_kernel(const float* __restri
     }
 }
 
+// The same quantity for Z = 16 with a 16-lane group per site (4 sites per wave, 16 per workgroup) and no barrier inside the
+// triangular algebra.  The wave-per-site form above keeps 16 of 64 lanes busy and crosses a workgroup barrier per row of the
+// inverse (64 / 39 us forward / backward at 12 544 sites: 13 % of the VDVAE step).  Here lane j of a group owns COLUMN j of
+// M = L^-1: forward substitution L x = e_j runs in its registers, L's entries come as broadcast LDS reads (the 16 lanes of
+// a group read the same address), u = M d is solved redundantly by every lane off the same L reads.  Backward: the columns
+// go to LDS once; lane c then builds column c of Q = M diag(s^2) M^T + u u^T and, in the same pass over the rows of M,
+// column c of M^T Q (rows of M are broadcast reads); results leave through an LDS row image so that stores are coalesced.
+constexpr int T16 = 16;
+constexpr int T16_LP = 20;                        // LDS row pitch of L / M (floats): 16-byte aligned rows
+constexpr int T16_SITE = T16 * T16_LP + 4;        // floats per site: the 4-float skew moves the 4 groups of a wave to different banks
+constexpr int T16_NP = T16 + T16 * (T16 + 1) / 2; // parameters per site: mean + fill_triangular entries
+template <bool BWD>
+__global__ __launch_bounds__(256) void diag_tril_kl16_kernel(const float* __restrict__ post, const float* __restrict__ mp,
+                                                              float* __restrict__ kl, float g, float* __restrict__ dmp,
+                                                              long long R, int P) {
+    constexpr int Z = T16;
+    __shared__ __attribute__((aligned(16))) float Ls[16 * T16_SITE];
+    __shared__ __attribute__((aligned(16))) float Ms[BWD ? 16 * T16_SITE : 4];
+    __shared__ float sv[16][3 * Z];               // s_a^2, d = mu_b - mu_a, raw diagonal parameters
+    __shared__ float ob[BWD ? 16 * T16_NP : 4];   // the output rows of the workgroup's 16 sites
+    __shared__ float wsum[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, j = lane & 15;
+    const int sl = wave * 4 + grp;                // site slot inside the workgroup
+    const long long r_raw = (long long)blockIdx.x * 16 + sl;
+    const bool active = r_raw < R;
+    const long long r = active ? r_raw : R - 1;
+    float* L = Ls + sl * T16_SITE;
+    const float* prow = mp + (size_t)r * T16_NP;
+#pragma unroll
+    for (int it = 0; it < Z; ++it) {              // element (i, c) = (it, j) of L
+        float x = 0.f;
+        if (j <= it) {
+            x = prow[Z + tril_index(it, j, Z)];
+            if (j == it) {
+                sv[sl][2 * Z + j] = x;
+                x = pm_softplus(x) + kDiagShift;
+            }
+        }
+        L[it * T16_LP + j] = x;
+    }
+    {
+        const float sa = pm_softplus(post[(size_t)r * 2 * Z + Z + j]) + kDiagShift;
+        sv[sl][j] = sa * sa;
+        sv[sl][Z + j] = prow[j] - post[(size_t)r * 2 * Z + j];
+    }
+    __syncthreads();
+
+    // forward substitution: x = column j of M (x[i] = 0 for i < j falls out of the recurrence), u = M d
+    float x[Z], u[Z];
+    float ljj = 1.f, uj = 0.f;
+#pragma unroll
+    for (int i = 0; i < Z; ++i) {
+        float lrow[Z];
+#pragma unroll
+        for (int q = 0; q < Z / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(L + i * T16_LP + 4 * q);
+            lrow[4 * q] = v[0]; lrow[4 * q + 1] = v[1]; lrow[4 * q + 2] = v[2]; lrow[4 * q + 3] = v[3];
+        }
+        float sx = i == j ? 1.f : 0.f, su = sv[sl][Z + i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            sx -= lrow[k] * x[k];
+            su -= lrow[k] * u[k];
+        }
+        const float inv = 1.f / lrow[i];
+        x[i] = sx * inv;
+        u[i] = su * inv;
+        if (i == j) { ljj = lrow[i]; uj = u[i]; }
+    }
+    float cn = 0.f;
+#pragma unroll
+    for (int i = 0; i < Z; ++i) cn += x[i] * x[i];                       // |M e_j|^2
+    const float sa2 = sv[sl][j];
+    float part = 0.5f * (sa2 * cn + uj * uj - 1.f) + logf(ljj) - 0.5f * logf(sa2);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);     // over the 16 lanes of the group
+    if (!BWD) {
+        // one value per example a workgroup touches: added site by site the 784 sites of an example serialise in the L2
+        // atomic unit
+        const long long wg_first = (long long)blockIdx.x * 16;
+        long long wg_last = wg_first + 15;
+        if (wg_last > R - 1) wg_last = R - 1;
+        if (wg_first / P == wg_last / P) {
+            float t = (active && j == 0) ? part : 0.f;
+            t = pm_wave_sum(t);
+            if (lane == 0) wsum[wave] = t;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(kl + wg_first / P, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        } else if (j == 0 && active) {
+            atomicAdd(kl + r / P, part);
+        }
+        return;
+    }
+    if constexpr (BWD) {
+        float* M = Ms + sl * T16_SITE;
+#pragma unroll
+        for (int i = 0; i < Z; ++i) M[i * T16_LP + j] = x[i];            // column j
+        __syncthreads();
+        // mcs[k] = M[c][k] * s_k^2 (row c = this lane's own row of M), c = j
+        float mcs[Z];
+#pragma unroll
+        for (int q = 0; q < Z / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(M + j * T16_LP + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mcs[4 * q + e] = v[e] * sv[sl][4 * q + e];
+        }
+        float G[Z];                                                      // G[rr] = sum_i M[i][rr] Q[i][c]
+#pragma unroll
+        for (int rr = 0; rr < Z; ++rr) G[rr] = 0.f;
+        float dmu = 0.f;                                                 // d mu_b[c] = sum_i M[i][c] u_i
+#pragma unroll
+        for (int i = 0; i < Z; ++i) {
+            float mrow[Z];
+#pragma unroll
+            for (int q = 0; q < Z / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(M + i * T16_LP + 4 * q);
+                mrow[4 * q] = v[0]; mrow[4 * q + 1] = v[1]; mrow[4 * q + 2] = v[2]; mrow[4 * q + 3] = v[3];
+            }
+            float qi = u[i] * uj;                                        // Q[i][c]
+#pragma unroll
+            for (int k = 0; k <= i; ++k) qi += mrow[k] * mcs[k];         // M[i][k] = 0 for k > i, mcs[k] = 0 for k > c
+#pragma unroll
+            for (int rr = 0; rr <= i; ++rr) G[rr] += mrow[rr] * qi;
+            dmu += x[i] * u[i];
+        }
+        float* orow = ob + sl * T16_NP;
+        orow[j] = g * dmu;
+#pragma unroll
+        for (int rr = 0; rr < Z; ++rr) {
+            if (rr < j) continue;                                        // lower part only: entries (rr, c = j), rr >= j
+            float sres = -G[rr];
+            if (rr == j) sres = (sres + 1.f / ljj) * pm_sigmoid(sv[sl][2 * Z + j]);
+            orow[Z + tril_index(rr, j, Z)] = g * sres;
+        }
+        __syncthreads();
+        const long long row0 = (long long)blockIdx.x * 16;
+        long long nrows = R - row0;
+        if (nrows > 16) nrows = 16;
+        float* dst = dmp + (size_t)row0 * T16_NP;
+        for (int t = threadIdx.x; t < (int)nrows * T16_NP; t += 256) dst[t] = ob[t];
+    }
+}
+
 __global__ __launch_bounds__(256) void affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gain,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           long long total, int C) {
@@ -547,6 +692,11 @@ extern "C" int pm_diag_sample_kl_bwd(pm_stream_t stream, const float* post, cons
 extern "C" int pm_diag_tril_kl_fwd(pm_stream_t stream, const float* post, const float* masked_params, float* kl,
                                    long long rows, int Z, int P) {
     if (!post || !masked_params || !kl || rows <= 0 || Z <= 0 || Z > 16 || P <= 0) return PM_EINVAL;
+    static const bool old_form = getenv("PM_TRIL_KL_WAVE") != nullptr;     // A/B switch for measurements
+    if (Z == 16 && !old_form)
+        hipLaunchKernelGGL(diag_tril_kl16_kernel<false>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, post,
+                           masked_params, kl, 0.f, (float*)nullptr, rows, P);
+    else
     hipLaunchKernelGGL(diag_tril_kl_kernel<false>, dim3((unsigned)((rows + 4 * DT_SPW - 1) / (4 * DT_SPW))), dim3(256), 0, (hipStream_t)stream, post,
                        masked_params, kl, 0.f, (float*)nullptr, rows, Z, P);
     return pm_check_launch("pm_diag_tril_kl_fwd");
@@ -555,6 +705,11 @@ extern "C" int pm_diag_tril_kl_fwd(pm_stream_t stream, const float* post, const 
 extern "C" int pm_diag_tril_kl_bwd(pm_stream_t stream, const float* post, const float* masked_params, float g,
                                    float* dmasked_params, long long rows, int Z, int P) {
     if (!post || !masked_params || !dmasked_params || rows <= 0 || Z <= 0 || Z > 16 || P <= 0) return PM_EINVAL;
+    static const bool old_form = getenv("PM_TRIL_KL_WAVE") != nullptr;
+    if (Z == 16 && !old_form)
+        hipLaunchKernelGGL(diag_tril_kl16_kernel<true>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, post,
+                           masked_params, (float*)nullptr, g, dmasked_params, rows, P);
+    else
     hipLaunchKernelGGL(diag_tril_kl_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, post,
                        masked_params, (float*)nullptr, g, dmasked_params, rows, Z, P);
     return pm_check_launch("pm_diag_tril_kl_bwd");

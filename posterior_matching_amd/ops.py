@@ -399,6 +399,12 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=No
 USE_BF16_WGRAD = True   # weight gradients on the bf16 matrix cores when the shape qualifies
 
 
+def _bf16_wgrad_channels(C: int) -> bool:
+    """gathered channel counts pm_gather_wgrad_bf16 accepts: multiples of 32, or 32 < C < 64 (one zero-padded tap per
+    k-block: the 48-channel layers of the VDVAE)"""
+    return C % 32 == 0 or (32 < C < 64 and C % 4 == 0)
+
+
 def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, db_gathered=None) -> None:
     """db_gathered: bias gradient taken over the GATHERED operand (transposed convs); only the thin lane form
     fuses it - callers must check the return value (True = db_gathered was accumulated)."""
@@ -410,7 +416,7 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, 
         _call("pm_thin_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), _ptr(db_gathered),
               tag=tag, work=work)
         return True
-    if (bf16 and USE_BF16_WGRAD and desc.C % 32 == 0 and desc.N % 4 == 0 and desc.d in (1, 2)
+    if (bf16 and USE_BF16_WGRAD and _bf16_wgrad_channels(desc.C) and desc.N % 4 == 0 and desc.d in (1, 2)
             and gathered.data_ptr() % 16 == 0 and dense.data_ptr() % 16 == 0):
         tag = work = None
         if _timer is not None:
@@ -556,7 +562,7 @@ class WgradBatch:
             raise NotImplementedError("deferred weight gradients of transposed convolutions")
         B = x.shape[0]
         d = g._desc(B, "wgrad")
-        use_bf16 = bool(bf16 and USE_BF16_WGRAD and d.C % 32 == 0 and d.N % 4 == 0 and d.d in (1, 2))
+        use_bf16 = bool(bf16 and USE_BF16_WGRAD and _bf16_wgrad_channels(d.C) and d.N % 4 == 0 and d.d in (1, 2))
         key = (B, g.kind, g.IH, g.IW, g.CI, g.OH, g.OW, g.CO, g.KH, g.KW, g.s, g.pad, g.pad_x, g.full_kh, g.full_kw, in_act,
                use_bf16, db is not None)
         self.items.setdefault(key, []).append((g, x, dy, dw, db))

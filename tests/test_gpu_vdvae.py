@@ -331,7 +331,14 @@ def test_fused_block_matches_oracle_and_layerwise_path(B, H, cin, cout, mid, res
     for a, b_ in zip(fused[1] + fused[3], plain[1] + plain[3]):
         assert rel_err(a, b_) < 2e-5
     for n in want_g:
-        assert rel_err(fused[4][n], want_g[n]) < 2e-4, (n, rel_err(fused[4][n], want_g[n]))
+        err = rel_err(fused[4][n], want_g[n])
+        where = ""
+        if err >= 2e-4 and want_g[n].dim() == 4:      # which taps / 16-channel blocks are off
+            e = (fused[4][n].double().cpu() - want_g[n]).abs() / want_g[n].abs().max()
+            where = [[round(float(e[ky, kx].max()), 4) for kx in range(e.shape[1])] for ky in range(e.shape[0])]
+            where = (where, [round(float(e[:, :, c:c + 16].max()), 4) for c in range(0, e.shape[2], 16)],
+                     round(float(rel_err(plain[4][n], want_g[n])), 6))
+        assert err < 2e-4, (n, err, where)
 
 
 def test_vdvae_param_names_and_init_match_oracle():

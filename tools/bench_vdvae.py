@@ -34,6 +34,7 @@ for B in [int(v) for v in args.batches.split(",")]:
                       "algorithmic_tflops": round(14.91e9 * B / (dt / args.steps) / 1e12, 2), "loss": round(met["loss"], 2),
                       "bpd": round(met["bpd"], 3), "params": m.num_params}), flush=True)
     if args.table and B == 16:
+        ts.use_plan = False; ts.invalidate_plan()  # eager: the timer brackets every C-ABI call (plan replay bypasses it)
         timer = ops.KernelTimer(); ops.set_timer(timer)
         ts.step(); ts.synchronize(); ops.set_timer(None)
         summ = timer.summary(); tot = sum(r["ms"] for r in summ.values())
