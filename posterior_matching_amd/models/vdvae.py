@@ -828,9 +828,28 @@ class PosteriorMatchingVDVAE(Module):
             ops.fill_zero(t)
         streams = self._branch_streams(self._x.device)
         main = torch.cuda.current_stream(self._x.device)
+        # Weight gradients are grouped per (resolution, layer shape), so the groups of a resolution are complete when the
+        # backward chain leaves it: they start then on their own stream, beside the rest of the chain (dependent small
+        # launches that leave most of the chip idle) - same number of launches as one flush at the very end.
+        flush_stream = None
+        if self.ws.wgrad_batch is not None and self.store.reducer is None and not os.environ.get("PM_VDVAE_ONE_FLUSH"):
+            if getattr(self, "_flush_stream", None) is None:
+                self._flush_stream = torch.cuda.Stream(device=self._x.device)
+            flush_stream = self._flush_stream
+
+        def flush_side():
+            ops.wait_stream(flush_stream, main)
+            if streams is not None:
+                ops.wait_stream(flush_stream, streams[0])
+                ops.wait_stream(flush_stream, streams[1])
+            with torch.cuda.stream(flush_stream):
+                self.ws.wgrad_batch.flush()
+
         for i in reversed(range(len(self.dec_blocks))):
             blk = self.dec_blocks[i]
             r = blk.base
+            if flush_stream is not None and i + 1 < len(self.dec_blocks) and self.dec_blocks[i + 1].base != r:
+                flush_side()                            # the finer resolution is finished
             dxin = blk.backward(dxs[r], dacts[r], dmacts[r], g, g, streams=streams)
             if self.store.reducer is not None and self.ws.wgrad_batch is None:   # data-parallel: block i's weight gradients are final once the
                 self.ws.join_all_aux()                  # main chain and the masked-posterior chain (streams[1]) got here
@@ -844,6 +863,8 @@ class PosteriorMatchingVDVAE(Module):
                 # x_in was the previous block of this resolution's output, and this block its only consumer (mix-in
                 # sources are always the LAST state of a coarser resolution): hand dxin over as that block's dx3
                 dxs[r] = dxin
+        if flush_stream is not None:
+            flush_side()                                # the coarsest decoder resolution; the encoders' follow at the end
         if getattr(self, "_paired", False):
             if streams is not None:
                 ops.wait_stream(main, streams[0])
@@ -865,6 +886,8 @@ class PosteriorMatchingVDVAE(Module):
             # every Block has left its operands in HBM: their weight gradients, one launch per (resolution, layer shape)
             self.ws.wgrad_batch.flush()
             self.ws.wgrad_batch = None
+        if flush_stream is not None:
+            ops.wait_stream(main, flush_stream)
         self.ws.join_all_aux()
 
     def zero_grad(self) -> None:

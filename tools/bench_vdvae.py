@@ -47,6 +47,6 @@ for B in [int(v) for v in args.batches.split(",")]:
             for tag, detail, ms, fl in timer.per_call():
                 a = agg.setdefault((tag, detail), [0, 0.0, 0.0])
                 a[0] += 1; a[1] += ms; a[2] += fl
-            for (tag, detail), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            for (tag, detail), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:80]:
                 fp.write(f"{tag:44s} {detail:50s} x{n:4d} avg {ms / n * 1e3:7.1f} us  {fl / (ms * 1e-3) / 1e12 if fl else 0:6.2f} TFLOP/s\n")
     del ts, m
