@@ -490,6 +490,39 @@ def pm_vae_is_log_prob(p: Params, model_cfg: dict, x: Tensor, b: Tensor, noise: 
     return log_p_x, log_p_x - log_p_xo
 
 
+def pm_vae_expected_info_gains(p: Params, model_cfg: dict, x: Tensor, b: Tensor, noise: Dict[str, Tensor]) -> Tensor:
+    """PosteriorMatchingVAE.expected_info_gains (vae.py:228-290) for ONE instance (no batch axis): the expected drop of
+    the partial posterior's entropy when feature i becomes observed, -inf where b == 1.  noise["eps"] [1,S,k].
+    Gaussian partial posteriors only: TFP's Autoregressive (AutoregressiveGMM) has no entropy(), the reference raises."""
+    S = noise["eps"].shape[1]
+    x_o = x * b                                                                      # :249
+    kind, cfg, pfeats, k = _partial_posterior(p, model_cfg, x_o[None], b[None])     # :250-252
+    if kind == "AutoregressiveGMM":
+        raise NotImplementedError("tfd.Autoregressive has no analytic entropy")
+    z, _ = _sample_partial_posterior(p, kind, cfg, pfeats, k, noise, S)              # :253-254
+    dkind, out = _decoder(p, model_cfg, z)
+    x_u = (torch.sigmoid(out) if dkind == "Bernoulli" else out).reshape((S,) + tuple(x.shape))   # :255 decoder(z).mean()
+    F = b.numel()
+    one_hots = torch.eye(F, dtype=b.dtype).reshape((F,) + tuple(b.shape))           # :257-259
+    masks = torch.cat([b[None], torch.maximum(b[None], one_hots)], 0)               # :261-262  [F+1, ...]
+    x_o_u = torch.where(b[None] == 1, x_o[None], x_u)                               # :264-268  [S, ...]
+    ents = []
+    for s in range(S):                                                               # hk.scan over the samples, :270-277
+        xs = x_o_u[s][None].expand(masks.shape[0], *x.shape)
+        _, _, pf, _ = _partial_posterior(p, model_cfg, xs * masks, masks)            # concat([x * masks, masks]) (masks are 0/1)
+        if kind == "TriLGaussian":
+            _, tril = tril_gaussian_params(p, "partial_posterior_dist", pf, k)
+            logdet = torch.log(torch.diagonal(tril, dim1=-2, dim2=-1)).sum(-1)
+        else:
+            _, scale = diagonal_gaussian_params(p, "partial_posterior_dist", pf, k)
+            logdet = torch.log(scale).sum(-1)
+        ents.append(0.5 * k * (1.0 + math.log(2 * math.pi)) + logdet)               # MVN entropy
+    ents = torch.stack(ents).mean(0)                                                 # :278
+    gains = (ents[0] - ents[1:]).reshape(b.shape)                                    # :280-283
+    gains = torch.where(b == 0, gains, torch.full_like(gains, -math.inf))            # :284
+    return gains.reshape(-1)
+
+
 def nrmse_score(imputations, true_data, observed_mask):
     """eval_pm_vae_uci.py:60-66 (numpy): per-feature RMSE over the missing entries / feature std, mean over features."""
     import numpy as np

@@ -148,6 +148,9 @@ SIGNATURES = {
     "pm_imputation_psnr": [_P, _P, _P, _P, _LL, _I, _LL, _F],
     "pm_gumbel_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
     "pm_mlp_pair_bf16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _F],
+    "pm_info_gain_inputs": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "pm_gaussian_entropy": [_P, _P, _P, _LL, _I, _I, _I],
+    "pm_info_gain_finish": [_P, _P, _P, _P, _I, _I],
     "pm_mlp_chain_bf16": [_P, _P, _I, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _F],
     "pm_repeat_rows": [_P, _P, _P, _LL, _I, _LL],
     "pm_sigmoid": [_P, _P, _P, _LL],

@@ -164,6 +164,61 @@ __global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restri
     if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.f) + sign * s;
 }
 
+// ---- PosteriorMatchingVAE.expected_info_gains (reference vae.py:228-290) ------------------------------------------------
+// The candidate batch of one decoder sample (vae.py:257-276): row c of [F + 1] rows is the instance with mask
+//   m_0 = b,   m_c = max(b, onehot_{c-1})   (feature index = position * Cb + mask channel)
+// and values where(b == 1, x, x_u) * m_c (x_o = x * b equals x there), concatenated with m_c: out [F + 1, P, C + Cb].
+__global__ __launch_bounds__(256) void info_gain_inputs_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                                                const float* __restrict__ x_u, float* __restrict__ out,
+                                                                int P, int C, int Cb) {
+    const int c = blockIdx.y;                       // candidate row: 0 = the current mask, c >= 1 = feature c - 1 acquired
+    const int W = C + Cb;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < P * W; e += gridDim.x * 256) {
+        const int pos = e / W, j = e - pos * W;
+        const int cb = j < C ? (Cb == C ? j : 0) : j - C;
+        const float bv = b[pos * Cb + cb];
+        const float m = (c >= 1 && c - 1 == pos * Cb + cb) ? fmaxf(bv, 1.f) : bv;
+        float v = m;
+        if (j < C) v = (bv == 1.f ? x[pos * C + j] : x_u[pos * C + j]) * m;   // where(b == 1, x * b, x_u) * m
+        out[(size_t)c * P * W + e] = v;
+    }
+}
+
+// entropy of a Gaussian head per row: 0.5 k (1 + log 2 pi) + sum_i log scale_i; scale_i = softplus(raw_i) + 1e-5 is the
+// diagonal of FillScaleTriL (tril != 0: parameters [loc k | fill_triangular k(k+1)/2]) or of the diagonal head [loc | raw]
+__global__ __launch_bounds__(256) void gaussian_entropy_kernel(const float* __restrict__ params, float* __restrict__ ent,
+                                                                 long long R, int k, int tril, int ent_stride) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int np = tril ? k + k * (k + 1) / 2 : 2 * k;
+    const float* prow = params + (size_t)r * np;
+    float s = 0.f;
+    for (int i = 0; i < k; ++i) {
+        int idx;
+        if (tril) {
+            const int m = k * (k + 1) / 2, t = i * k + i;       // TFP fill_triangular index of element (i, i)
+            idx = k + (t < m - k ? k + t : 2 * m - k - 1 - t);
+        } else {
+            idx = k + i;
+        }
+        s += logf(pm_softplus(prow[idx]) + 1e-5f);
+    }
+    ent[(size_t)r * ent_stride] = 0.5f * k * (1.f + kLog2Pi) + s;
+}
+
+// gains[f] = mean_s ents[s, 0] - mean_s ents[s, 1 + f] where b[f] == 0, else -inf   (vae.py:278-288)
+__global__ __launch_bounds__(256) void info_gain_finish_kernel(const float* __restrict__ ents, const float* __restrict__ b,
+                                                                 float* __restrict__ gains, int S, int F) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float before = 0.f, after = 0.f;
+    for (int s = 0; s < S; ++s) {
+        before += ents[(size_t)s * (F + 1)];
+        after += ents[(size_t)s * (F + 1) + 1 + f];
+    }
+    gains[f] = b[f] == 0.f ? before / S - after / S : -INFINITY;
+}
+
 }  // namespace
 
 extern "C" int pm_diag_logprob_acc(pm_stream_t stream, const float* params, int ld, const float* z, float* out,
@@ -234,4 +289,28 @@ extern "C" int pm_gmm_sample_step(pm_stream_t stream, const float* head, const f
     hipLaunchKernelGGL(gmm_sample_step_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head,
                        gumbel, eps, z, R, k, nc, i);
     return pm_check_launch("pm_gmm_sample_step");
+}
+
+extern "C" int pm_info_gain_inputs(pm_stream_t stream, const float* x, const float* b, const float* x_u, float* out, int P,
+                                   int C, int Cb) {
+    if (!x || !b || !x_u || !out || P <= 0 || C <= 0 || (Cb != C && Cb != 1)) return PM_EINVAL;
+    const int F = P * Cb;
+    int gx = (P * (C + Cb) + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(info_gain_inputs_kernel, dim3(gx, F + 1), dim3(256), 0, (hipStream_t)stream, x, b, x_u, out, P, C, Cb);
+    return pm_check_launch("pm_info_gain_inputs");
+}
+
+extern "C" int pm_gaussian_entropy(pm_stream_t stream, const float* params, float* ent, long long R, int k, int tril,
+                                   int ent_stride) {
+    if (!params || !ent || R <= 0 || k <= 0 || ent_stride <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(gaussian_entropy_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params,
+                       ent, R, k, tril, ent_stride);
+    return pm_check_launch("pm_gaussian_entropy");
+}
+
+extern "C" int pm_info_gain_finish(pm_stream_t stream, const float* ents, const float* b, float* gains, int S, int F) {
+    if (!ents || !b || !gains || S <= 0 || F <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(info_gain_finish_kernel, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, ents, b, gains, S, F);
+    return pm_check_launch("pm_info_gain_finish");
 }

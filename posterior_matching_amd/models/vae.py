@@ -215,6 +215,34 @@ class PosteriorMatchingVAE(Module):
         ops.add_cols(log_p_x.view(B, 1), neg, 0, out)       # log p(x_u | x_o) = log p(x) - log p(x_o)
         return log_p_x, out.view(B)
 
+    def expected_info_gains(self, x: torch.Tensor, b: torch.Tensor, num_samples: int = 100, noise=None,
+                            seed: Optional[int] = None) -> torch.Tensor:
+        """reference vae.py:228-290: for ONE instance (x, b without a batch axis) the expected drop of the partial
+        posterior's entropy when feature i becomes observed, -inf where b == 1; shape [num_features].
+        noise: {"eps" [1, S, k]} replaces the device Philox draw (parity mode).  Gaussian partial posteriors only - the
+        reference's AutoregressiveGMM is a tfd.Autoregressive, whose entropy() is not implemented, so it raises there too."""
+        pp = self.partial_posterior_dist
+        if isinstance(pp, AutoregressiveGMM):
+            raise NotImplementedError("expected_info_gains needs partial_posterior.entropy(): not defined for AutoregressiveGMM")
+        if self.store is None:
+            self.init(x.shape, x.device)
+        S, F = int(num_samples), b.numel()
+        x1, b1 = x.unsqueeze(0).contiguous(), b.unsqueeze(0).contiguous()
+        nz = self._eval_noise(1, S, noise, seed, need_posterior=False)
+        z, _ = self._partial_posterior_samples(x1, b1, nz, S)            # S samples of q(z | x_o)
+        mean = self.decoder_dist.mean(self.decoder_net(Feat(z), is_training=False))     # [S, ...]: decoder(z).mean()
+        mean = mean.reshape((S,) + tuple(x.shape))
+        cand = self.ws.get("ig_cand", (F + 1,) + tuple(x.shape[:-1]) + (x.shape[-1] + b.shape[-1],))
+        ents = self.ws.get("ig_ents", (S, F + 1))
+        tril = isinstance(pp, TriLGaussian)
+        for s in range(S):                                               # hk.scan over the samples (vae.py:270-277)
+            ops.info_gain_inputs(x1, b1, mean[s], cand)       # where(b == 1, x_o, x_u): x_o = x * b equals x where b == 1
+            pfeat = self.partial_encoder_net(Feat(cand), is_training=False)
+            ops.gaussian_entropy(pp._linear_fwd(pfeat), ents[s], self.latent_dim, tril)
+        gains = self.ws.get("ig_gains", (F,))
+        ops.info_gain_finish(ents, b1.reshape(-1), gains)
+        return gains
+
     def _side_stream(self, device) -> "torch.cuda.Stream":
         if not self.concurrent:
             return torch.cuda.current_stream(device)

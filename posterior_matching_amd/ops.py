@@ -804,6 +804,24 @@ def mlp_pair_bf16(x, w1_split, w2_split, b1, b2, aux1, aux2, out1, out2, in_act,
           work=work)
 
 
+def info_gain_inputs(x, b, x_u, out) -> None:
+    """csrc/pm_eval.hip: the [F + 1] candidate rows concat([x * m_c, m_c]) of one decoder sample (vae.py:257-276)"""
+    C_, Cb = x.shape[-1], b.shape[-1]
+    P = x.numel() // C_
+    _call("pm_info_gain_inputs", _ptr(x), _ptr(b), _ptr(x_u), _ptr(out), P, C_, Cb)
+
+
+def gaussian_entropy(params, ent, k: int, tril: bool) -> None:
+    """entropy per row of a TriL / diagonal Gaussian head; `ent` may be a strided view (one column of a matrix)"""
+    assert ent.is_cuda and ent.dtype == torch.float32
+    _call("pm_gaussian_entropy", _ptr(params), ent.data_ptr(), params.shape[0], k, int(tril), ent.stride(0) if ent.dim() else 1)
+
+
+def info_gain_finish(ents, b, gains) -> None:
+    S, F1 = ents.shape
+    _call("pm_info_gain_finish", _ptr(ents), _ptr(b), _ptr(gains), S, F1 - 1)
+
+
 def mlp_chain_ok(rows: int, hidden: int) -> bool:
     """preconditions of pm_mlp_chain_bf16: hidden width 256, whole 64-row tiles"""
     return hidden == 256 and rows % 64 == 0

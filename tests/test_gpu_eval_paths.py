@@ -98,3 +98,37 @@ def test_device_noise_path_and_nrmse():
     assert np.isfinite(score).all()
     lx, lxu = m.is_log_prob(xd, bd, 32, seed=7)
     assert torch.isfinite(lx).all() and torch.isfinite(lxu).all()
+
+
+@pytest.mark.parametrize("name,post,S", [("gas", "TriLGaussian", 6), ("gas", "DiagonalGaussian", 5), ("mnist", "TriLGaussian", 2)])
+def test_expected_info_gains_matches_oracle(name, post, S):
+    """PosteriorMatchingVAE.expected_info_gains (reference vae.py:228-290): one instance, S decoder samples, F + 1 masked
+    copies per sample through the partial encoder, entropy differences.  Entropies are O(k) and the gains their small
+    differences: absolute tolerance 2e-4 (f32 entropy of a 16 / 32-dimensional head is good to ~1e-5)."""
+    cfg, xs, x, b, _ = _inputs(name, 2, 31)
+    cfg["model"]["posterior_dist"] = post
+    cfg["model"]["partial_posterior_dist"] = post
+    cfg["model"].pop("partial_posterior_dist_config", None)
+    m = _product_model(cfg, xs, bf16x3=False)
+    p64 = {n: t.cpu().double() for n, t in m.params_dict().items()}
+    k = cfg["model"]["latent_dim"]
+    noise = {"eps": torch.randn((1, S, k), generator=torch.Generator().manual_seed(5), dtype=torch.float64)}
+    x0, b0 = x[1], b[1]
+    assert 0 < b0.sum() < b0.numel()
+    want = O.pm_vae_expected_info_gains(p64, cfg["model"], x0, b0, noise)
+    got = m.expected_info_gains(x0.float().cuda(), b0.float().cuda(), S, noise={"eps": noise["eps"].float().cuda()})
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (b0.numel(),)
+    hidden = b0.reshape(-1) == 0
+    g = got.cpu().double()
+    assert torch.isinf(g[~hidden]).all() and (g[~hidden] < 0).all()          # already observed: -inf
+    assert torch.isfinite(g[hidden]).all()
+    assert (g[hidden] - want[hidden]).abs().max() < 2e-4, (g[hidden] - want[hidden]).abs().max()
+
+
+def test_expected_info_gains_needs_an_entropy():
+    """the reference's AutoregressiveGMM is a tfd.Autoregressive: entropy() is not implemented there either"""
+    cfg, xs, x, b, _ = _inputs("mnist", 2, 32)
+    m = _product_model(cfg, xs, bf16x3=False)
+    with pytest.raises(NotImplementedError):
+        m.expected_info_gains(x[0].float().cuda(), b[0].float().cuda(), 2)

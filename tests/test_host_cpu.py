@@ -356,3 +356,55 @@ def test_data_parallel_glue_gloo_world2(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DP-OK" in out.stdout
+
+
+def test_ctypes_signatures_match_the_header():
+    """every prototype of include/pmhip.h against the argtypes table of posterior_matching_amd/_lib.py: same number of
+    parameters, pointer / int / long long / float class by class (a missing pointer entry makes ctypes pass the next
+    device pointer as a 32-bit int: a GPU memory fault instead of an error)."""
+    import ctypes as C
+    import re
+
+    from posterior_matching_amd import _lib
+
+    src = open(os.path.join(ROOT, "include", "pmhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = re.findall(r"\b(?:int|void|const char\s*\*)\s+(pm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)
+    assert len(protos) > 100
+
+    def cls(param: str):
+        p = " ".join(param.split())
+        if p in ("", "void"):
+            return None
+        if "*" in p or p.startswith("pm_stream_t"):
+            return C.c_void_p
+        if "unsigned long long" in p or "long long" in p:
+            return C.c_longlong
+        if p.startswith("float") or " float " in f" {p} ":
+            return C.c_float
+        if p.startswith(("int ", "unsigned ", "const int ")):
+            return C.c_int
+        raise AssertionError(f"unclassified parameter {p!r}")
+
+    table = dict(_lib.SIGNATURES)
+    table.update({k: v[0] for k, v in _lib._OTHER_RESTYPE.items()})
+    checked = 0
+    for name, params in protos:
+        want = [c for c in (cls(p) for p in params.split(",")) if c is not None]
+        assert name in table, f"{name} is declared in pmhip.h but has no ctypes signature"
+        got = []
+        for a in table[name]:
+            if a in (C.c_void_p, C.c_char_p) or (isinstance(a, type) and issubclass(a, (C._Pointer, C.Array))) or hasattr(a, "_type_") and a not in (C.c_int, C.c_longlong, C.c_float, C.c_ulonglong, C.c_uint):
+                got.append(C.c_void_p)
+            elif a in (C.c_longlong, C.c_ulonglong):
+                got.append(C.c_longlong)
+            elif a in (C.c_int, C.c_uint):
+                got.append(C.c_int)
+            elif a is C.c_float:
+                got.append(C.c_float)
+            else:
+                got.append(C.c_void_p)       # POINTER(struct) and friends
+        assert got == want, f"{name}: header {[t.__name__ for t in want]} vs _lib {[t.__name__ for t in got]}"
+        checked += 1
+    assert checked == len(protos)

@@ -577,3 +577,32 @@ def test_pattern_window_equals_crop_of_pillow_resize():
     pat = desc[:, 0] == MO.PATTERN
     assert mask.shape == (96, 64, 64, 1) and set(np.unique(mask)) <= {0.0, 1.0}
     assert pat.any() and (np.abs((1 - mask[pat]).mean((1, 2, 3)) - 0.25) < 0.05).all()
+
+
+def test_expected_info_gains_oracle_properties():
+    """pm_vae_expected_info_gains (reference vae.py:228-290): -inf exactly on the observed features; the entropy it uses
+    equals torch.distributions' MultivariateNormal(scale_tril).entropy(); acquiring a feature the partial encoder cannot
+    see differently (x_u sample == observed value pattern) changes nothing when the mask is already all ones."""
+    import math
+
+    from oracle import pm_vae_oracle as O
+    from tests.ref_configs import pm_vae_gas
+
+    cfg = pm_vae_gas()
+    p = O.init_params(cfg["model"], (8,), seed=3)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(8, generator=gen, dtype=torch.float64)
+    b = (torch.rand(8, generator=gen) < 0.5).double()
+    noise = {"eps": torch.randn((1, 4, 16), generator=gen, dtype=torch.float64)}
+    g = O.pm_vae_expected_info_gains(p, cfg["model"], x, b, noise)
+    assert g.shape == (8,)
+    assert torch.isinf(g[b == 1]).all() and torch.isfinite(g[b == 0]).all()
+    # the entropy formula against torch.distributions
+    feats = torch.randn((3, 256), generator=gen, dtype=torch.float64)
+    loc, tril = O.tril_gaussian_params(p, "partial_posterior_dist", feats, 16)
+    want = torch.distributions.MultivariateNormal(loc, scale_tril=tril).entropy()
+    got = 0.5 * 16 * (1.0 + math.log(2 * math.pi)) + torch.log(torch.diagonal(tril, dim1=-2, dim2=-1)).sum(-1)
+    assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)
+    # everything observed: every gain is -inf
+    g1 = O.pm_vae_expected_info_gains(p, cfg["model"], x, torch.ones(8, dtype=torch.float64), noise)
+    assert torch.isinf(g1).all()
