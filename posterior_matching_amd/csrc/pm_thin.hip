@@ -182,13 +182,34 @@ __global__ __launch_bounds__(256) void thin_conv_lane_kernel(ThinArgs t, int TH,
                     for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv[j + jx], wr[c][jy][jx], acc[j]);
             }
         if (n < t.N) {
+            // loads, arithmetic, stores in three phases (element by element every aux / res load waits for the store in
+            // front of it: vmcnt counts both)
+            const size_t o0 = ((size_t)(b * t.OH + y0 + y) * t.OW + 4 * qx) * t.N + n;
+            const int nv = t.OW - 4 * qx < 4 ? t.OW - 4 * qx : 4;         // valid positions of the item
+            float av[4], rv[4], v[4];
+            if (aux) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = aux[o0 + (size_t)(j < nv ? j : 0) * t.N];
+            }
+            if (res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[j] = res[o0 + (size_t)(j < nv ? j : 0) * t.N];
+            }
+            const bool after = (t.aux_act & PM_AUX_AFTER_RES) != 0;
+            const int dact = t.aux_act & (PM_AUX_AFTER_RES - 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int x = 4 * qx + j;
-                if (x >= t.OW) continue;
-                const size_t o = ((size_t)(b * t.OH + y0 + y) * t.OW + x) * t.N + n;
-                out[o] = pm_epilogue(acc[j] + bv, aux, res, o, t.aux_act, t.out_act, t.slope);
+                float xx = acc[j] + bv;
+                if (res && after) xx += rv[j];
+                if (aux) xx *= pm_dact(av[j], dact, t.slope);
+                if (res && !after) xx += rv[j];
+                xx = pm_act(xx, t.out_act, t.slope);
+                asm volatile("" : "+v"(xx));
+                v[j] = xx;
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nv) out[o0 + (size_t)j * t.N] = v[j];
         }
     }
 }
