@@ -136,6 +136,12 @@ def main():
                                                               "reverse-order buckets overlapped with it")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its first
+    # communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved one.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -176,6 +182,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    elif os.environ.get("PM_FORCE_DP") == "1":
+        # rehearsal of the N > 1 code path on ONE GPU: a 1-rank RCCL communicator, bucketed asynchronous all-reduce inside the
+        # replayed launch plan (no multi-GPU node is available to the builder)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
 
     cfg = load_config_file(os.path.join(ROOT, "configs", "pm_vae_mnist.py")).to_dict()   # the CLI's own config file
     xs, B = data_shape(cfg["data"]["dataset"]), args.batch
@@ -191,7 +203,7 @@ def main():
     model.ws.overlap_wgrad = args.wgrad_streams
     opt = make_opt()
     ts = PMVAETrainStep(model, cfg, opt, B, xs, seed=1234, world_size=world, rank=rank, use_graph=args.graph,
-                        **({"overlap_allreduce": not args.no_overlap} if world > 1 else {}))
+                        **({"overlap_allreduce": not args.no_overlap} if (world > 1 or os.environ.get("PM_FORCE_DP") == "1") else {}))
     pool = SyntheticDataset(cfg["data"], B, num_batches=16, seed=100 + rank, device=dev)
     batches = pool.batches
 
@@ -339,7 +351,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, xs, B)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -51,13 +51,21 @@ class _PlannedStep:
 
 def _make_reducer(store, world_size: int, overlap: bool):
     """data-parallel gradient reduction (parallel.GradReducer): buckets of a quarter of the buffer, 1-16 MB"""
-    if world_size <= 1:
+    import torch.distributed as dist
+
+    # PM_FORCE_DP=1 with an initialised process group: the reducer also runs on one rank (a 1-rank RCCL communicator on a single
+    # GPU rehearses the nccl stream semantics of the N > 1 path: asynchronous buckets on the communication stream, collectives
+    # inside a replayed launch plan)
+    forced = os.environ.get("PM_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized()
+    if world_size <= 1 and not forced:
         store.reducer = None
         return None
     from .parallel import GradReducer
 
     total = store.flat_g.numel() * 4
-    store.reducer = GradReducer(store, bucket_bytes=max(1 << 20, min(16 << 20, total // 4)), overlap=overlap)
+    mb = os.environ.get("PM_BUCKET_MB")                       # A/B knob for measurements
+    bucket = int(float(mb) * (1 << 20)) if mb else max(1 << 20, min(16 << 20, total // 4))
+    store.reducer = GradReducer(store, bucket_bytes=bucket, overlap=overlap)
     return store.reducer
 
 
@@ -151,7 +159,7 @@ class PMVAETrainStep(_PlannedStep):
 
     def _eager_sequence(self) -> None:
         self._forward_backward()
-        if self.world_size > 1:
+        if self.reducer is not None:
             self._allreduce()
         self._update()
 
@@ -245,7 +253,7 @@ class VQVAETrainStep(_PlannedStep):
         m(self.x, is_training=True)
         m.zero_grad()
         m.backward()
-        if self.world_size > 1:
+        if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
         s.split_all()
@@ -356,7 +364,7 @@ class PMVQVAETrainStep(_PlannedStep):
             self.ws.wgrad_batch.flush()
             self.ws.wgrad_batch = None
         self.ws.join_aux()
-        if self.world_size > 1:
+        if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
         s.split_all()
@@ -447,7 +455,7 @@ class VDVAETrainStep(_PlannedStep):
         m(self.x, self.b, self.eps)
         m.zero_grad()
         m.backward()
-        if self.world_size > 1:
+        if self.reducer is not None:
             self.reducer.finish()       # the clip / non-finite decision below sees the REDUCED gradient on every rank
         ops.sumsq(s.flat_g, self.gnorm_sq)
         ops.adam_step_clip_ema(s.flat_p, s.flat_g, s.flat_m, s.flat_v, self.ema, s.n_decay, self.opt_count, self.gnorm_sq,
