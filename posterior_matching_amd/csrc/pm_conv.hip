@@ -1803,6 +1803,237 @@ void launch_image(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const _
                        ip.nct);
 }
 
+// ------------- the same residence for the zero-dilated (d = 2, a = 1) problems: stride-2 transposed convolutions forward and
+// the data gradients of stride-2 convolutions,  src * 2 = dst + tap * cs + off ---------------------------------------------
+// In flat position order half the lanes of a row tile would miss every tap, so positions are walked CLASS-major: class
+// (ry, rx) = (dst_y & 1, dst_x & 1) only meets the taps ky = k0y, k0y + 2, ... with (ry + k0y * cs + off) even (likewise
+// in x): four small stride-1 convolutions over the same LDS-resident source image, each with its own tap list.  A wave owns
+// one class, one 32-column tile and up to T row tiles of that class (B fragments shared by the T tiles); the classes carry
+// 9 / 6 / 6 / 4 taps of a 5x5 kernel, so waves finish at different times - there is no barrier to hold them.
+template <int T>
+__global__ __launch_bounds__(512, 2) void image_d2_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
+                                                               long long plane, int nct) {
+    constexpr int NSET = 4, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform for the compiler too: the class and its tap
+                                                                        // walk stay in scalar registers
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int b = blockIdx.x;
+    const int PS = g.C + 8;
+    const int cch = g.C / BK;
+    const int npos = g.IH * g.IW;
+    __bf16* Ph = reinterpret_cast<__bf16*>(dsm);
+    __bf16* Pl = Ph + (size_t)npos * PS + 64;
+    const int zoff = npos * PS;
+
+    // this wave: class (ry, rx), column tile ct, row tiles rt0 + j * wct of the class
+    const int wct = NW / (4 * nct);                                     // waves per (class, column tile)
+    const int grp = wave / wct, rt0 = wave - grp * wct;
+    const int cls = grp / nct, ct = grp - cls * nct;
+    const int ry = cls >> 1, rx = cls & 1;
+    const int OHc = g.OH >> 1, OWc = g.OW >> 1, Mc = OHc * OWc;
+    const int k0y = (ry + g.off) & 1, k0x = (rx + g.offx) & 1;         // cs = +-1: parity of ky * cs is that of ky
+    const int nty = (g.KH - k0y + 1) >> 1, ntx = (g.KW - k0x + 1) >> 1;
+    const int nsteps = nty * ntx * cch;                                 // this wave's k-steps
+    const int nw_all = g.KH * g.KW * cch;
+    const int n = ct * 32 + i;
+    const int ncl = (n < npad ? n : 0) * BK + 8 * h;
+
+    // a walker yields the k-steps of the class in order: (ky, kx, channel chunk) -> weight step index and tap offsets
+    struct Walk { int ky, kx, cc; };
+    struct Tap { int dy, dx, c0, widx; };
+    auto advance = [&](Walk& w) -> Tap {
+        int widx = (w.ky * g.KW + w.kx) * cch + w.cc;
+        widx = widx < nw_all ? widx : nw_all - 1;                       // past the last tap: anything valid (never used)
+        const Tap t{__builtin_amdgcn_readfirstlane(w.ky * g.cs), __builtin_amdgcn_readfirstlane(w.kx * g.cs),
+                    __builtin_amdgcn_readfirstlane(w.cc * BK), __builtin_amdgcn_readfirstlane(widx)};
+        if (++w.cc == cch) {
+            w.cc = 0;
+            w.kx += 2;
+            if (w.kx >= g.KW) {
+                w.kx = k0x;
+                w.ky += 2;
+            }
+        }
+        return t;
+    };
+    Walk wa{k0y, k0x, 0}, wb{k0y, k0x, 0};                              // A side (3 steps in flight), B side (4 ahead)
+
+    bf16x8 bq[NSET][4];
+    auto load_b = [&](const Tap& t, bf16x8 (&bb)[4]) {
+        const __bf16* src = wsplit + (size_t)t.widx * npad * BK + ncl;
+        bb[0] = *reinterpret_cast<const bf16x8*>(src);
+        bb[1] = *reinterpret_cast<const bf16x8*>(src + plane);
+        bb[2] = *reinterpret_cast<const bf16x8*>(src + 16);
+        bb[3] = *reinterpret_cast<const bf16x8*>(src + plane + 16);
+    };
+    load_b(advance(wb), bq[0]);
+    load_b(advance(wb), bq[1]);
+    load_b(advance(wb), bq[2]);
+    load_b(advance(wb), bq[3]);
+    const float bv = p.bias ? p.bias[n < g.N ? n : 0] : 0.f;
+
+    if (tid < 32) {
+        reinterpret_cast<unsigned*>(Ph + zoff)[tid] = 0u;
+        reinterpret_cast<unsigned*>(Pl + zoff)[tid] = 0u;
+    }
+    {   // the source image: f32 -> in_act -> hi / lo bf16, a linear read
+        const float* img = p.in + (size_t)b * npos * g.C;
+        const int c4n = g.C >> 2;
+        const int total = npos * c4n;
+        const bool in_relu = g.in_act == PM_ACT_RELU;
+        const float in_ns = g.in_act == PM_ACT_LEAKY ? g.slope : 1.f;
+        constexpr int PB = 8;
+        for (int e0 = tid; e0 < total; e0 += 64 * NW * PB) {
+            f32x4 v[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int e = e0 + 64 * NW * j;
+                v[j] = *reinterpret_cast<const f32x4*>(img + 4 * (size_t)(e < total ? e : total - 1));
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int e = e0 + 64 * NW * j;
+                const int ee = e < total ? e : total - 1;
+                const int pos = ee / c4n, c4 = ee - pos * c4n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = v[j][q];
+                    const float neg = in_relu ? 0.f : x * in_ns;
+                    v[j][q] = x >= 0.f ? x : neg;
+                }
+                u32x2 h2, l2;
+                split4(v[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + pos * PS + 4 * c4) = h2;
+                *reinterpret_cast<u32x2*>(Pl + pos * PS + 4 * c4) = l2;
+            }
+        }
+    }
+
+    // per row tile: this lane's A row = class position m -> dst (oy, ox); py = oy + off, px = ox + offx (source coordinate
+    // times two before the tap is added)
+    int py[T], px[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int m = 32 * (rt0 + j * wct) + i;
+        const int cy = m / OWc, cx = m - cy * OWc;
+        py[j] = m < Mc ? 2 * cy + ry + g.off : ROW_INVALID;
+        px[j] = 2 * cx + rx + g.offx;
+    }
+    f32x16 acc[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    __syncthreads();                 // image visible; the only barrier of the kernel
+
+    bf16x8 a[4][4];
+    auto read_a = [&](const Tap& k, int j, bf16x8 (&aa)[4]) {
+        const int iy = (py[j] + k.dy) >> 1, ix = (px[j] + k.dx) >> 1;    // even by construction of the class's tap list
+        const bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+        const int o = (ok ? (iy * g.IW + ix) * PS + k.c0 : zoff) + 8 * h;
+        aa[0] = *reinterpret_cast<const bf16x8*>(Ph + o);
+        aa[1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
+        aa[2] = *reinterpret_cast<const bf16x8*>(Pl + o);
+        aa[3] = *reinterpret_cast<const bf16x8*>(Pl + o + 16);
+    };
+    Tap t0, t1, t2;
+    auto step = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int cur = (u * T + j) & 3;
+            const int jn = j + 2;
+            read_a(jn / T == 0 ? t0 : jn / T == 1 ? t1 : t2, jn % T, a[(cur + 2) & 3]);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], bq[u][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][2], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][3], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][3], bq[u][2], acc[j], 0, 0, 0);
+        }
+        t0 = t1;
+        t1 = t2;
+        t2 = advance(wa);
+        load_b(advance(wb), bq[u]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    using U3 = std::integral_constant<int, 3>;
+    static_assert(T == 1 || T == 2 || T == 4, "item index mod 4 must be static inside a group of NSET k-steps");
+    if (rt0 * 32 < Mc && nsteps > 0) {
+        t0 = advance(wa);
+        t1 = advance(wa);
+        t2 = advance(wa);
+        read_a(t0, 0, a[0]);
+        read_a(T == 1 ? t1 : t0, T == 1 ? 0 : 1, a[1]);
+        int s0 = 0;
+        for (; s0 + NSET <= nsteps; s0 += NSET) {
+            step(U0{});
+            step(U1{});
+            step(U2{});
+            step(U3{});
+        }
+        if (s0 < nsteps) {
+            step(U0{});
+            if (s0 + 1 < nsteps) {
+                step(U1{});
+                if (s0 + 2 < nsteps) step(U2{});
+            }
+        }
+    }
+    if (rt0 * 32 < Mc && n < g.N) {                                      // a class without taps (1x1 kernels) still owes bias
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            int ro[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = 32 * (rt0 + j * wct) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int cy = m / OWc, cx = m - cy * OWc;
+                ro[e] = m < Mc ? ((b * g.OH + 2 * cy + ry) * g.OW + 2 * cx + rx) * g.N : -1;
+            }
+            pm_epilogue_tile(acc[j], ro, n, bv, p.aux, p.res, p.out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
+        }
+    }
+}
+
+bool plan_image_d2(const Geom& g, int groups, ImagePlan& ip) {
+    if (groups != 1 || g.d != 2 || g.a != 1 || g.C % BK != 0 || g.B < 128) return false;
+    if (g.in_act != PM_ACT_NONE && g.in_act != PM_ACT_RELU && g.in_act != PM_ACT_LEAKY) return false;
+    if (g.KH * g.KW < 4 || g.kws != g.KW || (g.OH & 1) || (g.OW & 1)) return false;
+    if (g.IH * 2 < g.KH || g.IW * 2 < g.KW) return false;
+    ip.lds = 2 * ((size_t)g.IH * g.IW * (g.C + 8) + 64) * 2;
+    if (ip.lds > 158 * 1024) return false;
+    ip.nct = (g.N + 31) / 32;
+    if (ip.nct != 1 && ip.nct != 2) return false;
+    ip.nw = 8;
+    const int wct = 8 / (4 * ip.nct);
+    const int rt = ((g.OH >> 1) * (g.OW >> 1) + 31) / 32;
+    int t = (rt + wct - 1) / wct;
+    if (t > 4) return false;
+    ip.t = t == 3 ? 4 : t;
+    return true;
+}
+
+template <int T>
+void launch_image_d2(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const __bf16* ws, int npad, long long plane) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&image_d2_bf16_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    PM_KTAG("image_d2_bf16_kernel<%d>", T);
+    hipLaunchKernelGGL((image_d2_bf16_kernel<T>), dim3((unsigned)a.g.B), dim3(512), ip.lds, s, a, ws, npad, plane, ip.nct);
+}
+
 // ------------- zero-dilated (d = 2) problems, patch-staged with the four residue classes fused -------------
 // Stride-2 transposed convolutions (forward) and the data gradients of stride-2 convolutions:  src * 2 = dst + tap * cs + off.
 // An output position of residue class (ry, rx) = (dst_y & 1, dst_x & 1) only meets the taps with
@@ -3200,6 +3431,13 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
         else if (ip.t == 2) launch_image<4, 2>(ip, s, a, ws, npad, plane);
         else launch_image<4, 1>(ip, s, a, ws, npad, plane);
         return pm_check_launch("pm_gather_gemm_bf16(image)");
+    }
+    if (!image_off && plan_image_d2(a.g, G, ip)) {    // zero-dilated problems: class-major walk over the resident source image
+        a.ksplit = 1;
+        if (ip.t == 4) launch_image_d2<4>(ip, s, a, ws, npad, plane);
+        else if (ip.t == 2) launch_image_d2<2>(ip, s, a, ws, npad, plane);
+        else launch_image_d2<1>(ip, s, a, ws, npad, plane);
+        return pm_check_launch("pm_gather_gemm_bf16(image_d2)");
     }
     PatchPlan pp;
     static const bool patch_off = getenv("PM_NO_PATCH") != nullptr;      // A/B switch for measurements

@@ -59,6 +59,12 @@ CONV_CASES = [
     ("conv", 3, 11, 2, 16, 3, 1, "SAME"), ("conv", 300, 14, 1, 24, 5, 1, "SAME"), ("convT", 2, 10, 8, 1, 3, 1, "SAME"),
     ("conv", 2, 12, 16, 1, 5, 1, "SAME"), ("convT", 3, 9, 2, 20, 5, 1, "SAME"), ("conv", 2, 40, 1, 32, 3, 1, "SAME"),
     ("convT", 2, 9, 64, 1, 3, 1, "SAME"), ("conv", 2, 12, 32, 1, 5, 1, "SAME"),   # wide -> 1 on the matrix cores
+    # batches >= 128: the image-resident forms (image_conv_bf16 / image_d2_bf16): ragged position counts, 1 / 2 / 4 row tiles
+    # per wave, 1 / 2 / 4 column tiles, stride 2, flipped taps, and the class-major walk of the zero-dilated problems
+    # (stride-2 transposed convolutions forward, stride-2 convolutions' data gradients; 4x4 and 5x5 kernels)
+    ("conv", 128, 13, 32, 32, 5, 1, "SAME"), ("conv", 128, 14, 32, 64, 5, 2, "SAME"), ("conv", 128, 12, 64, 128, 3, 1, "SAME"),
+    ("convT", 128, 9, 32, 32, 5, 1, "SAME"), ("convT", 128, 7, 64, 64, 5, 2, "SAME"), ("convT", 128, 6, 32, 32, 4, 2, "SAME"),
+    ("conv", 128, 12, 32, 32, 5, 2, "SAME"), ("convT", 128, 14, 32, 32, 5, 2, "SAME"),
 ]
 
 
