@@ -23,13 +23,23 @@ constexpr int TRIL_MAXK = 64;
 
 // Stage one example's scale factor into LDS as Lp[r][c] (row stride k+1, conflict-free per-row reads),
 // softplus + shift already applied on the diagonal.  `v` points at params + k.
+// Loads are issued 16 at a time with clamped indices, then consumed: a load under `if (c <= r)` makes the compiler drain
+// vmcnt at the join, i.e. one memory round trip per loop trip (16 of them for k = 32: the whole kernel was 17 us of latency).
 __device__ __forceinline__ void tril_stage(const float* __restrict__ v, float* Lp, int k, int lane) {
-    for (int t = lane; t < k * k; t += 64) {
-        int r = t / k, c = t - r * k;
-        if (c <= r) {
-            float x = v[tril_index(r, c, k)];
-            if (c == r) x = pm_softplus(x) + kDiagShift;
-            Lp[r * (k + 1) + c] = x;
+    constexpr int NB = 16;
+    for (int t0 = lane; t0 < k * k; t0 += 64 * NB) {
+        float x[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = t0 + 64 * j;
+            const int r = t / k, c = t - r * k;
+            x[j] = v[(t < k * k && c <= r) ? tril_index(r, c, k) : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = t0 + 64 * j;
+            const int r = t / k, c = t - r * k;
+            if (t < k * k && c <= r) Lp[r * (k + 1) + c] = c == r ? pm_softplus(x[j]) + kDiagShift : x[j];
         }
     }
 }
@@ -88,20 +98,40 @@ __global__ __launch_bounds__(256) void tril_sample_kl_bwd_kernel(const float* __
     __syncthreads();
     const float gk = g_kl[b];
     if (!active) return;
-    if (lane < k) drow[lane] = dzs[lane] + gk * prow[lane];  // d loc
-    for (int t = lane; t < k * k; t += 64) {
-        int r = t / k, c = t - r * k;
-        if (c > r) continue;
-        int idx = k + tril_index(r, c, k);
-        float raw = prow[idx];
-        float g;
-        if (c == r) {
-            float l = pm_softplus(raw) + kDiagShift;
-            g = (dzs[r] * es[c] + gk * (l - 1.f / l)) * pm_sigmoid(raw);
-        } else {
-            g = dzs[r] * es[c] + gk * raw;
+    const float mu = lane < k ? prow[lane] : 0.f;
+    // loads (16 per lane, clamped), arithmetic, stores in three phases: interleaved, every load waits for the store in front
+    // of it (vmcnt counts both) - 16 round trips
+    constexpr int NB = 16;
+    for (int t0 = lane; t0 < k * k; t0 += 64 * NB) {
+        float raw[NB], gv[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = t0 + 64 * j;
+            const int r = t / k, c = t - r * k;
+            raw[j] = prow[(t < k * k && c <= r) ? k + tril_index(r, c, k) : 0];
         }
-        drow[idx] = g;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = t0 + 64 * j;
+            const int tt = t < k * k ? t : 0;
+            const int r = tt / k, c = tt - r * k;
+            float g;
+            if (c == r) {
+                const float l = pm_softplus(raw[j]) + kDiagShift;
+                g = (dzs[r] * es[c] + gk * (l - 1.f / l)) * pm_sigmoid(raw[j]);
+            } else {
+                g = dzs[r] * es[c] + gk * raw[j];
+            }
+            asm volatile("" : "+v"(g));
+            gv[j] = g;
+        }
+        if (t0 == lane && lane < k) drow[lane] = dzs[lane] + gk * mu;  // d loc
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = t0 + 64 * j;
+            const int r = t / k, c = t - r * k;
+            if (t < k * k && c <= r) drow[k + tril_index(r, c, k)] = gv[j];
+        }
     }
 }
 
