@@ -33,7 +33,7 @@ class PosteriorMatchingVAE(Module):
         self._device = device
         self._seed = seed
         self.concurrent = True   # run the ELBO and the posterior-matching chains on two HIP streams
-        self.lend_wgrad = ""     # "dec" / "all": weight gradients of the ELBO chain's decoder / decoder+encoder on the side stream
+        self.lend_wgrad = ""     # "dec" / "enc" / "all": weight gradients of the ELBO chain's decoder / encoder / both on the side stream
         self.store: Optional[ParamStore] = None
         if not isinstance(posterior_dist, (TriLGaussian, DiagonalGaussian)):
             raise NotImplementedError("posterior_dist must be TriLGaussian or DiagonalGaussian")
@@ -282,6 +282,8 @@ class PosteriorMatchingVAE(Module):
             ops.wait_event(main, dz_ready)
             ops.axpy1(dz_pm, dz)
         denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
+        if lend == "enc":       # the encoder's weight gradients, issued when the posterior-matching chain has long finished
+            self.ws.wgrad_stream = side
         self.encoder_net.backward(denc, need_input_grad=False)
         self.ws.wgrad_stream = None
         self.ws.join_aux()
