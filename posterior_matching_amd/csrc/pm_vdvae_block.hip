@@ -152,7 +152,10 @@ __device__ __forceinline__ int band_off(int il, int yl, int x, int rows, int W) 
 // each thread keeps the pieces of the next PD k-steps in registers (4 VGPRs per k-step), so the L2 round trip (~1 us) of a
 // k-step is covered by the PD - 1 steps in front of it.  One workgroup barrier per k-step: slot (ks & 1) is rewritten
 // only after every wave has passed the barrier of step ks - 1, i.e. has finished multiplying step ks - 2.
-constexpr int PD = 6;            // k-steps of weights in flight per thread
+#ifndef PM_VB_PD
+#define PM_VB_PD 6
+#endif
+constexpr int PD = PM_VB_PD;    // k-steps of weights in flight per thread (even: ring slot = step & 1)
 constexpr int BROWP = 40;        // ring row: 32 bf16 + 16 B pad (80-byte pitch: conflict-free 16-byte fragment reads)
 constexpr int RING_SLOT = 2 * 64 * BROWP;   // bf16 elements of one slot (2 planes x 64 columns)
 
