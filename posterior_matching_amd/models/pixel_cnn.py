@@ -12,6 +12,8 @@ Only num_hierarchies == 1 is implemented (every BASELINE config uses 1).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -62,6 +64,8 @@ class PixelCNN(Module):
         self._num_indices, self._dropout = num_indices, float(dropout)
         self._num_resnet, self._num_filters = num_resnet, num_filters
         self._receptive_field_dims = tuple(receptive_field_dims)
+
+    two_streams = True       # forward: the vertical stack on its own stream (see logits)
 
     @property
     def event_shape(self) -> Tuple[int, ...]:
@@ -196,15 +200,40 @@ class PixelCNN(Module):
             return out
 
         nres = self._num_resnet
+        # The vertical stack never reads the horizontal one (a horizontal block reads the vertical block of its level), so
+        # the two are two dependent chains of small launches: the vertical chain runs ahead on its own stream and every
+        # horizontal block waits for the event of the vertical output it reads.  (One stream: 2 x the chain length.)
+        main = torch.cuda.current_stream(value.device)
+        two = self.two_streams and not os.environ.get("PM_PIXELCNN_ONE_STREAM")
+        vs = main
+        if two:
+            if getattr(self, "_vstream", None) is None:
+                self._vstream = torch.cuda.Stream(device=value.device)
+                self._vev = [torch.cuda.Event() for _ in range(2 * nres)]
+            vs = self._vstream
+            ops.wait_stream(vs, main)                           # embeddings, v_init, conditional projections
+
+        def vblock(k, blk, *args, **kw):
+            if not two:
+                return run_block(blk, *args, **kw)
+            with torch.cuda.stream(vs):
+                out = run_block(blk, *args, **kw)
+                ops.record_event(self._vev[k], vs)
+            return out
+
         V, Hs = [v], [h]
         for i in range(nres):                                   # down pass (:427-460)
-            v = run_block(self.blocks[2 * i], V[-1])
+            v = vblock(i, self.blocks[2 * i], V[-1])
             V.append(v)
+            if two:
+                ops.wait_event(main, self._vev[i])
             h = run_block(self.blocks[2 * i + 1], Hs[-1], extra_a=v)
             Hs.append(h)
         up_v, up_h = V.pop(), Hs.pop()
         for i in range(nres):                                   # up pass (:487-522)
-            up_v = run_block(self.blocks[2 * nres + 2 * i], up_v, extra_a=V.pop())
+            up_v = vblock(nres + i, self.blocks[2 * nres + 2 * i], up_v, extra_a=V.pop())
+            if two:
+                ops.wait_event(main, self._vev[nres + i])
             up_h = run_block(self.blocks[2 * nres + 2 * i + 1], up_h, extra_a=up_v, extra_b=Hs.pop())
         self._up_h = up_h
         x_out = self.buf("x_out", sh(F))
