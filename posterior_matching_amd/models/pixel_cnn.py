@@ -293,6 +293,47 @@ class PixelCNN(Module):
         return out.view(*shape, B, H, W) if shape else out[0]
 
     # ------------------------------------------------------------------------------------------
+    def _block_backward(self, blk: "_Block", gbuf, gbuf_h, gname, sh, dh_all, R: int, P: int, F: int, two: bool, from_h) -> None:
+        """data gradients of one gated block (its weight gradients go to the grouped launches or the companion stream)"""
+        n = blk.name
+        input_x, extra_a, extra_b = self._io[blk.group]
+        out = self.buf(f"{n}/out", sh(F))
+        dout = gbuf(out, n)
+        if two and out.data_ptr() in from_h:                                   # the horizontal reader's share, kept apart
+            ops.axpy1(from_h[out.data_ptr()], dout)
+        d_in = gbuf(input_x, gname(input_x))
+        ops.axpy1(dout, d_in)                                              # residual branch
+        y = self.buf(f"{n}/y", sh(2 * F))
+        dy = self.buf(f"{n}/dy", sh(2 * F))
+        ops.gate_bwd(y, self._hproj[blk.group] if self._hproj is not None else None, dout, dy, P)
+        if dh_all is not None:
+            ops.rows_sum(dy.view(R, 2 * F), dh_all[blk.group], P)
+        ce2 = self.buf(f"{n}/ce2", sh(2 * F))
+        self._wg(blk.conv2, ce2, dy)
+        dce2 = self.buf(f"{n}/dce2", sh(2 * F))
+        self._dg(blk.conv2, dy, dce2)
+        x1 = self.buf(f"{n}/x1", sh(F))
+        dx1 = self.buf(f"{n}/dx1", sh(F))
+        ops.concat_elu_bwd(x1, None, self._drops[blk.group], dce2, dx1, None, accumulate=False)
+        if blk.linear is not None:
+            ce_e = self.buf(f"{n}/ce_e", (R, blk.linear.g.CI))
+            self._wg(blk.linear, ce_e, dx1.view(R, F))
+            dce_e = self.buf(f"{n}/dce_e", (R, blk.linear.g.CI))
+            self._dg(blk.linear, dx1.view(R, F), dce_e)
+            # a horizontal block's extra_a is a VERTICAL tensor: with two chains its gradient goes to that tensor's own buffer
+            to_h = two and blk.stack == "horizontal"
+            da = gbuf_h(extra_a, gname(extra_a)) if to_h else gbuf(extra_a, gname(extra_a))
+            db = gbuf(extra_b, gname(extra_b)) if extra_b is not None else None
+            ops.concat_elu_bwd(extra_a, extra_b, None, dce_e, da, db, accumulate=True)
+        ce1 = self.buf(f"{n}/ce1", sh(2 * F))
+        self._wg(blk.conv1, ce1, dx1)
+        dce1 = self.buf(f"{n}/dce1", sh(2 * F))
+        self._dg(blk.conv1, dx1, dce1)
+        ops.concat_elu_bwd(input_x, None, None, dce1, d_in, None, accumulate=True)
+        if self.store.reducer is not None and self.ws.wgrad_batch is None:   # data-parallel: this block's weight gradients are final
+            self.ws.join_aux()
+            self.store.grads_ready([f"{self.prefix}/{n}/{leaf}" for leaf in ("conv1", "linear", "conv2")])
+
     def backward(self, g_ll: torch.Tensor) -> Optional[torch.Tensor]:
         """g_ll [B] = d loss / d log_prob.  Accumulates parameter gradients; returns d loss / d
         conditional_input [B, cond_dim] (None without conditioning)."""
@@ -330,42 +371,47 @@ class PixelCNN(Module):
         ops.elu_bwd(self._up_h, dx_out, gbuf(self._up_h, gname(self._up_h)), accumulate=True)
         dh_all = self.buf("dhproj", (G, B, 2 * F)) if self._hproj is not None else None
 
+        # Two chains again (see logits): a horizontal block's backward writes gradients of horizontal tensors and of ONE
+        # vertical tensor (its extra_a); a vertical block only touches vertical tensors.  With the horizontal blocks'
+        # contribution to a vertical tensor kept in its own buffer, the horizontal chain never waits for the vertical one: it
+        # runs ahead on the main stream, the vertical chain follows on its stream and waits, block by block, for the event
+        # of the horizontal block that read its output.  (Weight gradients are collected for the grouped launches at the
+        # end, so only data gradients are on the chains; without the batch the single-stream order is kept.)
+        main = torch.cuda.current_stream(dlogits.device)
+        two = (self.two_streams and self.ws.wgrad_batch is not None and getattr(self, "_vstream", None) is not None
+               and not os.environ.get("PM_PIXELCNN_ONE_STREAM"))
+        vs = self._vstream if two else main
+        from_h: Dict[int, torch.Tensor] = {}
+
+        def gbuf_h(t: torch.Tensor, name: str) -> torch.Tensor:
+            key = t.data_ptr()
+            if key not in from_h:
+                gb = self.buf(f"grad_h/{name}", tuple(t.shape))
+                ops.fill_zero(gb)
+                from_h[key] = gb
+            return from_h[key]
+
+        if two:
+            if getattr(self, "_hev", None) is None:
+                self._hev = [torch.cuda.Event() for _ in range(G)]
+            ops.wait_stream(vs, main)
+
         for blk in reversed(self.blocks):
             n = blk.name
             input_x, extra_a, extra_b = self._io[blk.group]
             out = self.buf(f"{n}/out", sh(F))
-            dout = gbuf(out, n)
-            d_in = gbuf(input_x, gname(input_x))
-            ops.axpy1(dout, d_in)                                              # residual branch
-            y = self.buf(f"{n}/y", sh(2 * F))
-            dy = self.buf(f"{n}/dy", sh(2 * F))
-            ops.gate_bwd(y, self._hproj[blk.group] if self._hproj is not None else None, dout, dy, P)
-            if dh_all is not None:
-                ops.rows_sum(dy.view(R, 2 * F), dh_all[blk.group], P)
-            ce2 = self.buf(f"{n}/ce2", sh(2 * F))
-            self._wg(blk.conv2, ce2, dy)
-            dce2 = self.buf(f"{n}/dce2", sh(2 * F))
-            self._dg(blk.conv2, dy, dce2)
-            x1 = self.buf(f"{n}/x1", sh(F))
-            dx1 = self.buf(f"{n}/dx1", sh(F))
-            ops.concat_elu_bwd(x1, None, self._drops[blk.group], dce2, dx1, None, accumulate=False)
-            if blk.linear is not None:
-                ce_e = self.buf(f"{n}/ce_e", (R, blk.linear.g.CI))
-                self._wg(blk.linear, ce_e, dx1.view(R, F))
-                dce_e = self.buf(f"{n}/dce_e", (R, blk.linear.g.CI))
-                self._dg(blk.linear, dx1.view(R, F), dce_e)
-                da = gbuf(extra_a, gname(extra_a))
-                db = gbuf(extra_b, gname(extra_b)) if extra_b is not None else None
-                ops.concat_elu_bwd(extra_a, extra_b, None, dce_e, da, db, accumulate=True)
-            ce1 = self.buf(f"{n}/ce1", sh(2 * F))
-            self._wg(blk.conv1, ce1, dx1)
-            dce1 = self.buf(f"{n}/dce1", sh(2 * F))
-            self._dg(blk.conv1, dx1, dce1)
-            ops.concat_elu_bwd(input_x, None, None, dce1, d_in, None, accumulate=True)
-            if self.store.reducer is not None and self.ws.wgrad_batch is None:   # data-parallel: this block's weight gradients are final
-                self.ws.join_aux()
-                self.store.grads_ready([f"{self.prefix}/{n}/{leaf}" for leaf in ("conv1", "linear", "conv2")])
-
+            vertical = blk.stack == "vertical"
+            if two and vertical:
+                # its output was read (as extra_a) by the horizontal block right behind it in execution order
+                ops.wait_event(vs, self._hev[blk.group + 1])
+                with torch.cuda.stream(vs):
+                    self._block_backward(blk, gbuf, gbuf_h, gname, sh, dh_all, R, P, F, two, from_h)
+                continue
+            self._block_backward(blk, gbuf, gbuf_h, gname, sh, dh_all, R, P, F, two, from_h)
+            if two:
+                ops.record_event(self._hev[blk.group], main)
+        if two:
+            ops.wait_stream(main, vs)
         dv0, dh0 = gbuf(self._v0, "v_init"), gbuf(self._h0, "h_init")
         emb = self._emb
         self._wg(self.v_init, emb, dv0)
