@@ -13,6 +13,7 @@ with channel padding), multi-channel logistic mixtures (coefficients), is_log_pr
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -375,7 +376,13 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.add_cols(x_in, self._pr, 2 * Z, x1)              # x += h (:558)
         self._z = self.buf("z", sh(Z))
         ops.diag_sample_kl_fwd(self._pp, self._pr, eps, self._z, kl, P)
-        ops.diag_tril_kl_fwd(self._pp, self._mp, pm_kl, Z, P)
+        ks = self.kl_stream          # pm_kl only feeds the loss: off the chain, beside z_proj and the resnet Block
+        if ks is not None:
+            ops.wait_stream(ks, main)
+            with torch.cuda.stream(ks):
+                ops.diag_tril_kl_fwd(self._pp, self._mp, pm_kl, Z, P)
+        else:
+            ops.diag_tril_kl_fwd(self._pp, self._mp, pm_kl, Z, P)
         x2 = self.buf("x2", sh(W))
         ops.layer_forward(self.z_proj.g, self._z, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
                           wsplit=self.store.split_view(self.z_proj.ws_f))
@@ -467,6 +474,20 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.gelu_fwd(x2, None, x2g)
         return self.resnet.forward(x2g, res=x2)
 
+    kl_stream = None             # set by the model: side stream of the posterior-matching KL kernels
+    _kl_ev_pending = False
+
+    def pm_kl_backward(self, g_pm: float) -> None:
+        """d pm_kl / d(masked-posterior parameters) depends on forward values only (the loss weight is a constant): the model
+        launches it for every decoder block on the side stream when the backward pass starts, so that the 20 launches are off
+        the dependent chain; backward() then only waits for the event"""
+        dmp = self.buf("dmp", tuple(self._mp.shape))
+        ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, self.Z, self.base * self.base)
+        if getattr(self, "_kl_ev", None) is None:
+            self._kl_ev = torch.cuda.Event()
+        ops.record_event(self._kl_ev, torch.cuda.current_stream(dmp.device))
+        self._kl_ev_pending = True
+
     def backward(self, dx3: torch.Tensor, dacts: torch.Tensor, dmacts: torch.Tensor, g_kl: float, g_pm: float,
                  streams=None) -> torch.Tensor:
         """dx3: gradient w.r.t. this block's output.  Accumulates into dacts / dmacts (the encoder
@@ -485,7 +506,11 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.diag_sample_kl_bwd(self._pp, self._pr, self._eps, dz, g_kl, dpp, dpr)
         ops.copy_cols(dx2, dpr, 2 * Z)                                            # d h = d x1
         dmp = self.buf("dmp", tuple(self._mp.shape))
-        ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, P)
+        if self._kl_ev_pending:      # launched on the side stream when the backward pass started (pm_kl_backward)
+            ops.wait_event(main, self._kl_ev)
+            self._kl_ev_pending = False
+        else:
+            ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, P)
         if getattr(self, "_grouped", False):
             da, dam, dxin = self.buf("da", sh(2 * W)), self.buf("dam", sh(2 * W)), self.buf("dxin", sh(W))
             ios = [self.posterior.bwd_io(dpp, da, None, None), self.masked_posterior.bwd_io(dmp, dam, None, None),
@@ -493,7 +518,13 @@ class PosteriorMatchingDecoderBlock(Module):
             ops.vdvae_blocks_bwd(ios, B, r, r, self.posterior.mid, self.posterior.c2.g.k)
             for blk in (self.posterior, self.masked_posterior, self.prior):
                 blk.weight_grads()
-            ops.gelu_bwd(self._x_in, self._macts, dam, None, dmacts, accumulate=True)   # no gradient into stop_gradient(x)
+            ks = self.kl_stream
+            if ks is not None:       # dmacts only feeds the masked encoder's backward at the very end: off the chain
+                ops.wait_stream(ks, main)
+                with torch.cuda.stream(ks):
+                    ops.gelu_bwd(self._x_in, self._macts, dam, None, dmacts, accumulate=True)
+            else:
+                ops.gelu_bwd(self._x_in, self._macts, dam, None, dmacts, accumulate=True)   # no gradient into stop_gradient(x)
             ops.gelu_bwd(self._x_in, self._acts, da, dxin, dacts, accumulate=True)
             return dxin
         if streams is not None:
@@ -536,6 +567,13 @@ class PosteriorMatchingVDVAE(Module):
         self.store: Optional[ParamStore] = None
         self.concurrent = True      # independent chains (the two encoders; the three Blocks of a decoder block) on companion streams
         self._streams = None
+
+    def _kl_stream(self, device):
+        if not self.concurrent or os.environ.get("PM_VDVAE_KL_INLINE"):
+            return None
+        if getattr(self, "_kls", None) is None:
+            self._kls = torch.cuda.Stream(device=device)
+        return self._kls
 
     def _branch_streams(self, device):
         if not self.concurrent:
@@ -619,6 +657,7 @@ class PosteriorMatchingVDVAE(Module):
         xs: Dict[int, torch.Tensor] = {}
         self._first_use: Dict[int, int] = {}
         self._x_ins: List[torch.Tensor] = []
+        kls = self._kl_stream(x.device)
         for i, blk in enumerate(self.dec_blocks):
             r = blk.base
             if r in xs:
@@ -628,7 +667,10 @@ class PosteriorMatchingVDVAE(Module):
                 self._first_use[r] = i
             if blk.mixin is not None:
                 ops.resize_nearest_add(xs[blk.mixin], x_in)
+            blk.kl_stream = kls
             xs[r] = blk.forward(x_in, acts[r], macts[r], eps[i], kl, pm_kl, streams=streams)
+        if kls is not None:
+            ops.wait_stream(main, kls)                 # pm_kl is complete before the loss reads it
         top = xs[H]
         self._top = top
         px_z = self.ws.get("decoder/px_z", tuple(top.shape))
@@ -845,6 +887,12 @@ class PosteriorMatchingVDVAE(Module):
             with torch.cuda.stream(flush_stream):
                 self.ws.wgrad_batch.flush()
 
+        ks = self._kl_stream(self._x.device)
+        if ks is not None:
+            ops.wait_stream(ks, main)
+            with torch.cuda.stream(ks):
+                for blk in reversed(self.dec_blocks):
+                    blk.pm_kl_backward(g)
         for i in reversed(range(len(self.dec_blocks))):
             blk = self.dec_blocks[i]
             r = blk.base
@@ -863,6 +911,8 @@ class PosteriorMatchingVDVAE(Module):
                 # x_in was the previous block of this resolution's output, and this block its only consumer (mix-in
                 # sources are always the LAST state of a coarser resolution): hand dxin over as that block's dx3
                 dxs[r] = dxin
+        if ks is not None:
+            ops.wait_stream(main, ks)                   # the masked-encoder activation gradients accumulated on the side stream
         if flush_stream is not None:
             flush_side()                                # the coarsest decoder resolution; the encoders' follow at the end
         if getattr(self, "_paired", False):
