@@ -353,11 +353,21 @@ class PosteriorMatchingDecoderBlock(Module):
         main = torch.cuda.current_stream(x_in.device)
         self._grouped = all(b._fused() is not None for b in (self.posterior, self.masked_posterior, self.prior)) and W % 32 == 0
         if self._grouped:
-            # the three Blocks only share x_in: ONE launch (blockIdx.y picks the Block), no companion streams
+            # the three Blocks only share x_in: ONE launch (blockIdx.y picks the Block), no companion streams.  The
+            # masked-posterior Block only feeds pm_kl (and, backward, the masked encoder): with a side stream it is a chain
+            # of its own and the main chain's launch holds two Blocks (28x28 at per-GPU 16: 224 workgroups, one round on 256
+            # CUs instead of 336 in two)
             io_p, self._pp = self.posterior.fwd_io(x_in, acts, None, raw=True)
             io_m, self._mp = self.masked_posterior.fwd_io(x_in, macts, None, raw=True)   # stop_gradient(x): see backward
             io_r, self._pr = self.prior.fwd_io(x_in, None, None, raw=True)
-            ops.vdvae_blocks_fwd([io_p, io_m, io_r], B, r, r, self.posterior.mid, self.posterior.c2.g.k)
+            self._mp_split = self.kl_stream is not None and not os.environ.get("PM_VDVAE_GROUP3")
+            if self._mp_split:
+                ops.wait_stream(self.kl_stream, main)            # x_in is the previous block's output
+                with torch.cuda.stream(self.kl_stream):
+                    ops.vdvae_blocks_fwd([io_m], B, r, r, self.posterior.mid, self.posterior.c2.g.k)
+                ops.vdvae_blocks_fwd([io_p, io_r], B, r, r, self.posterior.mid, self.posterior.c2.g.k)
+            else:
+                ops.vdvae_blocks_fwd([io_p, io_m, io_r], B, r, r, self.posterior.mid, self.posterior.c2.g.k)
             streams = None
         s1, s2 = streams if streams is not None else (main, main)
         if streams is not None:
@@ -476,6 +486,22 @@ class PosteriorMatchingDecoderBlock(Module):
 
     kl_stream = None             # set by the model: side stream of the posterior-matching KL kernels
     _kl_ev_pending = False
+    _mp_split = False            # forward ran the masked-posterior Block as its own launch on the side stream
+    _mp_bwd_done = False
+
+    def masked_backward(self, g_pm: float, dmacts: torch.Tensor) -> None:
+        """everything behind pm_kl, on the side stream: d pm_kl / d(masked-posterior parameters) (forward values and a
+        constant), the masked-posterior Block's data gradients, its gelu' into the masked encoder's activation gradients.
+        Nothing here reads the main chain, so the model issues it for every decoder block when the backward pass starts."""
+        B, r, W, Z = self._x_in.shape[0], self.base, self.width, self.Z
+        dmp = self.buf("dmp", tuple(self._mp.shape))
+        ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, r * r)
+        dam = self.buf("dam", (B, r, r, 2 * W))
+        ops.vdvae_blocks_bwd([self.masked_posterior.bwd_io(dmp, dam, None, None)], B, r, r, self.posterior.mid,
+                             self.posterior.c2.g.k)
+        self.masked_posterior.weight_grads()
+        ops.gelu_bwd(self._x_in, self._macts, dam, None, dmacts, accumulate=True)   # no gradient into stop_gradient(x)
+        self._mp_bwd_done = True
 
     def pm_kl_backward(self, g_pm: float) -> None:
         """d pm_kl / d(masked-posterior parameters) depends on forward values only (the loss weight is a constant): the model
@@ -506,11 +532,23 @@ class PosteriorMatchingDecoderBlock(Module):
         ops.diag_sample_kl_bwd(self._pp, self._pr, self._eps, dz, g_kl, dpp, dpr)
         ops.copy_cols(dx2, dpr, 2 * Z)                                            # d h = d x1
         dmp = self.buf("dmp", tuple(self._mp.shape))
-        if self._kl_ev_pending:      # launched on the side stream when the backward pass started (pm_kl_backward)
+        if self._mp_bwd_done:
+            pass                     # dmp and everything behind it were handled on the side stream
+        elif self._kl_ev_pending:    # launched on the side stream when the backward pass started (pm_kl_backward)
             ops.wait_event(main, self._kl_ev)
             self._kl_ev_pending = False
         else:
             ops.diag_tril_kl_bwd(self._pp, self._mp, g_pm, dmp, Z, P)
+        if getattr(self, "_grouped", False) and self._mp_bwd_done:
+            # the masked-posterior Block's whole backward already ran on the side stream (masked_backward)
+            self._mp_bwd_done = False
+            da, dxin = self.buf("da", sh(2 * W)), self.buf("dxin", sh(W))
+            ios = [self.posterior.bwd_io(dpp, da, None, None), self.prior.bwd_io(dpr, dxin, self._x_in, dx2)]
+            ops.vdvae_blocks_bwd(ios, B, r, r, self.posterior.mid, self.posterior.c2.g.k)
+            self.posterior.weight_grads()
+            self.prior.weight_grads()
+            ops.gelu_bwd(self._x_in, self._acts, da, dxin, dacts, accumulate=True)
+            return dxin
         if getattr(self, "_grouped", False):
             da, dam, dxin = self.buf("da", sh(2 * W)), self.buf("dam", sh(2 * W)), self.buf("dxin", sh(W))
             ios = [self.posterior.bwd_io(dpp, da, None, None), self.masked_posterior.bwd_io(dmp, dam, None, None),
@@ -881,6 +919,8 @@ class PosteriorMatchingVDVAE(Module):
 
         def flush_side():
             ops.wait_stream(flush_stream, main)
+            if ks is not None:
+                ops.wait_stream(flush_stream, ks)       # the masked-posterior Blocks' operands were produced there
             if streams is not None:
                 ops.wait_stream(flush_stream, streams[0])
                 ops.wait_stream(flush_stream, streams[1])
@@ -892,7 +932,10 @@ class PosteriorMatchingVDVAE(Module):
             ops.wait_stream(ks, main)
             with torch.cuda.stream(ks):
                 for blk in reversed(self.dec_blocks):
-                    blk.pm_kl_backward(g)
+                    if blk._mp_split and self.ws.wgrad_batch is not None:
+                        blk.masked_backward(g, dmacts[blk.base])
+                    else:
+                        blk.pm_kl_backward(g)
         for i in reversed(range(len(self.dec_blocks))):
             blk = self.dec_blocks[i]
             r = blk.base
