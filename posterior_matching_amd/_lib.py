@@ -133,7 +133,7 @@ SIGNATURES = {
     "pm_embed_fwd": [_P, _P, _P, _P, _LL, _I, _I],
     "pm_embed_bwd": [_P, _P, _P, _P, _LL, _I, _I],
     "pm_concat_elu_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
-    "pm_concat_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I],
+    "pm_concat_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P],
     "pm_gate_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_gate_bwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_rows_sum": [_P, _P, _P, _LL, _I, _I],

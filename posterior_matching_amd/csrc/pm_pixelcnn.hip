@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void concat_elu_bwd_kernel(const float* __rest
                                                               const float* __restrict__ drop,
                                                               const float* __restrict__ dout, float* __restrict__ da,
                                                               float* __restrict__ db, long long R, int Ca, int Cb,
-                                                              int accumulate) {
+                                                              int accumulate, const float* __restrict__ add_a) {
     const int C = Ca + Cb;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * C) return;
@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void concat_elu_bwd_kernel(const float* __rest
     const float g = gp * elu_d(v) - gn * elu_d(-v);
     float* dst = first ? da : db;
     if (!dst) return;
-    dst[src] = accumulate ? dst[src] + g : g;
+    float r_ = accumulate ? dst[src] + g : g;
+    if (first && add_a) r_ += add_a[src];            // the block's residual path (d_in += dout) folded into this pass
+    dst[src] = r_;
 }
 
 // out = input + sigmoid(y_g + h_g) * (y_a + h_a);  y [R, 2F] = [activation | gate], h [B, 2F] broadcast over P rows
@@ -306,10 +308,10 @@ extern "C" int pm_concat_elu_fwd(pm_stream_t stream, const float* a, const float
 
 extern "C" int pm_concat_elu_bwd(pm_stream_t stream, const float* a, const float* b, const float* drop,
                                  const float* dout, float* da, float* db, long long rows, int Ca, int Cb,
-                                 int accumulate) {
-    if (!a || !dout || rows <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && !b)) return PM_EINVAL;
+                                 int accumulate, const float* add_a) {
+    if (!a || !dout || rows <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && !b) || (add_a && !da)) return PM_EINVAL;
     hipLaunchKernelGGL(concat_elu_bwd_kernel, dim3(blocks_for(rows * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, b,
-                       drop, dout, da, db, rows, Ca, Cb, accumulate);
+                       drop, dout, da, db, rows, Ca, Cb, accumulate, add_a);
     return pm_check_launch("pm_concat_elu_bwd");
 }
 

@@ -301,9 +301,8 @@ class PixelCNN(Module):
         dout = gbuf(out, n)
         if two and out.data_ptr() in from_h:                                   # the horizontal reader's share, kept apart
             ops.axpy1(from_h[out.data_ptr()], dout)
-        d_in = gbuf(input_x, gname(input_x))
-        ops.axpy1(dout, d_in)                                              # residual branch
-        y = self.buf(f"{n}/y", sh(2 * F))
+        d_in = gbuf(input_x, gname(input_x))                                  # (+= dout, the residual branch: folded into the
+        y = self.buf(f"{n}/y", sh(2 * F))                                      #  last concat_elu_bwd of the block)
         dy = self.buf(f"{n}/dy", sh(2 * F))
         ops.gate_bwd(y, self._hproj[blk.group] if self._hproj is not None else None, dout, dy, P)
         if dh_all is not None:
@@ -329,7 +328,7 @@ class PixelCNN(Module):
         self._wg(blk.conv1, ce1, dx1)
         dce1 = self.buf(f"{n}/dce1", sh(2 * F))
         self._dg(blk.conv1, dx1, dce1)
-        ops.concat_elu_bwd(input_x, None, None, dce1, d_in, None, accumulate=True)
+        ops.concat_elu_bwd(input_x, None, None, dce1, d_in, None, accumulate=True, add_a=dout)
         if self.store.reducer is not None and self.ws.wgrad_batch is None:   # data-parallel: this block's weight gradients are final
             self.ws.join_aux()
             self.store.grads_ready([f"{self.prefix}/{n}/{leaf}" for leaf in ("conv1", "linear", "conv2")])

@@ -730,10 +730,11 @@ def concat_elu_fwd(a, b, drop, out) -> None:
           work={"bytes": _nbytes(a, b, drop, out)})
 
 
-def concat_elu_bwd(a, b, drop, dout, da, db, accumulate: bool) -> None:
+def concat_elu_bwd(a, b, drop, dout, da, db, accumulate: bool, add_a=None) -> None:
+    """add_a (same shape as a): added to da in the same pass (a gated block's residual path d_in += dout)"""
     Ca, Cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
     _call("pm_concat_elu_bwd", _ptr(a), _ptr(b), _ptr(drop), _ptr(dout), _ptr(da), _ptr(db), a.numel() // Ca, Ca, Cb,
-          int(accumulate), work={"bytes": _nbytes(a, b, drop, dout, da, db)})
+          int(accumulate), _ptr(add_a), work={"bytes": _nbytes(a, b, drop, dout, da, db, add_a)})
 
 
 def gate_fwd(y, h, inp, out, P: int) -> None:
