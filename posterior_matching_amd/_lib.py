@@ -151,6 +151,8 @@ SIGNATURES = {
     "pm_info_gain_inputs": [_P, _P, _P, _P, _P, _I, _I, _I],
     "pm_gaussian_entropy": [_P, _P, _P, _LL, _I, _I, _I],
     "pm_info_gain_finish": [_P, _P, _P, _P, _I, _I],
+    "pm_sample_project_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I],
+    "pm_sample_project_bwd": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _P, _LL, _I, _I],
     "pm_mlp_chain_bf16": [_P, _P, _I, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _F],
     "pm_repeat_rows": [_P, _P, _P, _LL, _I, _LL],
     "pm_sigmoid": [_P, _P, _P, _LL],

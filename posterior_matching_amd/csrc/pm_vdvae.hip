@@ -218,6 +218,112 @@ __global__ __launch_bounds__(256) void diag_sample_kl_bwd_kernel(const float* __
     dprior[r * ldp + Z + j] = g_kl * (1.f / sp - (sq * sq + d * d) * isp2 / sp) * pm_sigmoid(rp);
 }
 
+// ---- a decoder block's three launches between its Blocks, fused (reference vdvae.py:532-563) ---------------------------------
+//   forward :  z = loc_q + scale_q * eps,  kl[b] += KL(q || p),  x2 = x_in + h + z W_z + b_z          (x += h; x += z_proj(z))
+//   backward:  dz = dx2 W_z^T,  d(posterior, prior parameters) of the sample + KL,  d h = dx2 (copied into the prior gradient)
+// were  add_cols + diag_sample_kl_fwd + a 16 -> 192 1x1 convolution  and  that convolution's data gradient +
+// diag_sample_kl_bwd + copy_cols: three launches of 8 - 13 us each on a dependent chain of 20 decoder blocks, for a few
+// hundred FMAs per position.  One wave per position row (SP_RW rows per wave), W_z in LDS, f32 FMAs.
+constexpr int SP_RW = 4;
+__global__ __launch_bounds__(256) void sample_project_fwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
+                                                                  int ldp, const float* __restrict__ eps,
+                                                                  const float* __restrict__ x_in, const float* __restrict__ wz,
+                                                                  const float* __restrict__ bz, float* __restrict__ z,
+                                                                  float* __restrict__ x2, float* __restrict__ kl, long long R,
+                                                                  int Z, int W, int P) {
+    extern __shared__ float sp_lds[];
+    float* Wl = sp_lds;                  // [Z][W]
+    float* bl = Wl + Z * W;              // [W]
+    float* zr = bl + W;                  // [4][Z]
+    __shared__ float wsum[4];
+    for (int e = threadIdx.x; e < Z * W; e += 256) Wl[e] = wz[e];
+    for (int e = threadIdx.x; e < W; e += 256) bl[e] = bz ? bz[e] : 0.f;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long r_first = (long long)blockIdx.x * 4 * SP_RW;
+    long long r_last = r_first + 4 * SP_RW - 1;
+    if (r_last > R - 1) r_last = R - 1;
+    const bool one_example = r_first / P == r_last / P;      // 784 rows adding to ONE address one by one serialise in L2
+    float klacc = 0.f;
+    for (int it = 0; it < SP_RW; ++it) {
+        const long long r = r_first + (long long)wave * SP_RW + it;
+        if (r >= R) break;                                   // wave-uniform
+        float t = 0.f;
+        if (lane < Z) {
+            const float mq = post[r * 2 * Z + lane], sq = pm_softplus(post[r * 2 * Z + Z + lane]) + kDiagShift;
+            const float mp = prior[r * ldp + lane], spv = pm_softplus(prior[r * ldp + Z + lane]) + kDiagShift;
+            const float zj = mq + sq * eps[r * Z + lane];
+            z[r * Z + lane] = zj;
+            zr[wave * Z + lane] = zj;
+            const float d = mq - mp;
+            t = logf(spv) - logf(sq) + (sq * sq + d * d) / (2.f * spv * spv) - 0.5f;
+        }
+        t = pm_wave_sum(t);
+        if (one_example) klacc += t;
+        else if (lane == 0) atomicAdd(kl + r / P, t);
+        for (int w = lane; w < W; w += 64) {
+            float acc = x_in[r * W + w] + prior[r * ldp + 2 * Z + w] + bl[w];
+            for (int j = 0; j < Z; ++j) acc = fmaf(zr[wave * Z + j], Wl[j * W + w], acc);
+            x2[r * W + w] = acc;
+        }
+    }
+    if (one_example) {
+        if (lane == 0) wsum[wave] = klacc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(kl + r_first / P, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_project_bwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
+                                                                  int ldp, const float* __restrict__ eps,
+                                                                  const float* __restrict__ dx2, const float* __restrict__ wz,
+                                                                  float g_kl, float* __restrict__ dpost,
+                                                                  float* __restrict__ dprior, long long R, int Z, int W) {
+    extern __shared__ float sp_lds[];
+    const int WP = W + 1;                // padded pitch: the Z rows of a column fall into different banks
+    float* Wl = sp_lds;                  // [Z][W + 1]
+    float* dr = Wl + Z * WP;             // [4][W]
+    for (int e = threadIdx.x; e < Z * W; e += 256) Wl[(e / W) * WP + e % W] = wz[e];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // lane -> (latent j, one of NCH column ranges): NCH * Z = 64 for Z = 16; other Z: NCH = 1 and lanes >= Z idle in the dot product
+    const int NCH = Z <= 16 ? 64 / 16 : 1;
+    const int Zs = Z <= 16 ? 16 : Z;     // lanes per column range
+    const int j = lane % Zs, ch = lane / Zs;
+    const int wlen = (W + NCH - 1) / NCH;
+    float* drow = dr + wave * W;
+    for (int it = 0; it < SP_RW; ++it) {
+        const long long r = ((long long)blockIdx.x * 4 + wave) * SP_RW + it;
+        if (r >= R) break;                                   // wave-uniform
+        for (int w = lane; w < W; w += 64) {
+            const float v = dx2[r * W + w];
+            drow[w] = v;
+            dprior[r * ldp + 2 * Z + w] = v;                 // d h = d x1 = dx2
+        }
+        float s = 0.f;
+        if (j < Z && ch < NCH) {
+            const int w0 = ch * wlen, w1 = w0 + wlen < W ? w0 + wlen : W;
+            for (int w = w0; w < w1; ++w) s = fmaf(drow[w], Wl[j * WP + w], s);
+        }
+        if (NCH == 4) {                                      // sum over the four column ranges: lanes j, j + 16, j + 32, j + 48
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+        }
+        if (lane < Z) {
+            const float gz = s;
+            const float rq = post[r * 2 * Z + Z + lane], rp = prior[r * ldp + Z + lane];
+            const float mq = post[r * 2 * Z + lane], sq = pm_softplus(rq) + kDiagShift;
+            const float mp = prior[r * ldp + lane], spv = pm_softplus(rp) + kDiagShift;
+            const float d = mq - mp, e = eps[r * Z + lane];
+            const float isp2 = 1.f / (spv * spv);
+            dpost[r * 2 * Z + lane] = gz + g_kl * d * isp2;
+            dpost[r * 2 * Z + Z + lane] = (gz * e + g_kl * (-1.f / sq + sq * isp2)) * pm_sigmoid(rq);
+            dprior[r * ldp + lane] = -g_kl * d * isp2;
+            dprior[r * ldp + Z + lane] = g_kl * (1.f / spv - (sq * sq + d * d) * isp2 / spv) * pm_sigmoid(rp);
+        }
+    }
+}
+
 // TFP fill_triangular index (see pm_heads.hip)
 __device__ __forceinline__ int tril_index(int r, int c, int k) {
     int m = k * (k + 1) / 2;
@@ -687,6 +793,32 @@ extern "C" int pm_diag_sample_kl_bwd(pm_stream_t stream, const float* post, cons
     hipLaunchKernelGGL(diag_sample_kl_bwd_kernel, dim3(blocks_for(rows * Z)), dim3(256), 0, (hipStream_t)stream, post, prior,
                        ldp, eps, dz, g_kl, dpost, dprior, rows, Z);
     return pm_check_launch("pm_diag_sample_kl_bwd");
+}
+
+extern "C" int pm_sample_project_fwd(pm_stream_t stream, const float* post, const float* prior, int ldp, const float* eps,
+                                     const float* x_in, const float* wz, const float* bz, float* z, float* x2, float* kl,
+                                     long long rows, int Z, int W, int P) {
+    if (!post || !prior || !eps || !x_in || !wz || !z || !x2 || !kl || rows <= 0 || Z <= 0 || Z > 64 || W <= 0 || P <= 0 ||
+        ldp < 2 * Z + W)
+        return PM_EINVAL;
+    const size_t lds = ((size_t)Z * W + W + 4 * Z) * sizeof(float);
+    if (lds > 60 * 1024) return PM_EINVAL;
+    hipLaunchKernelGGL(sample_project_fwd_kernel, dim3((unsigned)((rows + 4 * SP_RW - 1) / (4 * SP_RW))), dim3(256), lds,
+                       (hipStream_t)stream, post, prior, ldp, eps, x_in, wz, bz, z, x2, kl, rows, Z, W, P);
+    return pm_check_launch("pm_sample_project_fwd");
+}
+
+extern "C" int pm_sample_project_bwd(pm_stream_t stream, const float* post, const float* prior, int ldp, const float* eps,
+                                     const float* dx2, const float* wz, float g_kl, float* dpost, float* dprior, long long rows,
+                                     int Z, int W) {
+    if (!post || !prior || !eps || !dx2 || !wz || !dpost || !dprior || rows <= 0 || Z <= 0 || Z > 64 || W <= 0 ||
+        ldp < 2 * Z + W)
+        return PM_EINVAL;
+    const size_t lds = ((size_t)Z * (W + 1) + 4 * W) * sizeof(float);
+    if (lds > 60 * 1024) return PM_EINVAL;
+    hipLaunchKernelGGL(sample_project_bwd_kernel, dim3((unsigned)((rows + 4 * SP_RW - 1) / (4 * SP_RW))), dim3(256), lds,
+                       (hipStream_t)stream, post, prior, ldp, eps, dx2, wz, g_kl, dpost, dprior, rows, Z, W);
+    return pm_check_launch("pm_sample_project_bwd");
 }
 
 extern "C" int pm_diag_tril_kl_fwd(pm_stream_t stream, const float* post, const float* masked_params, float* kl,

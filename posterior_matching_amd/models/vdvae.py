@@ -382,10 +382,17 @@ class PosteriorMatchingDecoderBlock(Module):
         if streams is not None:
             ops.wait_stream(main, s1)
             ops.wait_stream(main, s2)
-        x1 = self.buf("x1", sh(W))
-        ops.add_cols(x_in, self._pr, 2 * Z, x1)              # x += h (:558)
         self._z = self.buf("z", sh(Z))
-        ops.diag_sample_kl_fwd(self._pp, self._pr, eps, self._z, kl, P)
+        # one launch for the three steps - measured no faster than the three (891 vs 897 img/s at per-GPU 8): off unless asked for
+        fuse_sp = bool(os.environ.get("PM_VDVAE_SAMPLE_PROJECT"))
+        x2 = self.buf("x2", sh(W))
+        if fuse_sp:     # x += h (:558), sample + KL (:559-561), x += z_proj(z) (:562): one launch
+            ops.sample_project_fwd(self._pp, self._pr, eps, x_in, self.store.p[self.z_proj.w].view(Z, W),
+                                   self.store.p[self.z_proj.b], self._z, x2, kl, P)
+        else:
+            x1 = self.buf("x1", sh(W))
+            ops.add_cols(x_in, self._pr, 2 * Z, x1)              # x += h (:558)
+            ops.diag_sample_kl_fwd(self._pp, self._pr, eps, self._z, kl, P)
         ks = self.kl_stream          # pm_kl only feeds the loss: off the chain, beside z_proj and the resnet Block
         if ks is not None:
             ops.wait_stream(ks, main)
@@ -393,9 +400,9 @@ class PosteriorMatchingDecoderBlock(Module):
                 ops.diag_tril_kl_fwd(self._pp, self._mp, pm_kl, Z, P)
         else:
             ops.diag_tril_kl_fwd(self._pp, self._mp, pm_kl, Z, P)
-        x2 = self.buf("x2", sh(W))
-        ops.layer_forward(self.z_proj.g, self._z, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
-                          wsplit=self.store.split_view(self.z_proj.ws_f))
+        if not fuse_sp:
+            ops.layer_forward(self.z_proj.g, self._z, self.store.p[self.z_proj.w], self.store.p[self.z_proj.b], x2, res=x1,
+                              wsplit=self.store.split_view(self.z_proj.ws_f))
         self._x2 = x2
         return self.resnet.forward_raw(x2, None, res=x2)
 
@@ -526,11 +533,15 @@ class PosteriorMatchingDecoderBlock(Module):
         dx2 = self.buf("dx2", sh(W))
         self.resnet.backward(dx3, dx2, x_pre=self._x2, res=dx3)                 # dx2 = dx1
         self.wgrad(self.z_proj.g, self._z, dx2, self.store.g[self.z_proj.w], self.store.g[self.z_proj.b])
-        dz = self.buf("dz", sh(Z))
-        ops.layer_dgrad(self.z_proj.g, dx2, self.store.p[self.z_proj.w], dz, wsplit=self.store.split_view(self.z_proj.ws_d))
         dpp, dpr = self.buf("dpp", sh(2 * Z)), self.buf("dpr", sh(2 * Z + W))
-        ops.diag_sample_kl_bwd(self._pp, self._pr, self._eps, dz, g_kl, dpp, dpr)
-        ops.copy_cols(dx2, dpr, 2 * Z)                                            # d h = d x1
+        if os.environ.get("PM_VDVAE_SAMPLE_PROJECT"):
+            # dz = z_proj^T(dx2), the sample / KL gradients, d h = d x1 = dx2: one launch
+            ops.sample_project_bwd(self._pp, self._pr, self._eps, dx2, self.store.p[self.z_proj.w].view(Z, W), g_kl, dpp, dpr)
+        else:
+            dz = self.buf("dz", sh(Z))
+            ops.layer_dgrad(self.z_proj.g, dx2, self.store.p[self.z_proj.w], dz, wsplit=self.store.split_view(self.z_proj.ws_d))
+            ops.diag_sample_kl_bwd(self._pp, self._pr, self._eps, dz, g_kl, dpp, dpr)
+            ops.copy_cols(dx2, dpr, 2 * Z)                                            # d h = d x1
         dmp = self.buf("dmp", tuple(self._mp.shape))
         if self._mp_bwd_done:
             pass                     # dmp and everything behind it were handled on the side stream

@@ -1083,6 +1083,19 @@ def diag_sample_kl_bwd(post, prior, eps, dz, g_kl: float, dpost, dprior) -> None
           _ptr(dprior), eps.numel() // Z, Z)
 
 
+def sample_project_fwd(post, prior, eps, x_in, wz, bz, z, x2, kl, P: int) -> None:
+    """x += h; z sampled + kl; x += z_proj(z) in one launch (csrc/pm_vdvae.hip, reference vdvae.py:558-562)"""
+    Z, W = eps.shape[-1], x_in.shape[-1]
+    _call("pm_sample_project_fwd", _ptr(post), _ptr(prior), prior.shape[-1], _ptr(eps), _ptr(x_in), _ptr(wz), _ptr(bz), _ptr(z),
+          _ptr(x2), _ptr(kl), eps.numel() // Z, Z, W, P)
+
+
+def sample_project_bwd(post, prior, eps, dx2, wz, g_kl: float, dpost, dprior) -> None:
+    Z, W = eps.shape[-1], dx2.shape[-1]
+    _call("pm_sample_project_bwd", _ptr(post), _ptr(prior), prior.shape[-1], _ptr(eps), _ptr(dx2), _ptr(wz), g_kl, _ptr(dpost),
+          _ptr(dprior), eps.numel() // Z, Z, W)
+
+
 def diag_tril_kl_fwd(post, mp, kl, Z: int, P: int) -> None:
     _call("pm_diag_tril_kl_fwd", _ptr(post), _ptr(mp), _ptr(kl), post.numel() // (2 * Z), Z, P)
 
