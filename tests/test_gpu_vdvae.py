@@ -381,6 +381,26 @@ def test_vdvae_forward_and_grads(bf16x3):
     assert worst[0] < (1e-4 if not bf16x3 else 1e-2), worst
 
 
+def test_vdvae_fused_sample_projection_path(monkeypatch):
+    """PM_VDVAE_SAMPLE_PROJECT=1: `x += h`, sample + KL and `x += z_proj(z)` as one launch, and their gradients as one
+    launch (pm_sample_project_fwd / _bwd, reference vdvae.py:558-562), against the float64 oracle like the default path"""
+    monkeypatch.setenv("PM_VDVAE_SAMPLE_PROJECT", "1")
+    B = 5
+    m, p64, x, b, eps = _setup(TINY, B, bf16x3=False)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, aux, out = DO.vdvae_loss(leaves, TINY, x, b, eps)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    got = m(f32d(x), f32d(b), [f32d(e) for e in eps])
+    m.zero_grad()
+    m.backward()
+    torch.cuda.synchronize()
+    for k in ("reconstruction_ll", "kl", "pm_kl"):
+        assert rel_err(got[k], out[k]) < 2e-5, k
+    gd = m.grads_dict()
+    worst = max((rel_err(gd[n], grads[n]), n) for n in grads)
+    assert worst[0] < 1e-4, worst
+
+
 def test_vdvae_train_steps_match_oracle():
     from posterior_matching_amd.engine import VDVAETrainStep
 
