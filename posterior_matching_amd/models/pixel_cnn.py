@@ -397,11 +397,8 @@ class PixelCNN(Module):
 
         fs = None
         for blk in reversed(self.blocks):
-            n = blk.name
-            input_x, extra_a, extra_b = self._io[blk.group]
-            out = self.buf(f"{n}/out", sh(F))
             vertical = blk.stack == "vertical"
-            if two and fs is None and n.startswith("down") and os.environ.get("PM_PIXELCNN_MID_FLUSH"):
+            if two and fs is None and blk.name.startswith("down") and os.environ.get("PM_PIXELCNN_MID_FLUSH"):
                 # (measured neutral: celeb_a 1638 -> 1622 img/s, mnist 20.3k -> 20.5k; off unless asked for)
                 # every up-pass block has left its operands in HBM: their grouped weight gradients (throughput-bound) start
                 # now on a third stream, beside the two latency-bound chains of the down pass
