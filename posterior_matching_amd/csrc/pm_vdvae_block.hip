@@ -14,6 +14,7 @@
 // read as MFMA B fragments straight from L2, two k-steps ahead.
 // The pre-activations h1..h3 and their gelus g1..g3 (inputs of the weight gradients) are stored exactly as the unfused
 // path stores them, so the weight-gradient launches and every parity test are unchanged.
+#include <cstdlib>
 #include "pm_common.h"
 
 namespace {
@@ -712,15 +713,22 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(MultiArgs multi) 
 
 // band plan: rows per band and images per workgroup so that no stage owns more than MAXM positions and the LDS fits
 struct BandPlan { int R, NI, bands; size_t lds; };
-bool plan_block(int B, int H, int W, int k3, BandPlan& bp) {
+bool plan_block(int B, int H, int W, int k3, int nblk, BandPlan& bp) {
     const int halo = k3 / 2;
     if (W > 62 || H < 1) return false;
     int R = H, NI = 1;
     while (R > 1 && (R + 4 * halo) * W > MAXM) R = (R + 1) / 2;
     if ((R + 4 * halo) * W > MAXM) return false;
-    // the chain inside a workgroup is serial: prefer many small bands (>= 64 workgroups) while a band keeps >= 3 rows, and
-    // pack whole small images (resolution <= 3) several per workgroup only when the grid stays >= 128 workgroups
-    while (halo > 0 && R > 4 && (long long)B * ((H + R - 1) / R) < 64) R = (R + 1) / 2;
+    // The chain inside a workgroup is serial and a launch is one link of a dependent chain: while the whole launch (all its
+    // Blocks) still fits one round of one workgroup per CU, halve the bands - a workgroup then walks fewer rows (28x28 at
+    // per-GPU 8: 4-row bands = 56 workgroups per Block, 2-row bands = 112; the halo rows it recomputes run on CUs that were
+    // idle).  Whole small images (resolution <= 3) are packed several per workgroup only when the grid stays >= 128 workgroups.
+    static const int round_wgs = getenv("PM_VB_ROUND") ? atoi(getenv("PM_VB_ROUND")) : 256;      // A/B knob
+    while (halo > 0 && R > 2) {
+        const int R2 = (R + 1) / 2;
+        if ((long long)B * ((H + R2 - 1) / R2) * nblk > round_wgs) break;
+        R = R2;
+    }
     if (R == H)
         while (NI < B && (NI + 1) * (H + 4 * halo) * W <= MAXM && (B + NI) / (NI + 1) >= 128) ++NI;
     bp.R = R; bp.NI = NI; bp.bands = (H + R - 1) / R;
@@ -732,7 +740,7 @@ bool plan_block(int B, int H, int W, int k3, BandPlan& bp) {
 int launch_blocks(hipStream_t stream, bool backward, MultiArgs& m, int n) {
     BandPlan bp;
     const BlockArgs& a0 = m.b[0];
-    if (n < 1 || n > MAXBLK || !plan_block(a0.B, a0.H, a0.W, a0.k3, bp)) return PM_EINVAL;
+    if (n < 1 || n > MAXBLK || !plan_block(a0.B, a0.H, a0.W, a0.k3, n, bp)) return PM_EINVAL;
     for (int i = 0; i < n; ++i) {
         if (m.b[i].B != a0.B || m.b[i].H != a0.H || m.b[i].W != a0.W || m.b[i].mid != a0.mid || m.b[i].k3 != a0.k3) return PM_EINVAL;
         m.b[i].R = bp.R; m.b[i].NI = bp.NI; m.b[i].bands = bp.bands;
