@@ -33,3 +33,12 @@ for t, d in ev:
     last = t
 for c in sorted(hist):
     print(f"{c} kernels in flight: {hist[c] / steps:8.1f} us/step")
+# timeline of the last step: start offset, duration, queue, kernel
+if len(sys.argv) > 3:
+    last_lo = adam[-2]
+    step = ks[last_lo + 1:hi + 1]
+    s0 = step[0][0]
+    qid = {q: i for i, q in enumerate(sorted({k[2] for k in step}))}
+    with open(sys.argv[3], "w") as f:
+        for s, e, q, n in step:
+            f.write(f"{(s - s0) / 1e3:9.1f} {(e - s) / 1e3:7.1f}  q{qid[q]}  {n[:90]}\n")
