@@ -1114,6 +1114,111 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
     }
 }
 
+// ----------------------- whole-image layers with ONE output position and few rows (bf16x3) -----------------------
+// The 7x7 layers at either end of the PM-VAE's convolution stacks (7x7x64 -> 1x1x128 forward, 7x7x64 -> 1x1x32 as a data
+// gradient; reference networks.py conv stacks at configs/pm_vae_mnist.py sizes) are GEMMs of 256 rows with K = 3136: the
+// direct form has 4 tiles, so it ran split 24 ways over K with a zero-fill in front and an epilogue launch behind (three
+// dependent launches, 24 us of a dependent chain).  Here one launch does it: a workgroup owns a 16 x 16 output tile
+// (16 x 8 = 128 workgroups for 256 x 128), its 8 waves take the k-steps (32 channels of one tap) round-robin - 12 or 13
+// each, all of them in flight at once (13 register sets: 233 VGPRs, two waves per SIMD), A rows and pre-split weights straight from L2 into MFMA fragments - and the 8
+// partial tiles meet in 8 KB of LDS; the shared epilogue (bias, act'(aux), residual, activation, second store) follows.
+constexpr int SK_NW = 8;      // waves per workgroup = interleaved K slices
+#ifndef PM_SK_PD
+#define PM_SK_PD 13
+#endif
+constexpr int SK_PD = PM_SK_PD;   // k-steps in flight per wave (16 registers each)
+template <class F, int... U>
+__device__ __forceinline__ void sk_for(F&& f, std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }
+
+__global__ __launch_bounds__(64 * SK_NW) void skinny_gemm_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit,
+                                                                      int npad, long long plane) {
+    __shared__ float red[SK_NW][4][64];
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, kg = lane >> 4;        // A: row r, B: column r; both: k = 8 kg .. 8 kg + 7 of the 32-deep step
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+    const int cchunks = (g.C + BK - 1) / BK;       // C % 32 != 0: the last chunk of a tap is part zero-padded weights
+    const int nsteps = g.KH * g.KW * cchunks;
+    const int mrow = m0 + r < g.M ? m0 + r : g.M - 1;
+    const int ncol = n0 + r < npad ? n0 + r : npad - 1;
+    const float* arow = p.in + (size_t)mrow * g.IH * g.IW * g.C + 8 * kg;
+    const __bf16* bcol = wsplit + (size_t)ncol * BK + 8 * kg;
+
+    f32x4 a0[SK_PD], a1[SK_PD];
+    bf16x8 bh[SK_PD], bl[SK_PD];
+    auto issue = [&](int s, auto set_tag) {          // this wave's s-th step = global step wave + SK_NW * s (clamped)
+        constexpr int U = decltype(set_tag)::value;
+        int st = wave + SK_NW * s;
+        st = st < nsteps ? st : nsteps - 1;
+        const int tap = st / cchunks, cc = st - tap * cchunks;
+        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+        const int pix = (g.off + ky * g.cs) * g.IW + g.offx + kx * g.cs;
+        const bool kok = cc * BK + 8 * kg < g.C;       // C % 8 == 0: a lane's 8 channels are all inside the row or all outside
+        const float* ap = arow + (size_t)pix * g.C + (kok ? cc * BK : 0);
+        a0[U] = *reinterpret_cast<const f32x4*>(ap);
+        a1[U] = *reinterpret_cast<const f32x4*>(ap + 4);
+        if (!kok) a0[U] = a1[U] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const __bf16* bp = bcol + (size_t)st * npad * BK;
+        bh[U] = *reinterpret_cast<const bf16x8*>(bp);
+        bl[U] = *reinterpret_cast<const bf16x8*>(bp + plane);
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](auto set_tag, bool valid) {
+        constexpr int U = decltype(set_tag)::value;
+        bf16x8 ah, al;
+        split8(a0[U], a1[U], ah, al);
+        if (!valid) {                                 // a clamped step past this wave's share: zero operand, finite weights
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            ah = __builtin_bit_cast(bf16x8, z);
+            al = ah;
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[U], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[U], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[U], acc, 0, 0, 0);
+    };
+    const int my = wave < nsteps ? (nsteps - wave + SK_NW - 1) / SK_NW : 0;       // steps of this wave
+    constexpr auto sets = std::make_integer_sequence<int, SK_PD>{};
+    sk_for([&](auto u) { issue(decltype(u)::value, u); }, sets);
+    int s0 = 0;
+    for (; s0 + SK_PD < my; s0 += SK_PD)              // full groups: every step is this wave's, the next group's loads follow
+        sk_for([&](auto u) {
+            mma(u, true);
+            issue(s0 + SK_PD + decltype(u)::value, u);
+            __builtin_amdgcn_sched_barrier(0);        // or the scheduler sinks every load of the group behind its last MFMA
+        }, sets);
+    sk_for([&](auto u) { mma(u, s0 + decltype(u)::value < my); }, sets);
+
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][e][lane] = acc[e];
+    __syncthreads();
+    if (tid < 256) {                                  // C/D layout: column = lane & 15, row = 4 (lane >> 4) + e
+        const int e = tid >> 6;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_NW; ++w) v += red[w][e][lane];
+        const int row = m0 + 4 * (lane >> 4) + e, n = n0 + (lane & 15);
+        if (row < g.M && n < g.N) {
+            const size_t o = (size_t)row * g.N + n;
+            if (p.bias) v += p.bias[n];
+            v = pm_epilogue(v, p.aux, p.res, o, g.aux_act, g.out_act, g.slope);
+            p.out[o] = v;
+            if (p.out2) p.out2[o] = pm_act(v, p.act2, g.slope);
+        }
+    }
+}
+
+// one output position per image, every tap inside the image, few rows, long K
+bool plan_skinny(const Geom& g, int groups) {
+    static const bool off = getenv("PM_NO_SKINNY") != nullptr;         // A/B switch for measurements
+    if (off || groups != 1 || g.d != 1 || g.OH != 1 || g.OW != 1 || g.C % 8 != 0 || g.in_act != PM_ACT_NONE) return false;
+    if (g.M > 512 || g.KH * g.KW * g.C < 512) return false;
+    const int y0 = g.off, y1 = g.off + (g.KH - 1) * g.cs, x0 = g.offx, x1 = g.offx + (g.KW - 1) * g.cs;
+    if (y0 < 0 || y1 < 0 || y0 >= g.IH || y1 >= g.IH || x0 < 0 || x1 < 0 || x0 >= g.IW || x1 >= g.IW) return false;
+    return true;
+}
+
 // ----------------------- stride-1 convolutions, patch-staged form (bf16x3) -----------------------
 // The direct form above re-reads every input element once per tap from L2 (25x for a 5x5 kernel: the
 // measured limiter, FETCH_SIZE 1.6x the algorithmic bytes and 40 % of the kernel time in the gather).
@@ -3420,6 +3525,13 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
         if (rn == 2 && wgs64 < rn2_min) rn = 1;
     }
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
+    if (plan_skinny(a.g, G)) {                         // one output position, few rows, long K: one launch, K over the waves
+        a.ksplit = 1;
+        PM_KTAG("skinny_gemm_bf16_kernel");
+        hipLaunchKernelGGL(skinny_gemm_bf16_kernel, dim3((a.g.M + 15) / 16, (a.g.N + 15) / 16), dim3(64 * SK_NW), 0, s, a, ws,
+                           npad, plane);
+        return pm_check_launch("pm_gather_gemm_bf16(skinny)");
+    }
     ImagePlan ip;
     static const bool image_off = getenv("PM_NO_IMAGE_CONV") != nullptr;   // A/B switch for measurements
     if (!image_off && plan_image(a.g, G, ip)) {       // whole input image of a workgroup resident in LDS

@@ -65,6 +65,10 @@ CONV_CASES = [
     ("conv", 128, 13, 32, 32, 5, 1, "SAME"), ("conv", 128, 14, 32, 64, 5, 2, "SAME"), ("conv", 128, 12, 64, 128, 3, 1, "SAME"),
     ("convT", 128, 9, 32, 32, 5, 1, "SAME"), ("convT", 128, 7, 64, 64, 5, 2, "SAME"), ("convT", 128, 6, 32, 32, 4, 2, "SAME"),
     ("conv", 128, 12, 32, 32, 5, 2, "SAME"), ("convT", 128, 14, 32, 32, 5, 2, "SAME"),
+    # whole-image layers with one output position (skinny_gemm_bf16: K = 3136 over the waves of a workgroup), forward and as a
+    # data gradient with flipped taps, ragged row / column tiles
+    ("conv", 256, 7, 64, 128, 7, 1, "VALID"), ("convT", 130, 1, 32, 64, 7, 1, "VALID"), ("conv", 21, 6, 32, 40, 6, 1, "VALID"),
+    ("dense", 256, 1, 560, 128, 1, 1, "VALID"), ("dense", 100, 1, 128, 560, 1, 1, "VALID"),   # C % 32 != 0: part-padded last chunk
 ]
 
 
