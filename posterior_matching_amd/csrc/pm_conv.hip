@@ -2720,6 +2720,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const short* base0, int row_stride_ele
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// the same fragment from two per-lane addresses: rows +0..3 at base0, rows +4..7 at base1 (positions that do not sit a
+// fixed pitch apart: consecutive output positions of a linearised grid)
+__device__ __forceinline__ bf16x8 tr_frag2(const short* base0, const short* base1) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base1));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int RC, int RN, int DD>
 __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
     constexpr int CB = 32 * RC;
@@ -3260,6 +3270,210 @@ __global__ __launch_bounds__(256) void patch_wgrad_bf16_kernel(WgradArgs p, int 
     }
 }
 
+// ----------------------- weight gradients with BOTH images of a sample resident in LDS (bf16x3) -----------------------
+// Stride-2 layers had no patch-staged weight gradient (gather_wgrad_bf16_kernel re-gathers its rows and re-reads the dense
+// operand once per tap: 25 x through L2, 46 TFLOP/s on the 28x28 -> 14x14 layers), and the patch-staged form walks 14x14
+// grids as two 8 x 16 tiles per image (77 % of the positions real).  Here a persistent workgroup takes whole samples: the
+// gathered image ([IH][IW][32] f32 -> hi / lo bf16 planes, one extra all-zero pixel for the taps that fall outside) and
+// the dense image ([OH*OW][N] -> hi / lo, plus one all-zero row) are staged once, every k16 step is one output row
+// (9 <= OW <= 16: 14 of 16 positions real on 14x14), and a tap's A operand is a transposed LDS read at per-lane pixel
+// addresses (any stride a).  Taps are owned by the 4 waves as in patch_wgrad_bf16_kernel; accumulators
+// stay in registers over all samples of the workgroup; one atomic flush at the end.  Needs d = 1 and C == 32.
+template <int RN, int NPI, int NPD, int TPW>      // NPI / NPD: 16-byte pieces per thread of the gathered / dense image
+__global__ __launch_bounds__(256) void image_wgrad_bf16_kernel(WgradArgs p, int nsub) {
+    constexpr int NB = 32 * RN;
+    constexpr int DS = NB + 8;
+    constexpr int PS = 40;                         // 32 channels + 16 B pad
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int npix = g.IH * g.IW, npos = g.OH * g.OW;
+    short* Ph = reinterpret_cast<short*>(dsm);
+    short* Pl = Ph + (npix + 1) * PS;
+    short* Dh = Pl + (npix + 1) * PS;
+    short* Dl = Dh + (npos + 1) * DS;
+    const int ntaps = g.KH * g.KW;
+
+    // the taps are dealt to nsub workgroup classes (sub = blockIdx.x % nsub), inside a class to its 4 waves: TPW each
+    const int sub = blockIdx.x % nsub, b_first = blockIdx.x / nsub, b_step = gridDim.x / nsub;
+    int tdy[TPW], tdx[TPW];                        // pixel offsets of this wave's taps
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tap = sub + nsub * (wave + 4 * j);
+        const int tt = tap < ntaps ? tap : 0;
+        const int ky = tt / g.KW, kx = tt - ky * g.KW;
+        tdy[j] = ky * g.cs;
+        tdx[j] = kx * g.cs;
+    }
+    const int gq = lane >> 4;                      // transposed-read lane geometry (see gather_wgrad_bf16_kernel)
+    const int q = (lane & 15) >> 2;
+    const int pq = lane & 3;
+    const int tr_row = 8 * (gq >> 1) + q;
+    const int tr_col = 16 * (gq & 1) + 4 * pq;
+
+    f32x16 acc[TPW][RN];
+    f32x16 accb[RN];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][b][e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < RN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[b][e] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const bool do_bias = p.db != nullptr && wave == 0 && sub == 0;
+
+    // the zero pixel and the zero dense row are written once: staging never touches them
+    if (tid < PS / 2) {
+        reinterpret_cast<unsigned*>(Ph + npix * PS)[tid] = 0u;
+        reinterpret_cast<unsigned*>(Pl + npix * PS)[tid] = 0u;
+    }
+    if (tid < DS / 2) {
+        reinterpret_cast<unsigned*>(Dh + npos * DS)[tid] = 0u;
+        reinterpret_cast<unsigned*>(Dl + npos * DS)[tid] = 0u;
+    }
+
+    // A k16 step is ONE output row (9 <= OW <= 16): whether a tap's source row exists is then the same for the whole wave, and
+    // whether its source column exists depends on the lane and the tap only - both leave the loop.  Per lane and tap: the column
+    // part of the two pixel addresses (positions tr_row and tr_row + 4 of the row) and their validity; per step and tap what is
+    // left is one scalar row base, an add and a select per address.
+    const int oxa = tr_row, oxb = tr_row + 4;
+    int xoa[TPW], xob[TPW];
+    bool oka[TPW], okb[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int xa = oxa * g.a + g.offx + tdx[j], xb = oxb * g.a + g.offx + tdx[j];
+        oka[j] = oxa < g.OW && (unsigned)xa < (unsigned)g.IW;
+        okb[j] = oxb < g.OW && (unsigned)xb < (unsigned)g.IW;
+        xoa[j] = xa * PS + tr_col;
+        xob[j] = xb * PS + tr_col;
+    }
+    const int zpix = npix * PS + tr_col;
+    const bool okda = oxa < g.OW, okdb = oxb < g.OW;
+    const int dxa = oxa * DS + tr_col, dxb = oxb * DS + tr_col, zrow = npos * DS + tr_col;
+
+    const int np4 = npix * 8;                      // 16-byte pieces of the gathered image (C = 32)
+    const int nd4 = npos * (NB / 4);               // ... of the dense image (columns >= N are zero)
+    f32x4 pv[NPI], dv[NPD];
+    auto issue = [&](int b) {                      // global loads of one sample into registers
+        const float* img = p.gathered + (size_t)b * npix * g.C;
+        const float* dimg = p.dense + (size_t)b * npos * g.N;
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) {
+            const int e = tid + 256 * j;
+            pv[j] = *reinterpret_cast<const f32x4*>(img + 4 * (size_t)(e < np4 ? e : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NPD; ++j) {
+            const int e = tid + 256 * j;
+            const int ee = e < nd4 ? e : 0;
+            const int pos = ee / (NB / 4), n4 = ee - pos * (NB / 4);
+            const bool ok = 4 * n4 < g.N;
+            dv[j] = *reinterpret_cast<const f32x4*>(dimg + (ok ? (size_t)pos * g.N + 4 * n4 : 0));
+            if (!ok) dv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&]() {                           // registers -> hi / lo bf16 planes in LDS
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) {
+            const int e = tid + 256 * j;
+            if (e < np4) {
+                u32x2 h2, l2;
+                split4(pv[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + (e >> 3) * PS + 4 * (e & 7)) = h2;
+                *reinterpret_cast<u32x2*>(Pl + (e >> 3) * PS + 4 * (e & 7)) = l2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPD; ++j) {
+            const int e = tid + 256 * j;
+            if (e < nd4) {
+                const int pos = e / (NB / 4), n4 = e - pos * (NB / 4);
+                u32x2 h2, l2;
+                split4(dv[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Dh + pos * DS + 4 * n4) = h2;
+                *reinterpret_cast<u32x2*>(Dl + pos * DS + 4 * n4) = l2;
+            }
+        }
+    };
+    issue(b_first);
+    for (int b = b_first; b < g.B; b += b_step) {
+        stage();
+        __syncthreads();
+        // the next sample's loads fly during the MFMAs (the last round re-reads its own sample: no loads under a branch)
+        issue(b + b_step < g.B ? b + b_step : b);
+        for (int oy = 0; oy < g.OH; ++oy) {
+            const int drow = oy * g.OW * DS;
+            const int da = okda ? drow + dxa : zrow, db2 = okdb ? drow + dxb : zrow;
+            bf16x8 bh[RN], bl[RN];
+#pragma unroll
+            for (int b2 = 0; b2 < RN; ++b2) {
+                bh[b2] = tr_frag2(Dh + da + 32 * b2, Dh + db2 + 32 * b2);
+                bl[b2] = tr_frag2(Dl + da + 32 * b2, Dl + db2 + 32 * b2);
+            }
+            const int ybase = oy * g.a + g.off;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int y = ybase + tdy[j];                       // wave-uniform
+                const bool oky = (unsigned)y < (unsigned)g.IH;
+                const int rbase = y * g.IW * PS;
+                const int o0 = (oky && oka[j]) ? rbase + xoa[j] : zpix;
+                const int o1 = (oky && okb[j]) ? rbase + xob[j] : zpix;
+                const bf16x8 ah = tr_frag2(Ph + o0, Ph + o1);
+                const bf16x8 al = tr_frag2(Pl + o0, Pl + o1);
+#pragma unroll
+                for (int b2 = 0; b2 < RN; ++b2) {
+                    acc[j][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[b2], acc[j][b2], 0, 0, 0);
+                    acc[j][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[b2], acc[j][b2], 0, 0, 0);
+                    acc[j][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[b2], acc[j][b2], 0, 0, 0);
+                }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int b2 = 0; b2 < RN; ++b2) {
+                    accb[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bh[b2], accb[b2], 0, 0, 0);
+                    accb[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bl[b2], accb[b2], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // flush: C/D layout row (= channel) = (e&3) + 8*(e>>2) + 4*h, column (= n) = lane & 31
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tap = sub + nsub * (wave + 4 * j);
+        if (tap >= ntaps) continue;
+        const int wtap = (tap / g.KW) * g.kws + tap % g.KW;
+#pragma unroll
+        for (int b2 = 0; b2 < RN; ++b2) {
+            const int n = 32 * b2 + i;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
+                atomicAdd(p.dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[j][b2][e]);
+            }
+        }
+    }
+    if (do_bias && h == 0) {
+#pragma unroll
+        for (int b2 = 0; b2 < RN; ++b2) {
+            const int n = 32 * b2 + i;
+            if (n < g.N) atomicAdd(p.db + n, accb[b2][0]);
+        }
+    }
+}
+
 bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     if (!d || d->B <= 0 || d->C <= 0 || d->N <= 0 || d->KH <= 0 || d->KW <= 0 || d->d <= 0 || d->groups <= 0)
         return false;
@@ -3651,6 +3865,51 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
     if (gtab ? !tab_aligned : (d->in_gs % 4 != 0 || d->out_gs % 4 != 0)) return PM_EINVAL;
     a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db; a.gtab = gtab;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    {   // 32 gathered channels, both images of a sample fit LDS: image-resident persistent form (any stride)
+        static const bool image_off = getenv("PM_NO_IMAGE_WGRAD") != nullptr;      // A/B switch for measurements
+        const Geom& g = a.g;
+        const int rn = g.N > 32 ? 2 : 1;
+        const size_t lds = ((size_t)(g.IH * g.IW + 1) * 40 + (size_t)(g.OH * g.OW + 1) * (32 * rn + 8)) * 2 * 2;
+        if (!image_off && !gtab && d->groups == 1 && g.d == 1 && g.C == 32 && g.in_act == PM_ACT_NONE && g.N <= 64 &&
+            g.N % 4 == 0 && g.KH * g.KW <= 28 && g.KH * g.KW >= 9 && g.B >= 64 && g.OW >= 9 && g.OW <= 16 && g.OH >= 4 &&
+            lds <= 158 * 1024 && g.IH * g.IW <= (rn == 2 ? 224 : 800) && g.OH * g.OW <= (rn == 2 ? 208 : 224)) {
+            // Register-staged pieces per thread: 25 (64 columns: 7) / 13 (7).  The atomic flush moves G x (taps x 32 x N) / nsub
+            // floats at about 1.2 TB/s chip-wide, so the taps are dealt to nsub = 2 classes of workgroups (each sample is then
+            // staged by both).  Measured at B = 256 (14x14 32->64 / 28->14 stride 2 32->32, us): nsub 1 on 128 workgroups
+            // 64 / 44, nsub 2 on 192: 54 / 44, on 256: 56 / 41, nsub 4 on 256: 53 / 43; the PM-VAE step is fastest with
+            // 2 on 192 (PM_IW_GRID / PM_IW_SPLIT for experiments).
+            static const int grid_env = getenv("PM_IW_GRID") ? atoi(getenv("PM_IW_GRID")) : 0;
+            static const int sub_env = getenv("PM_IW_SPLIT") ? atoi(getenv("PM_IW_SPLIT")) : 0;
+            const int nsub = sub_env == 1 || sub_env == 2 ? sub_env : 2;
+            int grid = grid_env > 0 ? grid_env : (nsub == 1 ? 128 : 192);
+            if (grid > g.B * nsub) grid = g.B * nsub;
+            grid -= grid % nsub;
+            const int npi = (g.IH * g.IW * 8 + 255) / 256;
+            hipStream_t s = (hipStream_t)stream;
+#define PM_IW(RNv, NPIv, NPDv, TPWv)                                                                                  \
+    do {                                                                                                             \
+        static bool attr = false;                                                                                    \
+        if (!attr) {                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&image_wgrad_bf16_kernel<RNv, NPIv, NPDv, TPWv>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);                       \
+            attr = true;                                                                                             \
+        }                                                                                                            \
+        PM_KTAG("image_wgrad_bf16_kernel<%d, %d, %d, %d>", RNv, NPIv, NPDv, TPWv);                                   \
+        hipLaunchKernelGGL((image_wgrad_bf16_kernel<RNv, NPIv, NPDv, TPWv>), dim3(grid), dim3(256), lds, s, a, nsub); \
+    } while (0)
+#define PM_IW3(TPWv)                                                                                                  \
+    do {                                                                                                             \
+        if (rn == 1 && npi <= 7) PM_IW(1, 7, 7, TPWv);                                                               \
+        else if (rn == 1) PM_IW(1, 25, 7, TPWv);                                                                     \
+        else PM_IW(2, 7, 13, TPWv);                                                                                  \
+    } while (0)
+            if (nsub == 1) PM_IW3(7);
+            else PM_IW3(4);
+#undef PM_IW3
+#undef PM_IW
+            return pm_check_launch("pm_gather_wgrad_bf16(image)");
+        }
+    }
     {   // stride-1 problems with 32 gathered channels on grids >= 12 wide: patch-staged persistent form
         static const bool patch_off = getenv("PM_NO_PATCH_WGRAD") != nullptr;
         const Geom& g = a.g;
