@@ -3605,7 +3605,8 @@ WgradPlan plan_wgrad(const Geom& g, int groups, bool vec4, bool dvec4) {
     // m-splits: enough workgroups to fill the chip (~4 per CU), but every workgroup should walk
     // several 128-row chunks - its LDS reduction and atomics are a fixed cost per workgroup
     long long blocks = (long long)p.nkb * p.nnb * groups;
-    int splits = (int)((1024 + blocks - 1) / blocks);
+    static const int wg_target = getenv("PM_WG_TARGET") ? atoi(getenv("PM_WG_TARGET")) : 1024;     // A/B knob
+    int splits = (int)((wg_target + blocks - 1) / blocks);
     int max_splits = total_chunks / 4;      // measured flat optimum: 2..8 chunks per workgroup within 1 % (PM-VAE, PM-VQVAE)
     if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = max_splits;
