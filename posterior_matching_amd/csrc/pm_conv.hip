@@ -1875,7 +1875,10 @@ struct ImagePlan { int nw, t, nct; size_t lds; };
 bool plan_image(const Geom& g, int groups, ImagePlan& ip) {
     if (groups != 1 || g.d != 1 || g.C % BK != 0 || g.B < 128) return false;
     if (g.in_act != PM_ACT_NONE && g.in_act != PM_ACT_RELU && g.in_act != PM_ACT_LEAKY) return false;
-    if (g.KH * g.KW < 4 || g.kws != g.KW) return false;                 // 1x1: the dense form; masked sub-kernels: direct form
+    // 1x1: the dense form.  Masked sub-kernels (kws > KW: the PixelCNN's horizontal stack, 2 x 2 of a 3 x 3 kernel) qualify like
+    // any other kernel - the pre-split weight copy is compact in the walked taps (PM_NO_IMAGE_MASKED=1: back on the direct form)
+    static const bool masked_off = getenv("PM_NO_IMAGE_MASKED") != nullptr;
+    if (g.KH * g.KW < 4 || (masked_off && g.kws != g.KW)) return false;
     // every tap is walked for every position: grids smaller than the kernel (the 7x7 <-> 1x1 layers: 1 valid tap of 49)
     // stay on the direct form and its tap lists
     if (g.IH < g.KH || g.IW < g.KW || g.OH * g.OW < 32) return false;
