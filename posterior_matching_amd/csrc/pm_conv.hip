@@ -3587,7 +3587,9 @@ GemmPlan plan_gemm(const Geom& g, int groups, bool vec4) {
     // split K over workgroups only when the tile grid is far from filling the chip AND K is long: a split costs a
     // zero-fill and an epilogue launch plus f32 atomics (measured on the PM-VAE step: splitting the 14x14 / 7x7
     // layers 3-8 ways to reach 1024+ workgroups LOSES 8-11 % end to end)
-    if (groups == 1 && tiles < 128 && chunks >= 32) {
+    // (tiles < 64: the CelebA PixelCNN's 64-tile 256 -> 128 layers at per-GPU 16 run 2 % faster unsplit; 128 measured neutral elsewhere)
+    static const int ksplit_tiles = getenv("PM_KSPLIT_TILES") ? atoi(getenv("PM_KSPLIT_TILES")) : 64;      // A/B knob
+    if (groups == 1 && tiles < ksplit_tiles && chunks >= 32) {
         int ks = (int)((256 + tiles - 1) / tiles);
         if (ks > chunks / 4) ks = chunks / 4;
         if (ks > 32) ks = 32;
