@@ -254,8 +254,16 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ o
             k0 += 0x9E3779B9u;
             k1 += 0xBB67AE85u;
         }
-        for (int e = 0; e < 4; ++e)
-            if (qd * 4 + e < n) out[qd * 4 + e] = ((float)c[e] * 2.3283064365386963e-10f >= rate) ? keep_scale : 0.f;
+        float m[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = ((float)c[e] * 2.3283064365386963e-10f >= rate) ? keep_scale : 0.f;
+        if (qd * 4 + 3 < n && (reinterpret_cast<size_t>(out) & 15) == 0) {      // one 16-byte store per quad
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<f4*>(out + qd * 4) = f4{m[0], m[1], m[2], m[3]};
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (qd * 4 + e < n) out[qd * 4 + e] = m[e];
+        }
     }
 }
 
