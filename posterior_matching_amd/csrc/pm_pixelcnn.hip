@@ -145,6 +145,25 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
     }
 }
 
+// The same sum with 16-byte loads, one workgroup per (example, 256 columns): 64 column quads x 4 row groups, every thread's
+// P / 4 loads are independent (the 32-column form above is 2048 workgroups of 6 KB each at the mnist PixelCNN's size: 18 us
+// for 12.8 MB).  N % 4 == 0, 16-byte aligned x / out.
+__global__ __launch_bounds__(256) void rows_sum_v4_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int P) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ f4 red[4][64];
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long long b = blockIdx.y;
+    const int n = blockIdx.x * 256 + 4 * cq;
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        const float* p = x + (size_t)b * P * N + n;
+        for (int j = rg; j < P; j += 4) s += *reinterpret_cast<const f4*>(p + (size_t)j * N);
+    }
+    red[rg][cq] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) *reinterpret_cast<f4*>(out + b * N + n) = (red[0][cq] + red[1][cq]) + (red[2][cq] + red[3][cq]);
+}
+
 // out[i] = sum_{g < G} x[g*stride + i]
 __global__ __launch_bounds__(256) void groups_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           long long n, int G, long long stride, int accumulate) {
@@ -449,6 +468,11 @@ extern "C" int pm_gate_bwd(pm_stream_t stream, const float* y, const float* h, c
 extern "C" int pm_rows_sum(pm_stream_t stream, const float* x, float* out, long long B, int N, int P) {
     if (!x || !out || B <= 0 || N <= 0 || P <= 0) return PM_EINVAL;
     if (B > 65535) return PM_EINVAL;
+    if (N % 4 == 0 && N >= 128 && B * ((N + 255) / 256) >= 128 && al16(x) && al16(out)) {     // enough examples to fill the chip
+        hipLaunchKernelGGL(rows_sum_v4_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
+                           out, N, P);
+        return pm_check_launch("pm_rows_sum");
+    }
     hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out,
                        B * N, N, P);
     return pm_check_launch("pm_rows_sum");
