@@ -69,6 +69,8 @@ CONV_CASES = [
     # data gradient with flipped taps, ragged row / column tiles
     ("conv", 256, 7, 64, 128, 7, 1, "VALID"), ("convT", 130, 1, 32, 64, 7, 1, "VALID"), ("conv", 21, 6, 32, 40, 6, 1, "VALID"),
     ("dense", 256, 1, 560, 128, 1, 1, "VALID"), ("dense", 100, 1, 128, 560, 1, 1, "VALID"),   # C % 32 != 0: part-padded last chunk
+    # small images under long kernels (the PixelCNN's 7 x 7 x 256 grids): two images per workgroup share one weight pass
+    ("conv", 256, 7, 256, 256, 3, 1, "SAME"), ("convT", 256, 7, 256, 128, 3, 1, "SAME"),
 ]
 
 
