@@ -51,7 +51,7 @@ def pmc_traffic_child(counter, timeout_s=240):
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--serial", "--no-cpu-baseline", "--no-pmc", "--steps", "3", "--warmup", "2",
-               "--profile-steps", "0", "--no-f32-aux"]
+               "--profile-steps", "0", "--no-f32-aux", "--no-secondary", "--spread-steps", "0"]
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                        check=True)
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
@@ -134,7 +134,26 @@ def main():
     ap.add_argument("--no-f32-aux", action="store_true", help="skip the strict-f32 throughput sample (aux.f32_images_per_sec)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the backward pass instead of "
                                                               "reverse-order buckets overlapped with it")
+    ap.add_argument("--no-secondary", action="store_true", help="skip aux.secondary (a few timed steps of BASELINE.json's "
+                                                                "other configs, outside the headline's timed region)")
+    ap.add_argument("--spread-steps", type=int, default=200, help="extra untimed-for-the-headline steps whose per-step HIP-event "
+                                                                  "times give aux.step_ms quartiles (0 = off)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` unaided: this parent never touches the GPU; it starts the N ranks as CHILD processes
+        # through torch.distributed.run (never an exec of a process that has initialised the GPU) and passes their exit code
+        # on.  Rank 0 of the children writes the JSON line to the inherited stdout.
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its first
     # communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved one.
@@ -146,7 +165,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     # HBM-side traffic per kernel: two PMC passes over a short run of this same workload, each in a child process
     # BEFORE this process initialises the GPU (counters cannot be read from inside the measured process)
@@ -243,6 +262,19 @@ def main():
     per_step = sorted(a.elapsed_ms(b) for a, b in zip([e0] + marks[:-1], marks))
     spread = {"min": round(per_step[0], 4), "median": round(per_step[len(per_step) // 2], 4),
               "max": round(per_step[-1], 4)} if per_step else None
+    # The driver fixes --steps (20 steps = a 29 ms region): quartiles over `--spread-steps` further steps of the same loop,
+    # one HIP event per step on the step's stream, back the A/B claims in DESIGN.md (outside the headline's timed region)
+    if spread is not None and args.spread_steps > 0:
+        marks2 = []
+        with torch.cuda.stream(ts.stream):
+            s0 = ops.Event()
+            s0.record()
+        run(ts, args.spread_steps, args.warmup + args.steps, marks2)
+        fence()
+        ps = sorted(a.elapsed_ms(b) for a, b in zip([s0] + marks2[:-1], marks2))
+        q = lambda f: round(ps[min(len(ps) - 1, int(f * len(ps)))], 4)   # noqa: E731
+        spread["extra_steps"] = {"n": len(ps), "min": q(0.0), "q1": q(0.25), "median": q(0.5), "q3": q(0.75), "max": round(ps[-1], 4),
+                                 "mean": round(sum(ps) / len(ps), 4)}
 
     # strict arithmetic (every GEMM on the f32 MFMA) on the same batches: a few steps OUTSIDE the timed region
     f32_ips = None
@@ -320,6 +352,23 @@ def main():
                 for tag, detail, ms, fl in calls[-per_step_n:]:
                     fp.write(f"{tag:42s} {detail:52s} {ms * 1e3:9.1f} us  {fl / (ms * 1e-3) / 1e12 if fl else 0:6.2f} TFLOP/s\n")
 
+    # BASELINE.json's other configs on the driver's clock: a few timed steps each, after (outside) the headline's region
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary and not args.f32:
+        from tools.workloads import build, measure
+
+        secondary = []
+        for name, bsz, n_steps, n_warm in (("pm_vae_gas", 128, 200, 20), ("vqvae_mnist", 256, 200, 20),
+                                           ("pm_vqvae_mnist", 256, 20, 4), ("pm_vdvae_mnist", 8, 20, 4),
+                                           ("pm_vdvae_mnist", 16, 20, 4), ("pm_vqvae_celeb_a", 16, 20, 4)):
+            try:
+                w = build(name, bsz, device=str(dev))
+                secondary.append(measure(w, n_steps, n_warm))
+                del w
+            except Exception as exc:       # a secondary number must never take the headline down
+                secondary.append({"workload": name, "per_gpu_batch": bsz, "error": repr(exc)[:200]})
+            torch.cuda.empty_cache()
+
     if rank == 0:
         value = world * B * args.steps / dt
         per_gpu = value / world
@@ -341,6 +390,7 @@ def main():
             "aux": {"elbo": round(metrics["reconstruction_ll"] - metrics["beta"] * metrics["kl"], 4),
                     "matching_ll": round(metrics["matching_ll"], 4), "kl": round(metrics["kl"], 4),
                     "loss": round(metrics["loss"], 4), "step_ms": spread, "f32_images_per_sec": f32_ips,
+                    "secondary": secondary,
                     # whole-step fractions SURVEY.md 8(d) asks for, per GPU
                     "mfma_frac": round(per_gpu * F_ALG_EXECUTED / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
                     "mfma_frac_as_reference_states_ar_gmm": round(per_gpu * F_ALG_AS_WRITTEN / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),

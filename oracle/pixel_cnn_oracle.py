@@ -207,7 +207,11 @@ def init_params(cfg: dict, vqvae_cfg: dict, in_channels: int = 2, seed: int = 3,
     """Trainable parameters of stage 2.  haiku defaults: conv / linear TruncatedNormal(+-2)/sqrt(fan_in)
     (conv fan_in = kh*kw*Cin over the FULL kernel, pixel_cnn.py:181-184), Embed TruncatedNormal(stddev 1),
     the conditional projections RandomNormal(stddev 1) (:567), biases zero."""
-    from scipy.stats import truncnorm
+    from scipy.special import ndtr, ndtri
+
+    def _tn(size, random_state):      # scipy.stats.truncnorm.rvs(-2, 2, ...): same uniform draws, inverse CDF by ndtri (1000x faster)
+        lo, hi = ndtr(-2.0), ndtr(2.0)
+        return ndtri(lo + random_state.uniform(size=size) * (hi - lo))
 
     pc = dict(cfg["pixel_cnn"])
     pc["num_indices"] = vqvae_cfg["num_embeddings"]
@@ -218,11 +222,11 @@ def init_params(cfg: dict, vqvae_cfg: dict, in_channels: int = 2, seed: int = 3,
     out: Params = {}
     for name, shp in shapes.items():
         if name.endswith("/embeddings"):
-            arr = truncnorm.rvs(-2.0, 2.0, size=shp, random_state=rng)
+            arr = _tn(shp, rng)
         elif name.endswith("/cond/w"):
             arr = rng.normal(size=shp)
         elif name.endswith("/w"):
-            arr = truncnorm.rvs(-2.0, 2.0, size=shp, random_state=rng) / math.sqrt(int(np.prod(shp[:-1])))
+            arr = _tn(shp, rng) / math.sqrt(int(np.prod(shp[:-1])))
         else:
             arr = np.zeros(shp)
         out[name] = torch.tensor(arr, dtype=dtype)

@@ -302,7 +302,11 @@ def init_params(cfg: dict, seed: int = 1, dtype=torch.float64) -> Params:
     """haiku defaults + the special initialisers of vdvae.py:193-205: c4 of every residual block and z_proj
     TruncatedNormal(stddev/sqrt(N)) with N = number of blocks of that network; c4 of the prior block zeros;
     x_bias / bias zeros; gain ones."""
-    from scipy.stats import truncnorm
+    from scipy.special import ndtr, ndtri
+
+    def _tn(size, random_state):      # scipy.stats.truncnorm.rvs(-2, 2, ...): same uniform draws, inverse CDF by ndtri (1000x faster)
+        lo, hi = ndtr(-2.0), ndtr(2.0)
+        return ndtri(lo + random_state.uniform(size=size) * (hi - lo))
 
     rng = np.random.default_rng(seed)
     n_enc = len(parse_layer_string(cfg["encoder_blocks"]))
@@ -318,7 +322,7 @@ def init_params(cfg: dict, seed: int = 1, dtype=torch.float64) -> Params:
                     std *= math.sqrt(1.0 / n_enc)
                 elif name.endswith("/resnet/c4/w") or name.endswith("/z_proj/w"):
                     std *= math.sqrt(1.0 / n_dec)
-                arr = truncnorm.rvs(-2.0, 2.0, size=shp, random_state=rng) * std
+                arr = _tn(shp, rng) * std
         elif name == "decoder/gain":
             arr = np.ones(shp)
         else:

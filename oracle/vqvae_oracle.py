@@ -200,14 +200,18 @@ def init_params(model_cfg: dict, in_channels: int = 1, seed: int = 1, dtype=torc
     """haiku default init (Appendix A1/A2): TruncatedNormal(+-2) / sqrt(fan_in); conv fan_in =
     kh*kw*Cin, transposed conv fan_in = kh*kw*(last weight axis); biases / log_scale zero."""
     import numpy as np
-    from scipy.stats import truncnorm
+    from scipy.special import ndtr, ndtri
+
+    def _tn(size, random_state):      # scipy.stats.truncnorm.rvs(-2, 2, ...): same uniform draws, inverse CDF by ndtri (1000x faster)
+        lo, hi = ndtr(-2.0), ndtr(2.0)
+        return ndtri(lo + random_state.uniform(size=size) * (hi - lo))
 
     rng = np.random.default_rng(seed)
     out: Params = {}
     for name, shp in param_shapes(model_cfg, in_channels).items():
         if name.endswith("/w"):
             fan_in = shp[0] * shp[1] * (shp[3] if "/dec_2/" in name or "/dec_3/" in name else shp[2])
-            arr = truncnorm.rvs(-2.0, 2.0, size=shp, random_state=rng) / math.sqrt(fan_in)
+            arr = _tn(shp, rng) / math.sqrt(fan_in)
         else:
             arr = np.zeros(shp)
         out[name] = torch.tensor(arr, dtype=dtype)

@@ -221,6 +221,7 @@ SIGNATURES = {
 }
 _OTHER_RESTYPE = {"pm_strerror": ([_I], C.c_char_p), "pm_last_error": ([], C.c_char_p),
                   "pm_kernel_names_enable": ([_I], None), "pm_last_kernel_name": ([], C.c_char_p),
+                  "pm_last_kernel_variant": ([], C.c_char_p),
                   "pm_clear_kernel_name": ([], None)}
 
 _lib = None

@@ -103,11 +103,12 @@ def rename(path: str) -> str:
 
 
 def match_by_order(src: Mapping[str, np.ndarray], native_shapes: Mapping[str, Tuple[int, ...]],
-                   done: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+                   done: Mapping[str, np.ndarray], strict: bool = True) -> Dict[str, np.ndarray]:
     """Whatever the rules left unmatched: inside each top-level scope, pair the remaining source leaves (natural order of
     their haiku paths) with the remaining native names (creation order), leaf kind by leaf kind (w with w, b with b, ...),
     when - and only when - counts and shape sequences agree."""
     out: Dict[str, np.ndarray] = {}
+    ambiguous = []
     todo_native = [n for n in native_shapes if n not in done]
     todo_src = sorted(src, key=_natural_key)
     scope_of = lambda path: path.split("/")[0]   # noqa: E731
@@ -119,7 +120,20 @@ def match_by_order(src: Mapping[str, np.ndarray], native_shapes: Mapping[str, Tu
             nn = [n for n in nat if leaf_of(n) == leaf]
             cc = [s for s in cand if leaf_of(s) == leaf]
             if len(nn) == len(cc) and all(tuple(src[s].shape) == tuple(native_shapes[n]) for n, s in zip(nn, cc)):
+                # equal shapes prove nothing when several leaves share one shape (stacks of 256x256 linears, the VDVAE's
+                # repeated Blocks): a creation order that differs from haiku's natural name order would permute weights
+                # silently.  Pair by order only where every shape in the group is unique; otherwise a rename rule is needed.
+                shapes = [tuple(native_shapes[n]) for n in nn]
+                if len(set(shapes)) != len(shapes):
+                    if strict:
+                        continue
+                    ambiguous.extend(zip(nn, cc))
                 out.update(zip(nn, (src[s] for s in cc)))
+    if ambiguous:
+        import warnings
+
+        warnings.warn("checkpoint import paired same-shaped leaves by order only: "
+                      + ", ".join(f"{c} -> {n}" for n, c in ambiguous[:8]) + (" ..." if len(ambiguous) > 8 else ""))
     return out
 
 

@@ -14,9 +14,17 @@ void pm_ktagf(const char* fmt, ...) {
     vsnprintf(pm_ktag_text, sizeof(pm_ktag_text), fmt, ap);
     va_end(ap);
 }
-extern "C" void pm_kernel_names_enable(int on) { pm_ktag_on = on != 0; pm_ktag_text[0] = 0; }
+static thread_local char pm_kvar_text[64] = "";
+void pm_kvarf(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(pm_kvar_text, sizeof(pm_kvar_text), fmt, ap);
+    va_end(ap);
+}
+extern "C" void pm_kernel_names_enable(int on) { pm_ktag_on = on != 0; pm_ktag_text[0] = 0; pm_kvar_text[0] = 0; }
 extern "C" const char* pm_last_kernel_name(void) { return pm_ktag_text; }
-extern "C" void pm_clear_kernel_name(void) { pm_ktag_text[0] = 0; }
+extern "C" const char* pm_last_kernel_variant(void) { return pm_kvar_text; }
+extern "C" void pm_clear_kernel_name(void) { pm_ktag_text[0] = 0; pm_kvar_text[0] = 0; }
 
 int pm_check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -15,6 +15,10 @@ int pm_check_launch(const char* what);
 extern bool pm_ktag_on;
 void pm_ktagf(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 #define PM_KTAG(...) do { if (pm_ktag_on) pm_ktagf(__VA_ARGS__); } while (0)
+// A dispatch-relevant property of the call that the kernel name does not carry ("masked": a sub-kernel of a masked
+// convolution, kws > KW).  tests/test_gpu_zz_coverage.py keys on (name, variant).
+void pm_kvarf(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+#define PM_KVAR(...) do { if (pm_ktag_on) pm_kvarf(__VA_ARGS__); } while (0)
 // Zero-fill by a plain kernel (ptr and nbytes multiples of 4).  hipMemsetAsync is avoided on purpose:
 // captured as a memset node of a HIP graph on ROCm 7.2 it was observed to leave every fourth dword
 // of the range non-zero on replay (tests/test_gpu_vqvae.py::test_vqvae_train_steps_match_oracle).

@@ -3501,6 +3501,7 @@ bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {
     g.wts = d->wts; g.wcs = d->wcs; g.wns = d->wns; g.kws = d->kws; g.M = (int)M; g.K = (int)K;
     g.in_act = d->in_act; g.out_act = d->out_act; g.aux_act = d->aux_act; g.slope = d->slope;
     g.PY = g.PX = 1;
+    if (d->kws != d->KW) PM_KVAR("masked");
     if (class_major) {
         if (d->d > 1 && d->OH % d->d == 0 && d->OW % d->d == 0) {
             g.PY = g.PX = d->d;                      // zero-dilated forms: one class per residue

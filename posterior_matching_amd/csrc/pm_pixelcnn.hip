@@ -410,10 +410,12 @@ extern "C" int pm_concat_elu_fwd(pm_stream_t stream, const float* a, const float
     if (Ca % 4 == 0 && Cb % 4 == 0 && total < 0x7fffffffLL && al16(a) && al16(b) && al16(drop) && al16(out)) {
         const unsigned nv = (unsigned)(rows * (Ca + Cb) / 4);
         typedef const pc_f32x4* cp;
+        PM_KTAG("concat_elu_fwd_v4_kernel<%s>", drop ? "true" : "false");
         if (drop) hipLaunchKernelGGL(concat_elu_fwd_v4_kernel<true>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (pc_f32x4*)out, nv, (unsigned)Ca / 4, (unsigned)Cb / 4);
         else hipLaunchKernelGGL(concat_elu_fwd_v4_kernel<false>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (pc_f32x4*)out, nv, (unsigned)Ca / 4, (unsigned)Cb / 4);
         return pm_check_launch("pm_concat_elu_fwd");
     }
+    PM_KTAG("concat_elu_fwd_kernel");
     hipLaunchKernelGGL(concat_elu_fwd_kernel, dim3(blocks_for(rows * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, b,
                        drop, out, rows, Ca, Cb);
     return pm_check_launch("pm_concat_elu_fwd");
@@ -428,10 +430,12 @@ extern "C" int pm_concat_elu_bwd(pm_stream_t stream, const float* a, const float
         al16(db) && al16(add_a)) {
         const unsigned nv = (unsigned)(rows * (Ca + Cb) / 4);
         typedef const pc_f32x4* cp;
+        PM_KTAG("concat_elu_bwd_v4_kernel<%s>", drop ? "true" : "false");
         if (drop) hipLaunchKernelGGL(concat_elu_bwd_v4_kernel<true>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (cp)dout, (pc_f32x4*)da, (pc_f32x4*)db, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, accumulate, (cp)add_a);
         else hipLaunchKernelGGL(concat_elu_bwd_v4_kernel<false>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (cp)dout, (pc_f32x4*)da, (pc_f32x4*)db, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, accumulate, (cp)add_a);
         return pm_check_launch("pm_concat_elu_bwd");
     }
+    PM_KTAG("concat_elu_bwd_kernel");
     hipLaunchKernelGGL(concat_elu_bwd_kernel, dim3(blocks_for(rows * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, b,
                        drop, dout, da, db, rows, Ca, Cb, accumulate, add_a);
     return pm_check_launch("pm_concat_elu_bwd");
@@ -443,9 +447,11 @@ extern "C" int pm_gate_fwd(pm_stream_t stream, const float* y, const float* h, c
     if (F % 4 == 0 && rows * 2 * F < 0x7fffffffLL && al16(y) && al16(h) && al16(input) && al16(out)) {
         const unsigned nv = (unsigned)(rows * F / 4);
         typedef const pc_f32x4* cp;
+        PM_KTAG("gate_v4_kernel<false>");
         hipLaunchKernelGGL(gate_v4_kernel<false>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)y, (cp)h, (cp)input, (pc_f32x4*)out, nv, (unsigned)F / 4, (unsigned)P);
         return pm_check_launch("pm_gate_fwd");
     }
+    PM_KTAG("gate_fwd_kernel");
     hipLaunchKernelGGL(gate_fwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, y, h, input, out,
                        rows, F, P);
     return pm_check_launch("pm_gate_fwd");
@@ -457,9 +463,11 @@ extern "C" int pm_gate_bwd(pm_stream_t stream, const float* y, const float* h, c
     if (F % 4 == 0 && rows * 2 * F < 0x7fffffffLL && al16(y) && al16(h) && al16(dout) && al16(dy)) {
         const unsigned nv = (unsigned)(rows * F / 4);
         typedef const pc_f32x4* cp;
+        PM_KTAG("gate_v4_kernel<true>");
         hipLaunchKernelGGL(gate_v4_kernel<true>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)y, (cp)h, (cp)dout, (pc_f32x4*)dy, nv, (unsigned)F / 4, (unsigned)P);
         return pm_check_launch("pm_gate_bwd");
     }
+    PM_KTAG("gate_bwd_kernel");
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, y, h, dout, dy,
                        rows, F, P);
     return pm_check_launch("pm_gate_bwd");
@@ -469,10 +477,12 @@ extern "C" int pm_rows_sum(pm_stream_t stream, const float* x, float* out, long 
     if (!x || !out || B <= 0 || N <= 0 || P <= 0) return PM_EINVAL;
     if (B > 65535) return PM_EINVAL;
     if (N % 4 == 0 && N >= 128 && B * ((N + 255) / 256) >= 128 && al16(x) && al16(out)) {     // enough examples to fill the chip
+        PM_KTAG("rows_sum_v4_kernel");
         hipLaunchKernelGGL(rows_sum_v4_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
                            out, N, P);
         return pm_check_launch("pm_rows_sum");
     }
+    PM_KTAG("rows_sum_kernel");
     hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out,
                        B * N, N, P);
     return pm_check_launch("pm_rows_sum");

@@ -562,6 +562,7 @@ extern "C" int pm_thin_conv(pm_stream_t stream, const pm_gather_desc* d, const f
         }
         if (TH < 1) return PM_EINVAL;
         const int tiles = (t.OH + TH - 1) / TH;
+        PM_KTAG("thin_to1_kernel");
         hipLaunchKernelGGL(thin_to1_kernel, dim3(t.B * tiles), dim3(256), lds, s, t, TH, in, w, bias, aux, res, out);
         return pm_check_launch("pm_thin_conv");
     }
@@ -572,6 +573,7 @@ extern "C" int pm_thin_conv(pm_stream_t stream, const pm_gather_desc* d, const f
         const size_t lds = (size_t)t.C * (TH + t.KH - 1) * (4 * ((t.OW + 3) / 4) + 4) * 4;
         const dim3 grid(t.B * tiles);
 #define PM_TL(CCv, KSv) hipLaunchKernelGGL((thin_conv_lane_kernel<CCv, KSv>), grid, dim3(256), lds, s, t, TH, in, w, bias, aux, res, out)
+        PM_KTAG("thin_conv_lane_kernel<%d, %d>", t.C == 1 ? 1 : 2, t.KH == 5 ? 5 : 3);
         if (t.C == 1 && t.KH == 5) PM_TL(1, 5);
         else if (t.C == 2 && t.KH == 5) PM_TL(2, 5);
         else if (t.C == 1) PM_TL(1, 3);
@@ -580,6 +582,7 @@ extern "C" int pm_thin_conv(pm_stream_t stream, const pm_gather_desc* d, const f
         return pm_check_launch("pm_thin_conv");
     }
     if (t.KH * t.KW * t.C > THIN_MAXKK || t.N % 8 != 0) return PM_EINVAL;
+    PM_KTAG("thin_conv_kernel");
     hipLaunchKernelGGL(thin_conv_kernel, dim3((t.M + 63) / 64), dim3(256), 0, s, t, in, w, bias, aux, res, out);
     return pm_check_launch("pm_thin_conv");
 }
@@ -606,6 +609,7 @@ extern "C" int pm_thin_to1_bf16(pm_stream_t stream, const pm_gather_desc* d, con
     if (TH < 1) return PM_EINVAL;
     const int tiles = (t.OH + TH - 1) / TH;
     hipStream_t s = (hipStream_t)stream;
+    PM_KTAG("thin_to1_bf16_kernel<%d>", t.C == 32 ? 1 : 2);
     if (t.C == 32) hipLaunchKernelGGL(thin_to1_bf16_kernel<1>, dim3(t.B * tiles), dim3(256), lds, s, t, TH, in, w, bias, aux, res, out);
     else hipLaunchKernelGGL(thin_to1_bf16_kernel<2>, dim3(t.B * tiles), dim3(256), lds, s, t, TH, in, w, bias, aux, res, out);
     return pm_check_launch("pm_thin_to1_bf16");
@@ -633,6 +637,7 @@ extern "C" int pm_thin_wgrad(pm_stream_t stream, const pm_gather_desc* d, const 
     const dim3 grid(t.B < 256 ? t.B : 256);
     hipStream_t s = (hipStream_t)stream;
 #define PM_TW(CCv, KSv) hipLaunchKernelGGL((thin_wgrad_lane_kernel<CCv, KSv, NS>), grid, dim3(32 * NS), lds, s, t, gathered, dense, dw, db, db_gathered)
+    PM_KTAG("thin_wgrad_lane_kernel<%d, %d, 32>", t.C == 1 ? 1 : 2, t.KH == 5 ? 5 : 3);
     if (t.C == 1 && t.KH == 5) PM_TW(1, 5);
     else if (t.C == 2 && t.KH == 5) PM_TW(2, 5);
     else if (t.C == 1) PM_TW(1, 3);

@@ -825,11 +825,12 @@ extern "C" int pm_diag_tril_kl_fwd(pm_stream_t stream, const float* post, const 
                                    long long rows, int Z, int P) {
     if (!post || !masked_params || !kl || rows <= 0 || Z <= 0 || Z > 16 || P <= 0) return PM_EINVAL;
     static const bool old_form = getenv("PM_TRIL_KL_WAVE") != nullptr;     // A/B switch for measurements
+    PM_KTAG(Z == 16 && !old_form ? "diag_tril_kl16_kernel<false>" : "diag_tril_kl_kernel<false>");
     if (Z == 16 && !old_form)
         hipLaunchKernelGGL(diag_tril_kl16_kernel<false>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, post,
                            masked_params, kl, 0.f, (float*)nullptr, rows, P);
     else
-    hipLaunchKernelGGL(diag_tril_kl_kernel<false>, dim3((unsigned)((rows + 4 * DT_SPW - 1) / (4 * DT_SPW))), dim3(256), 0, (hipStream_t)stream, post,
+        hipLaunchKernelGGL(diag_tril_kl_kernel<false>, dim3((unsigned)((rows + 4 * DT_SPW - 1) / (4 * DT_SPW))), dim3(256), 0, (hipStream_t)stream, post,
                        masked_params, kl, 0.f, (float*)nullptr, rows, Z, P);
     return pm_check_launch("pm_diag_tril_kl_fwd");
 }
@@ -838,11 +839,12 @@ extern "C" int pm_diag_tril_kl_bwd(pm_stream_t stream, const float* post, const 
                                    float* dmasked_params, long long rows, int Z, int P) {
     if (!post || !masked_params || !dmasked_params || rows <= 0 || Z <= 0 || Z > 16 || P <= 0) return PM_EINVAL;
     static const bool old_form = getenv("PM_TRIL_KL_WAVE") != nullptr;
+    PM_KTAG(Z == 16 && !old_form ? "diag_tril_kl16_kernel<true>" : "diag_tril_kl_kernel<true>");
     if (Z == 16 && !old_form)
         hipLaunchKernelGGL(diag_tril_kl16_kernel<true>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, post,
                            masked_params, (float*)nullptr, g, dmasked_params, rows, P);
     else
-    hipLaunchKernelGGL(diag_tril_kl_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, post,
+        hipLaunchKernelGGL(diag_tril_kl_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, post,
                        masked_params, (float*)nullptr, g, dmasked_params, rows, Z, P);
     return pm_check_launch("pm_diag_tril_kl_bwd");
 }

@@ -214,9 +214,11 @@ extern "C" int pm_vq_select(pm_stream_t stream, const float* z, const float* emb
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_set = true;
         }
+        PM_KTAG("vq_select_kernel<true>");
         hipLaunchKernelGGL(vq_select_kernel<true>, grid, block, lds, s, z, emb, dots, e2, idx, quant, commit_grad, sqerr,
                            counts, dw, N, D, K, commit_coef);
     } else {
+        PM_KTAG("vq_select_kernel<false>");
         hipLaunchKernelGGL(vq_select_kernel<false>, grid, block, 0, s, z, emb, dots, e2, idx, quant, commit_grad, sqerr,
                            counts, dw, N, D, K, commit_coef);
     }

@@ -78,6 +78,9 @@ class SyntheticDataset:
             i += 1
 
 
+_RESIDENT: Dict[tuple, torch.Tensor] = {}     # host array identity -> its uint8 copy in HBM
+
+
 class DeviceUint8Dataset:
     """A uint8 image array [N, H, W, C] resident in HBM (MNIST 47 MB, CelebA 64x64 2.4 GB of the 288 GB): every yielded
     batch draws its B row indices from a device Philox stream and gathers + converts the rows in one kernel
@@ -91,14 +94,22 @@ class DeviceUint8Dataset:
                  training: bool = True):
         from . import ops  # noqa: F401  (fails loudly without the HIP library)
 
-        images = np.ascontiguousarray(images)
-        if images.dtype != np.uint8:
+        self.device = torch.device(device)
+        if images.dtype not in (np.uint8, torch.uint8):
             raise TypeError(f"DeviceUint8Dataset holds uint8 pixels, got {images.dtype}")
         shape = data_shape(config["dataset"])
         if tuple(images.shape[1:]) != tuple(shape):
             raise ValueError(f"{config['dataset']} examples are {shape}, the array holds {tuple(images.shape[1:])}")
-        self.device = torch.device(device)
-        self.images = torch.from_numpy(images).to(self.device)
+        if images.shape[0] < batch_size:        # pm_gather_u8_rows reads batch_size rows: a shorter array would be read past its end
+            raise ValueError(f"the array holds {images.shape[0]} examples, fewer than one batch of {batch_size}")
+        if isinstance(images, torch.Tensor):     # already resident (the train and validation datasets of one run share it)
+            self.images = images.to(self.device).contiguous()
+        else:
+            key = (images.__array_interface__["data"][0], tuple(images.shape), str(self.device))
+            if key not in _RESIDENT:
+                _RESIDENT.clear()                # one resident array per process (CelebA 64x64: 2.4 GB)
+                _RESIDENT[key] = torch.from_numpy(np.ascontiguousarray(images)).to(self.device)
+            self.images = _RESIDENT[key]
         self.key, self.batch_size, self.shape, self.seed = "image", batch_size, shape, seed
         self.scale = 1.0 / 255.0 if normalize_images else 1.0
         self._step = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -111,6 +122,7 @@ class DeviceUint8Dataset:
             self._mask = torch.empty((batch_size,) + shape[:-1] + (1,), dtype=torch.float32, device=self.device)
         self.sequential = not training          # validation: walk the array in order instead of sampling
         self._cursor = 0
+        self._batches = None
 
     def next_batch(self) -> Dict[str, torch.Tensor]:
         from . import ops
@@ -133,12 +145,13 @@ class DeviceUint8Dataset:
     @property
     def batches(self):
         """a few materialised batches (callbacks that index `.batches`, Trainer._validate)"""
-        n = max(1, min(8, self.images.shape[0] // self.batch_size))
-        out = []
-        for _ in range(n):
-            b = self.next_batch()
-            out.append({k: v.clone() for k, v in b.items()})
-        return out
+        if self._batches is None:               # materialised once: indexing `.batches` must not advance the cursor again
+            n = max(1, min(8, self.images.shape[0] // self.batch_size))
+            self._batches = []
+            for _ in range(n):
+                b = self.next_batch()
+                self._batches.append({k: v.clone() for k, v in b.items()})
+        return self._batches
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         while True:

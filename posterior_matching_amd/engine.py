@@ -107,7 +107,9 @@ class PMVAETrainStep(_PlannedStep):
         self.world_size, self.rank, self.seed = world_size, rank, seed
         self.loss_cfg = loss_cfg_from_config(config, batch_size)
         self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
-        self.reducer = _make_reducer(model.store, world_size, overlap_allreduce)
+        # a captured step reduces between its two graphs: nothing may be issued from inside the capture (GradReducer.ready
+        # is a no-op while capturing as well)
+        self.reducer = _make_reducer(model.store, world_size, overlap_allreduce and not use_graph)
         x_shape = tuple(x_shape)
         b_shape = x_shape[:-1] + (1,) if len(x_shape) == 3 else x_shape
         self.x = torch.zeros((batch_size,) + x_shape, device=dev)
@@ -348,6 +350,12 @@ class PMVQVAETrainStep(_PlannedStep):
         return ll
 
     def _sequence(self) -> None:
+        self._forward_backward()
+        self._update()
+
+    def _forward_backward(self) -> None:
+        """forward + loss + the whole backward pass as the train step runs it (grouped weight gradients, two chains): the
+        flat gradient buffer holds d loss / d trainable parameters afterwards"""
         s = self.store
         self.forward(True)
         ops.fill_zero(s.flat_g)
@@ -357,13 +365,21 @@ class PMVQVAETrainStep(_PlannedStep):
         if batched:
             if getattr(self, "_wgrad_batch", None) is None:
                 self._wgrad_batch = ops.WgradBatch()
+            self._wgrad_batch.reducer = self.reducer
             self.ws.wgrad_batch = self._wgrad_batch
-        dcond = self.pcnn.backward(self.g_ll)
-        self.penc.backward(dcond)
-        if batched:
-            self.ws.wgrad_batch.flush()
-            self.ws.wgrad_batch = None
+        try:
+            dcond = self.pcnn.backward(self.g_ll)
+            self.penc.backward(dcond)
+            if batched:
+                self.ws.wgrad_batch.flush()
+        finally:
+            if batched:                     # never leave the shared workspace in deferred mode (evaluation paths share it)
+                self._wgrad_batch.discard()
+                self.ws.wgrad_batch = None
         self.ws.join_aux()
+
+    def _update(self) -> None:
+        s = self.store
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)

@@ -21,6 +21,16 @@ from .. import ops
 from ..ops import ACT_NONE
 
 
+def truncated_normal(rng, shape) -> np.ndarray:
+    """N(0, 1) truncated to [-2, 2] by inverse-CDF sampling: the values scipy.stats.truncnorm.rvs(-2, 2, size=shape,
+    random_state=rng) returns (same uniform draws, equal to 2e-15), 1000x faster (scipy's ppf took 41 s for the PixelCNN's
+    35 M parameters)."""
+    from scipy.special import ndtr, ndtri
+
+    lo, hi = ndtr(-2.0), ndtr(2.0)
+    return ndtri(lo + rng.uniform(size=shape) * (hi - lo))
+
+
 @dataclass
 class Feat:
     """A network output handed to its consumer.
@@ -72,16 +82,14 @@ class ParamStore:
     def allocate(self, device, seed: int = 1) -> None:
         """Allocates the flat buffers and draws haiku-default initial values (SURVEY A1/A2/A4:
         N(0,1) truncated to [-2,2] times 1/sqrt(fan_in); biases and log_scale zero)."""
-        from scipy.stats import truncnorm
-
         self.device = device
         rng = np.random.default_rng(seed)
         host = {}
         for name, (shape, fan_in) in self.specs.items():      # creation order fixes the RNG stream
             if fan_in > 0:
-                host[name] = (truncnorm.rvs(-2.0, 2.0, size=shape, random_state=rng) / math.sqrt(fan_in)).astype(np.float32)
+                host[name] = (truncated_normal(rng, shape) / math.sqrt(fan_in)).astype(np.float32)
             elif fan_in == -1:
-                host[name] = truncnorm.rvs(-2.0, 2.0, size=shape, random_state=rng).astype(np.float32)
+                host[name] = truncated_normal(rng, shape).astype(np.float32)
             elif fan_in == -2:
                 host[name] = rng.normal(size=shape).astype(np.float32)
             elif fan_in == -3:

@@ -398,8 +398,11 @@ class PixelCNN(Module):
         fs = None
         for blk in reversed(self.blocks):
             vertical = blk.stack == "vertical"
-            if two and fs is None and blk.name.startswith("down") and os.environ.get("PM_PIXELCNN_MID_FLUSH"):
-                # (measured neutral: celeb_a 1638 -> 1622 img/s, mnist 20.3k -> 20.5k; off unless asked for)
+            if (two and fs is None and blk.name.startswith("down")
+                    and (os.environ.get("PM_PIXELCNN_MID_FLUSH") or self.store.reducer is not None)):
+                # (measured neutral on one GPU: celeb_a 1638 -> 1622 img/s, mnist 20.3k -> 20.5k; off unless asked for.  Data-
+                # parallel: ON - the up pass's weights (half of the 140 / 273 MB gradient) are final after this flush, so
+                # their buckets are all-reduced beside the whole down pass instead of after the last launch)
                 # every up-pass block has left its operands in HBM: their grouped weight gradients (throughput-bound) start
                 # now on a third stream, beside the two latency-bound chains of the down pass
                 if getattr(self, "_fstream", None) is None:

@@ -897,11 +897,22 @@ class PosteriorMatchingVDVAE(Module):
         if batched:
             if getattr(self, "_wgrad_batch", None) is None:
                 self._wgrad_batch = ops.WgradBatch()
+            self._wgrad_batch.reducer = self.store.reducer     # data-parallel: every grouped launch reports its weight ranges
             self.ws.wgrad_batch = self._wgrad_batch
+        try:
+            self._backward_body(g, B, H, W_, width, nm)
+        finally:
+            if batched:                 # never leave the shared workspace in deferred mode (evaluation paths share it)
+                self._wgrad_batch.discard()
+                self.ws.wgrad_batch = None
+
+    def _backward_body(self, g, B, H, W_, width, nm) -> None:
+        import os
+
         dparams = self.ws.get("decoder/d_dmol_params", tuple(self._params.shape))
         ops.dmol_ll_bwd(self._params, self._x, -g, dparams, nm, H * W_)
         self.wgrad(self.out_net.g, self._px_z, dparams, self.store.g[self.out_net.w], self.store.g[self.out_net.b])
-        if self.store.reducer is not None:
+        if self.store.reducer is not None and self.ws.wgrad_batch is None:     # (batched: the flush reports it)
             self.ws.join_all_aux()
             self.store.grads_ready(["decoder/out_net"])
         dpx = self.ws.get("decoder/d_px_z", tuple(self._px_z.shape))
@@ -923,7 +934,7 @@ class PosteriorMatchingVDVAE(Module):
         # backward chain leaves it: they start then on their own stream, beside the rest of the chain (dependent small
         # launches that leave most of the chip idle) - same number of launches as one flush at the very end.
         flush_stream = None
-        if self.ws.wgrad_batch is not None and self.store.reducer is None and not os.environ.get("PM_VDVAE_ONE_FLUSH"):
+        if self.ws.wgrad_batch is not None and not os.environ.get("PM_VDVAE_ONE_FLUSH"):
             if getattr(self, "_flush_stream", None) is None:
                 self._flush_stream = torch.cuda.Stream(device=self._x.device)
             flush_stream = self._flush_stream
@@ -989,7 +1000,6 @@ class PosteriorMatchingVDVAE(Module):
         if self.ws.wgrad_batch is not None:
             # every Block has left its operands in HBM: their weight gradients, one launch per (resolution, layer shape)
             self.ws.wgrad_batch.flush()
-            self.ws.wgrad_batch = None
         if flush_stream is not None:
             ops.wait_stream(main, flush_stream)
         self.ws.join_all_aux()

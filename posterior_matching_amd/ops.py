@@ -129,12 +129,38 @@ def host_call(fn, *args) -> None:
         _recording.append((fn, args, getattr(fn, "__name__", "host_call")))
 
 
+# ---- kernel coverage: which kernel variants a piece of host code launched (tests/test_gpu_zz_coverage.py) -------------
+_coverage: Optional[set] = None
+
+
+def coverage_begin() -> None:
+    """from here on every C-ABI call adds "<kernel name as rocprofv3 prints it>[<variant>]" (entry points with one kernel:
+    the entry point's name) to a set; eager calls only (a replayed launch plan repeats what was recorded)"""
+    global _coverage
+    _coverage = set()
+    _lib.load().pm_kernel_names_enable(1)
+
+
+def coverage_end() -> set:
+    global _coverage
+    out, _coverage = _coverage or set(), None
+    if _timer is None:
+        _lib.load().pm_kernel_names_enable(0)
+    return out
+
+
 def _call(fname: str, *args, tag: Optional[str] = None, work: Optional[dict] = None) -> None:
     lib = _lib.load()
     fn = getattr(lib, fname)
     if _timer is None:
         full = (_stream(),) + args
-        _lib.check(fn(*full), fname)
+        if _coverage is not None:
+            lib.pm_clear_kernel_name()
+            _lib.check(fn(*full), fname)
+            var = lib.pm_last_kernel_variant().decode()
+            _coverage.add((lib.pm_last_kernel_name().decode() or fname) + (f"[{var}]" if var else ""))
+        else:
+            _lib.check(fn(*full), fname)
         if _recording is not None:
             _recording.append((fn, full, fname))
         return
@@ -556,6 +582,7 @@ class WgradBatch:
     def __init__(self):
         self.items = {}          # key -> [(geom, x, dy, dw, db)]
         self._tables = {}        # (key, pointer tuple) -> (device table, aligned flag)
+        self.reducer = None      # parallel.GradReducer under data parallelism: every grouped launch reports its weight ranges
 
     def add(self, g: LayerGeom, x, dy, dw, db, bf16: bool, in_act: int = ACT_NONE) -> None:
         if g.kind == "convT":
@@ -595,6 +622,16 @@ class WgradBatch:
                 work = {"flops": _algorithmic_flops(d), "bytes": len(lst) * _nbytes(x0, dy0, dw0), "detail": _detail(d)}
             _call("pm_gather_wgrad_table", C.byref(d), _ptr(x0), _ptr(dy0), _ptr(dw0), _ptr(db0), table.data_ptr(), aligned,
                   int(key[-2]), tag=tag, work=work)
+            if self.reducer is not None:
+                # data-parallel: these weights have their final gradient once this launch has run (a parameter belongs to one
+                # layer, a layer to one group); bias gradients sit in the 1-D suffix, which finish() reduces
+                base, n = self.reducer.flat.data_ptr(), self.reducer.flat.numel()
+                offs = [((dw.data_ptr() - base) // 4, dw.numel()) for _, _, _, dw, _ in lst]
+                self.reducer.ready_ranges([(o, o + c) for o, c in offs if 0 <= o and o + c <= n])
+        self.items = {}
+
+    def discard(self) -> None:
+        """drops queued items (a backward pass that raised must not leave stale operands behind)"""
         self.items = {}
 
 

@@ -61,24 +61,30 @@ class GradReducer:
     what pmap's pmean does for the reference at train_pm_vdvae.py:146-154, one bucket at a time instead of after the fact).
 
     The flat gradient buffer is [ndim != 1 leaves in creation order | 1-D leaves].  A model's backward calls
-    `ready(prefixes)` on the stream that carried those modules' weight-gradient kernels as soon as every parameter under
-    the prefixes has its final gradient; the weight range of those modules (contiguous: a module's leaves are created
-    together) joins the pending range, and once `bucket_bytes` are pending the range is all-reduced on the communication
-    stream behind an event of the producing stream(s).  `finish()` reduces what is left - in particular the whole 1-D
-    suffix (biases: a few KB) in one call - and makes the current stream wait for every collective.  Sum only: the
-    optimizer kernels divide by the world size (grad_scale), and the VDVAE's global-norm clip / non-finite skip run on the
-    reduced buffer after finish(), so every rank takes the same decision.
+    `ready(prefixes)` (or `ready_ranges` with element ranges of the flat buffer: ops.WgradBatch reports the weight
+    gradients of every grouped launch that way) on the stream that carried the weight-gradient kernels as soon as those
+    parameters have their final gradient.  Ranges join the pending set; once `bucket_bytes` are pending, every merged
+    (contiguous) pending range of at least `min_issue_bytes` is all-reduced on the communication stream behind an event
+    of the producing stream(s); smaller fragments (one layer of a Block whose neighbours are still to come) wait until
+    their neighbours arrive or until finish().  `finish()` reduces what is left - in particular the whole 1-D suffix
+    (biases: a few KB) in one call - and makes the current stream wait for every collective.  Sum only: the optimizer
+    kernels divide by the world size (grad_scale), and the VDVAE's global-norm clip / non-finite skip run on the reduced
+    buffer after finish(), so every rank takes the same decision.  Every rank runs the same host code, so every rank
+    issues the same collectives in the same order.
 
     Every operation goes through ops.record_event / ops.wait_event / ops.host_call, so a recorded launch plan replays
-    the same overlap."""
+    the same overlap.  While a HIP graph is being captured ready() does nothing (a collective issued during capture would
+    run once at capture time and never again): a captured step reduces everything in finish(), between its graphs."""
 
-    def __init__(self, store, bucket_bytes: int = 16 << 20, overlap: bool = True, async_issue: Optional[bool] = None):
+    def __init__(self, store, bucket_bytes: int = 16 << 20, overlap: bool = True, async_issue: Optional[bool] = None,
+                 min_issue_bytes: Optional[int] = None):
         """async_issue: collectives are enqueued without blocking the host (default for nccl = RCCL: the collective is a
         kernel on RCCL's stream, ordered behind the bucket's event).  gloo stages device tensors through pinned host
         memory on a two-thread pool; several collectives of one step in flight there were measured 60x slower than one
         (2 ranks sharing one MI355X: 402 vs 6.9 ms per step), so for gloo (CPU tests, the one-GPU rehearsal) each bucket
         is reduced synchronously at its ready point: same buckets, same order, same results, no overlap."""
         self.store, self.bucket_bytes, self.overlap = store, int(bucket_bytes), overlap
+        self.min_issue_bytes = int(min_issue_bytes) if min_issue_bytes is not None else self.bucket_bytes // 4
         if async_issue is None:
             async_issue = dist.is_initialized() and dist.get_backend() == "nccl"
         self.async_issue = async_issue
@@ -90,7 +96,9 @@ class GradReducer:
         self._pending_events: List["torch.cuda.Event"] = []
         self._works: List = []
         self.calls_last_step = 0
+        self.calls_before_finish_last_step = 0          # collectives issued while the backward pass was still running
         self._calls = 0
+        self._calls_early = 0
 
     # -- ranges ---------------------------------------------------------------------------------------------------
     def _weight_range(self, prefixes: Sequence[str]) -> Optional[Tuple[int, int]]:
@@ -113,9 +121,14 @@ class GradReducer:
                 out.append((a, b))
         return out
 
+    @staticmethod
+    def _overlaps(r, ranges) -> bool:
+        return any(a < r[1] and r[0] < b for a, b in ranges)
+
     # -- host-side pieces that a launch plan replays --------------------------------------------------------------------
-    def _issue(self, a: int, b: int) -> None:
+    def _issue(self, a: int, b: int, early: bool = False) -> None:
         self._calls += 1
+        self._calls_early += int(early)
         if not self.async_issue:
             if self._cuda:
                 self.comm.synchronize()         # the bucket's producers (events the comm stream waits for) have run
@@ -132,16 +145,23 @@ class GradReducer:
             w.wait()                      # the current stream waits for the collective (nccl); gloo blocks the host
         self._works.clear()
         self.calls_last_step, self._calls = self._calls, 0
+        self.calls_before_finish_last_step, self._calls_early = self._calls_early, 0
 
-    def _flush(self) -> None:
+    def _flush(self, final: bool) -> None:
         from . import ops
 
+        merged = self._merge(self._pending)
+        go = [r for r in merged if final or (r[1] - r[0]) * 4 >= self.min_issue_bytes]
+        if not go:
+            return
+        # the communication stream is in order: once it has waited for an event, every later collective is behind it too
         for ev in self._pending_events:
             ops.wait_event(self.comm, ev)
-        for a, b in self._merge(self._pending):
-            ops.host_call(self._issue, a, b)
+        self._pending_events = []
+        for a, b in go:
+            ops.host_call(self._issue, a, b, not final)
             self._done.append((a, b))
-        self._pending, self._pending_events = [], []
+        self._pending = [r for r in merged if r not in go]
 
     # -- model-facing API ------------------------------------------------------------------------------------------
     def ready(self, prefixes: Sequence[str], streams: Optional[Sequence["torch.cuda.Stream"]] = None) -> None:
@@ -149,18 +169,30 @@ class GradReducer:
         the current stream) has run"""
         if not self.overlap:
             return
+        r = self._weight_range(prefixes)
+        if r is not None:
+            self.ready_ranges([r], streams)
+
+    def ready_ranges(self, ranges: Sequence[Tuple[int, int]], streams: Optional[Sequence["torch.cuda.Stream"]] = None) -> None:
+        """the elements [a, b) of the flat gradient buffer, for every (a, b) of `ranges`, are final once the work enqueued
+        so far on `streams` (default: the current stream) has run"""
+        if not self.overlap or not ranges:
+            return
+        if self._cuda and torch.cuda.is_current_stream_capturing():
+            return
         from . import ops
 
-        r = self._weight_range(prefixes)
-        if r is None:
-            return
+        for r in ranges:
+            if self._overlaps(r, self._done) or self._overlaps(r, self._pending):
+                raise ValueError(f"gradient range {r} was reported ready twice in one step")
+            self._pending.append((int(r[0]), int(r[1])))
+        self._pending = self._merge(self._pending)
         for s in ((streams or [torch.cuda.current_stream(self.store.device)]) if self._cuda else ()):
             ev = torch.cuda.Event()
             ops.record_event(ev, s)
             self._pending_events.append(ev)
-        self._pending.append(r)
         if sum(b - a for a, b in self._pending) * 4 >= self.bucket_bytes:
-            self._flush()
+            self._flush(final=False)
 
     def finish(self) -> None:
         """reduces every range not yet handed over (the 1-D suffix included) and joins the collectives; call on the stream
@@ -171,12 +203,14 @@ class GradReducer:
             ev = torch.cuda.Event()
             ops.record_event(ev, torch.cuda.current_stream(self.store.device))
             self._pending_events.append(ev)
-        covered = self._merge(self._done + self._pending)
+        covered = self._merge(self._done)
         pos, total = 0, self.flat.numel()
+        rest = []
         for a, b in covered + [(total, total)]:
             if a > pos:
-                self._pending.append((pos, a))
+                rest.append((pos, a))
             pos = max(pos, b)
-        self._flush()
-        self._done = []
+        self._pending = rest              # everything not reduced yet, pending fragments included, in as few calls as possible
+        self._flush(final=True)
+        self._done, self._pending, self._pending_events = [], [], []
         ops.host_call(self._wait_all)

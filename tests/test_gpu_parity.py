@@ -401,7 +401,18 @@ def test_bf16x3_gradients_at_batch_64():
     tensor (2x tighter than the B = 6 bar above, where single examples dominate) and strict f32 < 2.5e-3.  (No fixed
     ratio between the two holds per tensor: encoder_net/conv_1/w measured 1.3e-3 vs 8e-5, decoder_net/conv_t_0/w 1.5e-3 in
     BOTH modes.)"""
-    cfg, xs, x, b, eps = _inputs("mnist", 64, 5)
+    _gradients_at_batch(64)
+
+
+def test_gradients_at_the_benchmarked_batch_256():
+    """The same comparison at BASELINE's batch (the configuration bench.py times): every kernel the headline step
+    dispatches to at B = 256 (image-resident convolutions, image / patch weight gradients, skinny GEMMs, the fused
+    ResidualMLP chain) produces the gradient tensors checked here, all of them against the float64 oracle."""
+    _gradients_at_batch(256)
+
+
+def _gradients_at_batch(B):
+    cfg, xs, x, b, eps = _inputs("mnist", B, 5)
     m = _product_model(cfg, xs)
     p64 = {n: t.cpu().double() for n, t in m.params_dict().items()}
     leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
@@ -415,7 +426,7 @@ def test_bf16x3_gradients_at_batch_64():
         got = m(x.float().to(d), b.float().to(d), True, eps=eps.float().to(d))
         for key in ("reconstruction_ll", "kl", "matching_ll"):
             assert rel_err(got[key], out[key]) < (1e-4 if use else 1e-5), (use, key)
-        g = [torch.full((64,), v, device=d) for v in (-1.0 / 64, 1.0 / 64, -1.0 / 64)]
+        g = [torch.full((B,), v, device=d) for v in (-1.0 / B, 1.0 / B, -1.0 / B)]
         m.zero_grad()
         m.backward(*g)
         torch.cuda.synchronize()
@@ -629,6 +640,15 @@ MASKED_CASES = [
     (2, 7, 128, 128, (3, 3), 2, 1),    # horizontal_stack_left
     (5, 16, 64, 32, (3, 3), 2, 2),     # CelebA-sized grid
     (2, 7, 24, 40, (3, 3), 2, 2),      # C not a multiple of 32: f32 gather loaders
+    # the shapes and batches bench / tools run (pm_vqvae_mnist at B = 256): from B = 128 on these dispatch to the
+    # image-resident kernels (image_conv_bf16 with kws > KW) instead of direct_gemm_bf16
+    (256, 7, 256, 256, (3, 3), 2, 2),  # horizontal stack conv2
+    (128, 7, 256, 256, (3, 3), 2, 2),
+    (256, 7, 256, 128, (3, 3), 2, 3),  # vertical stack conv1 / horizontal conv1 (2F -> F)
+    (128, 7, 128, 128, (5, 3), 2, 3),  # vertical_stack_init
+    (256, 7, 128, 128, (3, 3), 1, 3),  # horizontal_stack_up
+    (256, 7, 128, 128, (3, 3), 2, 1),  # horizontal_stack_left
+    (16, 16, 256, 256, (3, 3), 2, 2),  # pm_vqvae_celeb_a at its per-GPU batch
 ]
 
 
@@ -682,6 +702,20 @@ def test_masked_conv_fwd_dgrad_wgrad(B, H, ci, co, full, vr, vc, bf16x3):
     assert torch.equal(dwd.cpu()[vr:], torch.zeros_like(dwd.cpu()[vr:]))
     assert torch.equal(dwd.cpu()[:, vc:], torch.zeros_like(dwd.cpu()[:, vc:]))
     assert rel_err(dbd, br.grad) < 1e-5
+    if bf16x3 and ws_f is not None:
+        # the grouped form the train steps use (ops.WgradBatch -> pm_gather_wgrad_table): two layers of this geometry in one
+        # launch, the second with its operands swapped in sign so that the groups cannot be confused
+        from posterior_matching_amd.ops import WgradBatch
+
+        batch = WgradBatch()
+        buf_x, buf_dy = torch.stack([xd, -xd]).contiguous(), torch.stack([dyd, 0.5 * dyd]).contiguous()
+        dw2, db2 = torch.zeros((2,) + geom.weight_shape, device=d), torch.zeros((2, co), device=d)
+        for i in range(2):
+            batch.add(geom, buf_x[i], buf_dy[i], dw2[i], db2[i], True)
+        batch.flush()
+        assert rel_err(dw2[0], wr.grad) < tol and rel_err(dw2[1], -0.5 * wr.grad) < tol
+        assert rel_err(db2[0], br.grad) < 1e-5 and rel_err(db2[1], 0.5 * br.grad) < 1e-5
+        assert torch.equal(dw2.cpu()[:, vr:], torch.zeros_like(dw2.cpu()[:, vr:]))
 
 
 def test_diagonal_gaussian_heads_and_model():

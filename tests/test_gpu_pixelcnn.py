@@ -82,6 +82,20 @@ def test_concat_elu_gate_rows_sum_elu():
     assert rel_err(de, a3.grad) < 1e-6
 
 
+@pytest.mark.parametrize("B,N,P", [(256, 256, 49), (16, 512, 256), (128, 128, 7), (3, 64, 5), (16, 256, 256), (130, 132, 3)])
+def test_rows_sum_forms(B, N, P):
+    """pm_rows_sum at the shapes the benchmarked steps run: (256, 256, 49) = pm_vqvae_mnist at B = 256 and (16, 512, 256)
+    (the one-workgroup-per-example rows_sum_v4 form, taken when N >= 128 and B * ceil(N / 256) >= 128), (16, 256, 256) =
+    pm_vqvae_celeb_a at its per-GPU batch (the 32-column form), and ragged sizes on both sides of the switch; vs float64."""
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(B + N + P)
+    x = torch.randn((B, P, N), generator=gen, dtype=F64)
+    out = torch.full((B, N), 7.0, device=dev())
+    ops.rows_sum(f32d(x).view(B * P, N), out, P)
+    assert rel_err(out, x.sum(1)) < 2e-6
+
+
 def test_embed_categorical_and_dropout_mask():
     from posterior_matching_amd import ops
 
@@ -410,6 +424,63 @@ def test_stage2_reference_config_small_batch():
     gd = ts.store.to_dict("g")
     for n in names:
         assert rel_err(gd[n], grads[n]) < 2e-4, (n, rel_err(gd[n], grads[n]))
+
+
+def _stage2_fwd_bwd_as_the_train_step(ts, x, b, masks):
+    ts.dropout_masks = [f32d(m) for m in masks]
+    ts.set_batch(f32d(x), f32d(b))
+    with torch.cuda.stream(ts.stream):
+        ts._forward_backward()          # grouped weight gradients (ops.WgradBatch), two chains: what ts.step() runs
+    ts.synchronize()
+    return ts.read_metrics()["loss"], {n: t.clone() for n, t in ts.store.to_dict("g").items()}
+
+
+STAGE2_SAMPLED = ["pixel_cnn/embed/embeddings", "pixel_cnn/down_3/horizontal/conv2/w", "pixel_cnn/up_7/horizontal/linear/w",
+                  "pixel_cnn/up_0/vertical/cond/w", "pixel_cnn/down_0/vertical/conv1/w", "pixel_cnn/up_5/vertical/conv2/w",
+                  "pixel_cnn/down_6/horizontal/conv1/w", "pixel_cnn/v_init/w", "pixel_cnn/h_up/w", "pixel_cnn/h_left/w",
+                  "partial_encoder/linear/w", "partial_encoder/encoder/enc_1/w", "pixel_cnn/out_conv/w", "pixel_cnn/out_conv/b",
+                  "pixel_cnn/down_2/horizontal/conv2/b"]
+
+
+def test_stage2_reference_config_at_batch_128_matches_oracle():
+    """configs/pm_vqvae_mnist.py (35.0 M trainable) in TRAINING mode with explicit dropout masks at B = 128 - the batch from
+    which the masked sub-kernels run on image_conv_bf16 and the conditional row sums on rows_sum_v4, i.e. the kernels of
+    the B = 256 benchmark - through the train step's own forward / backward (grouped weight gradients, two chains), default
+    arithmetic: code indices exact, loss 1e-4, sampled gradient tensors 1e-2 against the float64 oracle (the bars of
+    test_stage2_loss_and_grads[bf16x3])."""
+    cfg, vq_cfg = pm_vqvae_mnist(), vqvae_mnist()["model"]
+    B, xs = 128, (28, 28, 1)
+    ts, p64, vq64, st64 = _stage2(cfg, vq_cfg, xs, B, seed=6, bf16x3=True)
+    rng = np.random.default_rng(12)
+    x, b = _batch(rng, B, xs)
+    masks = _masks(rng, cfg, B)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
+    loss, idx, lp = PO.pm_vqvae_loss(leaves, vq64, st64, cfg, vq_cfg, x, b, True, masks)
+    grads = dict(zip(STAGE2_SAMPLED, torch.autograd.grad(loss, [leaves[n] for n in STAGE2_SAMPLED])))
+    got_loss, gd = _stage2_fwd_bwd_as_the_train_step(ts, x, b, masks)
+    assert torch.equal(ts._idx.cpu().long(), idx)
+    assert abs(got_loss - loss.item()) < 1e-4 * abs(loss.item()), (got_loss, loss.item())
+    for n in STAGE2_SAMPLED:
+        e = rel_err(gd[n], grads[n])
+        assert e < 1e-2, (n, e)
+
+
+def test_stage2_reference_config_at_batch_256_default_vs_strict():
+    """B = 256 (BASELINE's batch for pm_vqvae_mnist; the float64 CPU pass would need ~30 GB): the default arithmetic on
+    the train step's path against the strict-f32 path (f32 MFMA kernels, per-layer weight gradients - a disjoint set of
+    kernels, itself checked against the oracle at B <= 128): loss 1e-4, EVERY gradient tensor 1e-2."""
+    cfg, vq_cfg = pm_vqvae_mnist(), vqvae_mnist()["model"]
+    B, xs = 256, (28, 28, 1)
+    ts, p64, vq64, st64 = _stage2(cfg, vq_cfg, xs, B, seed=6, bf16x3=True)
+    rng = np.random.default_rng(13)
+    x, b = _batch(rng, B, xs)
+    masks = _masks(rng, cfg, B)
+    loss_fast, g_fast = _stage2_fwd_bwd_as_the_train_step(ts, x, b, masks)
+    ts.store.use_bf16 = False
+    loss_strict, g_strict = _stage2_fwd_bwd_as_the_train_step(ts, x, b, masks)
+    assert abs(loss_fast - loss_strict) < 1e-4 * abs(loss_strict), (loss_fast, loss_strict)
+    worst = max((rel_err(g_fast[n], g_strict[n]), n) for n in g_fast)
+    assert worst[0] < 1e-2, worst
 
 
 def test_sampling_imputation_and_psnr_match_oracle():

@@ -339,6 +339,25 @@ for overlap in (True, False):
     except ValueError:
         assert overlap
     red.finish()
+# fragments (ops.WgradBatch reports one layer shape of many Blocks at a time): pieces below min_issue_bytes wait for their
+# neighbours; a range reported twice is refused; finish() reduces the rest in ONE call
+st = FakeStore()
+red = GradReducer(st, bucket_bytes=4 * 900, overlap=True)
+for step in range(2):
+    st.flat_g.copy_(both[rank])
+    red.ready_ranges([(0, 100), (600, 700)])
+    red.ready_ranges([(1100, 1300), (1800, 1900)])
+    assert red._calls == 0
+    red.ready_ranges([(100, 600), (700, 1100)])           # 1400 pending: (0, 1300) goes, the 100-element piece stays
+    assert red._calls == 1 and red._pending == [(1800, 1900)], (red._calls, red._pending)
+    try:
+        red.ready_ranges([(50, 60)])
+        raise SystemExit("a range was accepted twice")
+    except ValueError:
+        pass
+    red.finish()
+    assert torch.allclose(st.flat_g, both[0] + both[1], rtol=0, atol=0), step
+    assert red.calls_last_step == 2 and red.calls_before_finish_last_step == 1, (red.calls_last_step, red.calls_before_finish_last_step)
 dist.barrier()
 if rank == 0:
     print("DP-OK")
