@@ -318,8 +318,9 @@ class PMVQVAETrainStep(_PlannedStep):
             pixel_cnn.build(store, "pixel_cnn", cond_dim)
             store.allocate(dev, seed)
         self.store, self.ws = pixel_cnn.store, pixel_cnn.ws
-        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
-        self.reducer = _make_reducer(self.store, world_size, overlap_allreduce)
+        # optimizer None: forward / evaluation only (trainer.PMVQVAELoss called as a function)
+        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size) if optimizer is not None else None
+        self.reducer = _make_reducer(self.store, world_size, overlap_allreduce) if optimizer is not None else None
         x_shape = tuple(x_shape)
         self.x = torch.zeros((batch_size,) + x_shape, device=dev)
         self.b = torch.zeros((batch_size,) + x_shape[:-1] + (1,), device=dev)
@@ -380,6 +381,8 @@ class PMVQVAETrainStep(_PlannedStep):
 
     def _update(self) -> None:
         s = self.store
+        if self.adam_cfg is None:
+            raise RuntimeError("this PMVQVAETrainStep was built without an optimizer (evaluation only)")
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)

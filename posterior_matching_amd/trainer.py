@@ -24,37 +24,123 @@ from .parallel import allreduce_mean_scalars, init_distributed
 from .utils import Callback
 
 
-class PMVAELoss:
-    """loss_fn(step, is_training, batch) of train_pm_vae.py:58-72 as an object, so that the
-    trainer can lower it to the fused step instead of tracing Python."""
+def _step_counter(step, device) -> torch.Tensor:
+    return torch.tensor([int(step)], dtype=torch.int32, device=device)
 
-    def __init__(self, config: Mapping[str, Any], model: PosteriorMatchingVAE, data_key: str = "image"):
-        self.config, self.model, self.data_key = config, model, data_key
+
+def _scalars(metrics: torch.Tensor, names) -> Dict[str, torch.Tensor]:
+    return {n: metrics[i] for i, n in enumerate(names)}
+
+
+class PMVAELoss:
+    """loss_fn(step, is_training, batch) of train_pm_vae.py:58-72.  Handed to Trainer it is lowered to the fused train
+    step (engine.PMVAETrainStep) instead of being traced; CALLED, it evaluates the same function through the same
+    kernels - forward + loss only - and returns (loss, aux) like the reference: 0-dim device tensors, aux = the batch means
+    of reconstruction_ll / kl / matching_ll and beta(step).  The posterior noise (hk.next_rng_key in the reference) is a
+    device Philox draw keyed by (`seed`, step) unless `eps` is given."""
+
+    def __init__(self, config: Mapping[str, Any], model: PosteriorMatchingVAE, data_key: str = "image", seed: int = 0):
+        self.config, self.model, self.data_key, self.seed = config, model, data_key, seed
+
+    def __call__(self, step, is_training, batch, eps: Optional[torch.Tensor] = None):
+        from .engine import loss_cfg_from_config
+        from .models.networks import ResidualMLP
+
+        m = self.model
+        x = batch[self.data_key]
+        if m.store is None:
+            m.init(tuple(x.shape[1:]), seed=self.seed)
+        dev = m.store.device
+        x, b = x.to(dev).float().contiguous(), batch["mask"].to(dev).float().contiguous()
+        B = x.shape[0]
+        step_dev = _step_counter(step, dev)
+        if eps is None:
+            eps = torch.empty((B, m.latent_dim), device=dev)
+            ops.normal_fill(eps, self.seed, step_dev, stream_id=0)
+        for i, net in enumerate((m.encoder_net, m.decoder_net, m.partial_encoder_net)):
+            if isinstance(net, ResidualMLP) and getattr(net, "dropout_step_dev", None) is None:
+                net.dropout_seed, net.dropout_step_dev, net.dropout_stream_base = self.seed, step_dev, 2000 + 64 * i
+        out = m(x, b, is_training=bool(is_training), eps=eps)
+        metrics = torch.zeros(8, device=dev)
+        ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], loss_cfg_from_config(self.config, B), step_dev,
+                       metrics, None, None, None)
+        aux = _scalars(metrics, ("loss", "reconstruction_ll", "kl", "matching_ll", "beta"))
+        return aux.pop("loss"), aux
 
 
 class VQVAELoss:
-    """loss_fn(step, is_training, batch) of train_vqvae.py:67-75 as an object: returns out["loss"] with
-    aux perplexity / reconstruction_loss / vq_loss."""
+    """loss_fn(step, is_training, batch) of train_vqvae.py:67-75: returns (out["loss"], aux) with aux perplexity /
+    reconstruction_loss / vq_loss.  Lowered to engine.VQVAETrainStep by Trainer; callable for validation / inspection
+    (is_training=True updates the EMA codebook state, as the haiku module does in the reference)."""
 
-    def __init__(self, config: Mapping[str, Any], model: VQVAE, data_key: str = "image"):
-        self.config, self.model, self.data_key = config, model, data_key
+    def __init__(self, config: Mapping[str, Any], model: VQVAE, data_key: str = "image", seed: int = 0):
+        self.config, self.model, self.data_key, self.seed = config, model, data_key, seed
+
+    def __call__(self, step, is_training, batch):
+        m = self.model
+        x = batch[self.data_key]
+        if m.store is None:
+            m.init(tuple(x.shape[1:]), seed=self.seed)
+        m(x.to(m.store.device).float().contiguous(), is_training=bool(is_training))
+        aux = _scalars(m.metrics.clone(), ("loss", "reconstruction_loss", "vq_loss", "perplexity"))
+        return aux.pop("loss"), aux
 
 
 class PMVQVAELoss:
-    """loss_fn of train_pm_vqvae.py:81-99 as an object: frozen VQ-VAE -> code indices, partial encoder ->
-    conditional vector, loss = -mean PixelCNN.log_prob.  `vqvae` must carry the stage-1 parameters and
-    state; `partial_encoder` / `pixel_cnn` come from models.vqvae.build_partial_posterior."""
+    """loss_fn of train_pm_vqvae.py:81-99: frozen VQ-VAE -> code indices, partial encoder -> conditional vector,
+    loss = -mean PixelCNN.log_prob, aux = {}.  `vqvae` must carry the stage-1 parameters and state; `partial_encoder` /
+    `pixel_cnn` come from models.vqvae.build_partial_posterior.  Lowered to engine.PMVQVAETrainStep by Trainer; callable
+    (forward + loss through the same kernels; is_training=True draws the PixelCNN's dropout masks from (seed, step))."""
 
-    def __init__(self, config: Mapping[str, Any], vqvae: VQVAE, partial_encoder, pixel_cnn, data_key: str = "image"):
-        self.config, self.model, self.data_key = config, vqvae, data_key
+    def __init__(self, config: Mapping[str, Any], vqvae: VQVAE, partial_encoder, pixel_cnn, data_key: str = "image",
+                 seed: int = 0):
+        self.config, self.model, self.data_key, self.seed = config, vqvae, data_key, seed
         self.partial_encoder, self.pixel_cnn = partial_encoder, pixel_cnn
+        self._eval = {}
+
+    def __call__(self, step, is_training, batch):
+        x = batch[self.data_key]
+        B, xs = x.shape[0], tuple(x.shape[1:])
+        ev = self._eval.get((B, xs))
+        if ev is None:
+            ev = PMVQVAETrainStep(self.model, self.partial_encoder, self.pixel_cnn, None, B, xs, seed=self.seed)
+            self._eval[(B, xs)] = ev
+        dev = ev.x.device
+        ev.set_batch(x.to(dev).float(), batch["mask"].to(dev).float())
+        with torch.cuda.stream(ev.stream):
+            ev.step_dev.fill_(int(step))
+            ev.forward(bool(is_training))
+        ev.synchronize()
+        return ev.metrics[0].clone(), {}
 
 
 class VDVAELoss:
-    """loss_fn of train_pm_vdvae.py:109-120 as an object: loss = -mean(rec_ll - kl) + mean(pm_kl), aux = the means and bpd."""
+    """loss_fn of train_pm_vdvae.py:109-120: loss = -mean(rec_ll - kl) + mean(pm_kl), aux = the batch means of
+    reconstruction_ll / kl / pm_kl and bpd.  Lowered to engine.VDVAETrainStep by Trainer; callable (the model has no
+    train / eval difference: `is_training` is accepted and ignored, as in the reference; posterior noise = device Philox
+    keyed by (`seed`, step) unless `eps` is given)."""
 
-    def __init__(self, config: Mapping[str, Any], model, data_key: str = "image"):
-        self.config, self.model, self.data_key = config, model, data_key
+    def __init__(self, config: Mapping[str, Any], model, data_key: str = "image", seed: int = 0):
+        self.config, self.model, self.data_key, self.seed = config, model, data_key, seed
+
+    def __call__(self, step, is_training, batch, eps=None):
+        m = self.model
+        if m.store is None:
+            m.init(seed=self.seed)
+        dev = m.store.device
+        x, b = batch[self.data_key].to(dev).float().contiguous(), batch["mask"].to(dev).float().contiguous()
+        if eps is None:
+            shapes = m.eps_shapes(x.shape[0])
+            flat = torch.empty(sum(int(torch.Size(sh).numel()) for sh in shapes), device=dev)
+            ops.normal_fill(flat, self.seed, _step_counter(step, dev), stream_id=0)
+            eps, off = [], 0
+            for sh in shapes:
+                n = int(torch.Size(sh).numel())
+                eps.append(flat[off:off + n].view(sh))
+                off += n
+        m(x, b, eps)
+        aux = _scalars(m.metrics.clone(), ("loss", "reconstruction_ll", "kl", "pm_kl", "bpd"))
+        return aux.pop("loss"), aux
 
 
 @dataclass
@@ -89,7 +175,7 @@ class LearningRateLoggerCallback(Callback):
 class Trainer:
     def __init__(self, loss_fn: PMVAELoss, optimizer: Chain, num_devices: int = 1, seed: int = 0,
                  trainable_predicate=None, skip_nonfinite_updates: bool = False, ema_rate: Optional[float] = None,
-                 use_ema_for_eval: bool = False, use_graph: bool = True):
+                 use_ema_for_eval: bool = False, use_graph: bool = False):
         if isinstance(loss_fn, PMVQVAELoss):
             # train_pm_vqvae.py:122-123: the only predicate the reference uses freezes every module under "vqvae/";
             # that is exactly what PMVQVAETrainStep does (the VQ-VAE lives on its own, never-updated store)

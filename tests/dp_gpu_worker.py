@@ -130,6 +130,128 @@ if rank == 0:
     report["vdvae"] = compare("vdvae", dp_p, one_p, 3e-4)
     report["vdvae_ema"] = compare("vdvae_ema", dp_e, one_e, 3e-4)
 
+# ---- the default arithmetic (bf16x3) and the launch forms the Trainer uses ------------------------------------------
+# Gradients: after the FIRST step the flat gradient buffer holds the all-reduced sum of the per-rank mean gradients, i.e.
+# world x the full-batch gradient; later steps compare losses (Adam's first updates are sign-like, parameters of two
+# float32 runs drift apart on entries whose gradient is rounding noise).
+def grad_and_losses(ts, feed, steps=3):
+    losses, g1 = [], None
+    for s in range(steps):
+        feed(s)
+        ts.step()
+        losses.append(ts.read_metrics()["loss"])
+        if s == 0:
+            ts.synchronize()
+            g1 = ts_store(ts).flat_g.clone()
+    ts.synchronize()
+    return g1, losses
+
+
+def ts_store(ts):
+    return ts.store if hasattr(ts, "store") else ts.model.store
+
+
+def check_dp(tag, run, G, gtol=1e-3, ltol=2e-4, min_early=0):
+    rows = shard_rows(G, rank, world)
+    ts, (g_dp, l_dp) = run(world, rank, rows)
+    calls, early = ts.reducer.calls_last_step, ts.reducer.calls_before_finish_last_step
+    assert calls >= 1 and early >= min_early, (tag, calls, early)
+    lt = torch.tensor(l_dp, dtype=torch.float64)
+    dist.all_reduce(lt)                                  # mean over ranks of the per-rank mean losses
+    if rank == 0:
+        _, (g_one, l_one) = run(1, 0, slice(0, G))
+        e = rel(g_dp / world, g_one)
+        assert e < gtol, (tag, "gradient", e)
+        for a, b in zip((lt / world).tolist(), l_one):
+            assert abs(a - b) <= ltol * abs(b), (tag, "loss", a, b)
+        report[tag] = {"grad_rel_err": e, "allreduce_calls": calls, "issued_before_finish": early}
+
+
+# conv PM-VAE (configs/pm_vae_mnist.py, the headline workload), global batch 64; eager / launch plan and HIP graph
+from tests.ref_configs import pm_vae_mnist, pm_vqvae_mnist  # noqa: E402
+
+mcfg, G = pm_vae_mnist(), 64
+mx = torch.tensor(rng.uniform(size=(3, G, 28, 28, 1)) * (rng.uniform(size=(3, G, 28, 28, 1)) < 0.3), dtype=torch.float32, device=dev)
+mb = torch.tensor(rng.uniform(size=(3, G, 28, 28, 1)) < 0.5, dtype=torch.float32, device=dev)
+me = torch.tensor(rng.normal(size=(3, G, 32)), dtype=torch.float32, device=dev)
+
+
+def conv_pmvae(use_graph):
+    def run(world_size, r, rows):
+        m = PosteriorMatchingVAE.from_config(mcfg["model"], device=dev, seed=3)
+        m.init((28, 28, 1))
+        opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(0.0),
+                          optim.scale_by_schedule(optim.exponential_decay(**mcfg["lr_schedule"])), optim.scale(-1.0))
+        ts = PMVAETrainStep(m, mcfg, opt, rows.stop - rows.start, (28, 28, 1), world_size=world_size, rank=r,
+                            external_eps=True, use_graph=use_graph)
+        return ts, grad_and_losses(ts, lambda s: ts.set_batch(mx[s, rows], mb[s, rows], me[s, rows]))
+    return run
+
+
+check_dp("pm_vae_mnist_bf16x3", conv_pmvae(False), G)
+check_dp("pm_vae_mnist_bf16x3_hip_graph", conv_pmvae(True), G)      # the Trainer's default launch form: reduce between the graphs
+
+# PM-VQVAE stage 2 (grouped weight gradients; the up pass's buckets leave while the down pass still runs)
+from posterior_matching_amd.engine import PMVQVAETrainStep  # noqa: E402
+from posterior_matching_amd.models.pixel_cnn import PixelCNN  # noqa: E402
+from posterior_matching_amd.models.vqvae import VQVAEPartialEncoder  # noqa: E402
+
+S2_VQ = {"embedding_dim": 32, "num_embeddings": 24, "hidden_units": 32, "residual_hidden_units": 32,
+         "residual_blocks": 1, "decay": 0.99, "use_ema": True, "commitment_cost": 0.25, "output_channels": 1}
+S2 = {"pixel_cnn": {"image_shape": (3, 3), "num_resnet": 2, "num_hierarchies": 1, "num_filters": 32, "dropout": 0.5},
+      "conditional_dim": 64, "lr_schedule": {"init_value": 3e-4, "decay_rate": 0.999995, "transition_steps": 1}}
+G = 16
+sx = torch.tensor(rng.uniform(size=(3, G, 12, 12, 1)) * (rng.uniform(size=(3, G, 12, 12, 1)) < 0.3), dtype=torch.float32, device=dev)
+sb = torch.tensor(rng.uniform(size=(3, G, 12, 12, 1)) < 0.5, dtype=torch.float32, device=dev)
+smask = [[torch.tensor((rng.uniform(size=(G, 3, 3, 64)) > 0.5) * 2.0, dtype=torch.float32, device=dev) for _ in range(8)]
+         for _ in range(3)]
+
+
+def stage2(world_size, r, rows):
+    vq = VQVAE(**S2_VQ, device=dev, seed=4)
+    vq.init((12, 12, 1))
+    vq.store.use_bf16 = False
+    penc, pcnn = VQVAEPartialEncoder(S2["conditional_dim"], S2_VQ), PixelCNN(**dict(S2["pixel_cnn"], num_indices=24))
+    opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(0.0),
+                      optim.scale_by_schedule(optim.exponential_decay(**S2["lr_schedule"])), optim.scale(-1.0))
+    os.environ["PM_BUCKET_MB"] = "0.05"                  # this toy has 0.3 MB of gradients: buckets small enough to leave early
+    ts = PMVQVAETrainStep(vq, penc, pcnn, opt, rows.stop - rows.start, (12, 12, 1), seed=4, world_size=world_size, rank=r,
+                          external_dropout=True)
+    os.environ.pop("PM_BUCKET_MB")
+
+    def feed(s):
+        ts.dropout_masks = [t[rows].contiguous() for t in smask[s]]
+        ts.set_batch(sx[s, rows], sb[s, rows])
+    return ts, grad_and_losses(ts, feed)
+
+
+check_dp("pm_vqvae_stage2_bf16x3", stage2, G, min_early=1)
+
+# VDVAE with fused Blocks and grouped weight gradients flushed per resolution on the side stream (default arithmetic)
+SMALL16 = dict(TINY["model"], latent_dim=16, width=64)
+G = 8
+vx = torch.tensor(np.round(rng.uniform(size=(3, G, 7, 7, 1)) * 255.0), dtype=torch.float32, device=dev)
+vb = torch.tensor(rng.uniform(size=(3, G, 7, 7, 1)) < 0.5, dtype=torch.float32, device=dev)
+
+
+def vdvae_fused(world_size, r, rows):
+    m = PosteriorMatchingVDVAE(**SMALL16, device=dev, seed=6)
+    m.init()
+    gen = torch.Generator().manual_seed(1)
+    m.load_params({n: t.cpu() + 0.05 * torch.randn(t.shape, generator=gen) for n, t in m.params_dict().items()})
+    assert any(b[0]._fused() is not None for b in m.encoder.blocks)
+    os.environ["PM_BUCKET_MB"] = "0.25"
+    ts = VDVAETrainStep(m, TINY["lr"], rows.stop - rows.start, gradient_clip=200.0, ema_rate=0.999, world_size=world_size,
+                        rank=r, external_eps=True)
+    os.environ.pop("PM_BUCKET_MB")
+    g2 = np.random.default_rng(9)
+    eps = [[torch.tensor(g2.normal(size=(G,) + sh[1:]), dtype=torch.float32, device=dev) for sh in m.eps_shapes(G)]
+           for _ in range(3)]
+    return ts, grad_and_losses(ts, lambda s: ts.set_batch(vx[s, rows], vb[s, rows], [e[rows] for e in eps[s]]))
+
+
+check_dp("pm_vdvae_fused_bf16x3", vdvae_fused, G, min_early=1)
+
 dist.barrier()
 if rank == 0:
     print("DP-GPU-OK", report)

@@ -137,26 +137,11 @@ def test_checkpoint_importer_renames_haiku_trees():
 
     rng = np.random.default_rng(0)
 
+    from tests.haiku_names import to_tree, vae_names, vdvae_names, vq_names
+
     def fake(shapes, to_haiku):
         native = {n: rng.normal(size=s).astype(np.float32) for n, s in shapes.items()}
-        tree = {}
-        for n, v in native.items():
-            mod, leaf = to_haiku(n).rsplit("/", 1)
-            tree.setdefault(mod, {})[leaf] = v
-        return native, tree
-
-    def vae_names(n):
-        m = re.match(r"(.*)/conv_t_(\d+)/(w|b)$", n)
-        if m:
-            return f"{m.group(1)}/conv2_d_transpose{'' if m.group(2) == '0' else '_' + m.group(2)}/{m.group(3)}"
-        m = re.match(r"(.*)/conv_(\d+)/(w|b)$", n)
-        if m:
-            return f"{m.group(1)}/conv2_d{'' if m.group(2) == '0' else '_' + m.group(2)}/{m.group(3)}"
-        n = n.replace("/mlp/", "/residual_mlp/").replace("/gmm/", "/one_dimensional_gmm/")
-        m = re.match(r"(.*)/block_(\d+)/linear_(\d)/(w|b)$", n)
-        if m:
-            return f"{m.group(1)}/linear_{1 + 2 * int(m.group(2)) + int(m.group(3))}/{m.group(4)}"
-        return re.sub(r"/linear_0/(w|b)$", r"/linear/\1", n)
+        return native, to_tree(native, to_haiku)
 
     for cfg, xs in ((pm_vae_mnist(), (28, 28, 1)), (pm_vae_gas(), (8,))):
         shapes = O.param_shapes(cfg["model"], xs)
@@ -165,19 +150,13 @@ def test_checkpoint_importer_renames_haiku_trees():
         got = haiku_to_native(tree, shapes)
         assert list(got) == list(shapes) and all(np.array_equal(got[n], native[n]) for n in shapes)
 
-    def vq_names(n):
-        n = re.sub(r"^(encoder|decoder)/(res\dx\d_\d+)/", lambda m: f"conv_residual_{m.group(1)}/conv_residual_stack/{m.group(2)}/", n)
-        n = re.sub(r"^(encoder|decoder)/", lambda m: f"conv_residual_{m.group(1)}/", n)
-        return "vqvae/~/" + n if n.count("/") else "vqvae/" + n
-
     shapes = VO.param_shapes(vqvae_mnist()["model"], 1)
     native, tree = fake(shapes, vq_names)
     got = haiku_to_native(tree, shapes)
     assert all(np.array_equal(got[n], native[n]) for n in shapes)
 
     shapes = DO.param_shapes(pm_vdvae_mnist()["model"])
-    native, tree = fake(shapes, lambda n: re.sub(r"x_bias_(\d+)$", r"x_bias_\1]", "posterior_matching_vdvae/" + n)
-                        if "x_bias" in n else "posterior_matching_vdvae/" + n)
+    native, tree = fake(shapes, vdvae_names)
     got = haiku_to_native(tree, shapes)
     assert len(got) == len(shapes) and np.array_equal(got["decoder/x_bias_28"], native["decoder/x_bias_28"])
 
