@@ -437,7 +437,7 @@ def _stage2_fwd_bwd_as_the_train_step(ts, x, b, masks):
 
 STAGE2_SAMPLED = ["pixel_cnn/embed/embeddings", "pixel_cnn/down_3/horizontal/conv2/w", "pixel_cnn/up_7/horizontal/linear/w",
                   "pixel_cnn/up_0/vertical/cond/w", "pixel_cnn/down_0/vertical/conv1/w", "pixel_cnn/up_5/vertical/conv2/w",
-                  "pixel_cnn/down_6/horizontal/conv1/w", "pixel_cnn/v_init/w", "pixel_cnn/h_up/w", "pixel_cnn/h_left/w",
+                  "pixel_cnn/down_6/horizontal/conv1/w", "pixel_cnn/vertical_init/w", "pixel_cnn/horizontal_up/w", "pixel_cnn/horizontal_left/w",
                   "partial_encoder/linear/w", "partial_encoder/encoder/enc_1/w", "pixel_cnn/out_conv/w", "pixel_cnn/out_conv/b",
                   "pixel_cnn/down_2/horizontal/conv2/b"]
 
