@@ -54,7 +54,7 @@ class AdamCfg(C.Structure):
         ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
         ("lr_init", C.c_float), ("lr_decay_rate", C.c_float), ("lr_transition_steps", C.c_float),
         ("grad_scale", C.c_float),
-        ("lr_kind", C.c_int), ("lr_end", C.c_float),
+        ("lr_kind", C.c_int), ("lr_end", C.c_float), ("zero_grad", C.c_int),
     ]
 
 

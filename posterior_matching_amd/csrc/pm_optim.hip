@@ -40,13 +40,16 @@ __global__ __launch_bounds__(256) void pmvae_loss_kernel(const float* __restrict
     const float beta = beta_from_step(cfg, step);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
-        s0 += rec[b];
-        s1 += kl[b];
-        s2 += mll[b];
+        if (rec) {
+            s0 += rec[b];
+            s1 += kl[b];
+            s2 += mll[b];
+        }
         if (g_rec) g_rec[b] = -cfg.grad_scale;
         if (g_kl) g_kl[b] = beta * cfg.grad_scale;
         if (g_mll) g_mll[b] = -cfg.matching_coef * cfg.grad_scale;
     }
+    if (!rec) return;                    // gradients-only call (see pm_pmvae_loss)
     s0 = pm_wave_sum(s0);
     s1 = pm_wave_sum(s1);
     s2 = pm_wave_sum(s2);
@@ -77,27 +80,115 @@ __device__ __forceinline__ float pm_lr(const pm_adam_cfg& c, int count) {
     return c.lr_init * powf(c.lr_decay_rate, (float)count / c.lr_transition_steps);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                     float* __restrict__ m, float* __restrict__ v, long long n,
+// One Adam element: the arithmetic of optax.scale_by_adam -> add_decayed_weights -> scale_by_schedule -> scale(-1), in
+// the order the scalar kernels of rounds 1-2 used (results are bit-identical to them).  gi arrives scaled.
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, bool decay, const pm_adam_cfg& c,
+                                         float bc1, float bc2, float lr) {
+    mi = c.b1 * mi + (1.f - c.b1) * gi;
+    vi = c.b2 * vi + (1.f - c.b2) * gi * gi;
+    float u = (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
+    if (decay) u += c.weight_decay * pi;
+    pi = pi - lr * u;
+}
+
+// HBM-bound: p, g, m, v read, p, m, v written (+ g zeroed with c.zero_grad, + ema read and written).  One 16-byte vector
+// per thread and tensor, two vectors of every tensor in flight per thread (8-10 loads outstanding), grid-stride over
+// 2 x 256 vectors per workgroup.  CLIP_EMA adds train_pm_vdvae.py:131-154: clip_by_global_norm (gnorm_sq = sum g^2 of the
+// already reduced gradient), Trainer(skip_nonfinite_updates=True, ema_rate); `count` is the optimizer's own update counter
+// (it does not advance on a skipped step).  VEC = false: element-wise form for buffers that are not 16-byte aligned.
+template <bool CLIP_EMA, bool VEC>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, float* __restrict__ ema, long long n,
                                                      long long n_decay, const int* __restrict__ count_dev,
-                                                     pm_adam_cfg c) {
+                                                     const float* __restrict__ gnorm_sq, pm_adam_cfg c, float clip,
+                                                     float ema_rate, int skip_nonfinite) {
+    const bool zero_g = c.zero_grad != 0;
+    float gscale = c.grad_scale;
+    bool skip = false;
+    float cs = 1.f;
+    if (CLIP_EMA) {
+        const float gn = sqrtf(gnorm_sq[0]) * c.grad_scale;
+        skip = skip_nonfinite && !isfinite(gn);                      // every thread sees the same value
+        cs = (clip > 0.f && !(gn < clip)) ? clip / gn : 1.f;         // optax: where(g_norm < max_norm, g, g/g_norm*max_norm)
+    }
+    if (skip && !zero_g) return;
     const int count = count_dev[0];
     const float t = (float)(count + 1);
     const float bc1 = 1.f - powf(c.b1, t);
     const float bc2 = 1.f - powf(c.b2, t);
     const float lr = pm_lr(c, count);
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        float gi = g[i] * c.grad_scale;
-        float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
-        float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        float u = (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
-        float pi = p[i];
-        if (i < n_decay) u += c.weight_decay * pi;
-        p[i] = pi - lr * u;
+    const long long nv = VEC ? (n >> 2) : 0;
+    if (VEC) {
+        f32x4* p4 = reinterpret_cast<f32x4*>(p);
+        f32x4* g4 = reinterpret_cast<f32x4*>(g);
+        f32x4* m4 = reinterpret_cast<f32x4*>(m);
+        f32x4* v4 = reinterpret_cast<f32x4*>(v);
+        f32x4* e4 = reinterpret_cast<f32x4*>(ema);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const long long stride = (long long)gridDim.x * 512;
+        for (long long i0 = (long long)blockIdx.x * 512 + threadIdx.x; i0 < nv; i0 += stride) {
+            const long long i1 = i0 + 256;
+            const bool two = i1 < nv;
+            const long long j1 = two ? i1 : i0;
+            if (skip) {                                              // a skipped step still hands back a zeroed gradient
+                g4[i0] = zero;
+                if (two) g4[i1] = zero;
+                continue;
+            }
+            f32x4 ga = g4[i0], gb = g4[j1], ma = m4[i0], mb = m4[j1], va = v4[i0], vb = v4[j1], pa = p4[i0], pb = p4[j1];
+            f32x4 ea = zero, eb = zero;
+            if (CLIP_EMA && ema) { ea = e4[i0]; eb = e4[j1]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float p0 = pa[e], m0 = ma[e], v0 = va[e], p1 = pb[e], m1 = mb[e], v1 = vb[e];
+                adam_one(p0, CLIP_EMA ? ga[e] * gscale * cs : ga[e] * gscale, m0, v0, 4 * i0 + e < n_decay, c, bc1, bc2, lr);
+                adam_one(p1, CLIP_EMA ? gb[e] * gscale * cs : gb[e] * gscale, m1, v1, 4 * j1 + e < n_decay, c, bc1, bc2, lr);
+                pa[e] = p0; ma[e] = m0; va[e] = v0; pb[e] = p1; mb[e] = m1; vb[e] = v1;
+                if (CLIP_EMA) {
+                    ea[e] = ema_rate * ea[e] + (1.f - ema_rate) * p0;
+                    eb[e] = ema_rate * eb[e] + (1.f - ema_rate) * p1;
+                }
+            }
+            m4[i0] = ma; v4[i0] = va; p4[i0] = pa;
+            if (CLIP_EMA && ema) e4[i0] = ea;
+            if (zero_g) g4[i0] = zero;
+            if (two) {
+                m4[i1] = mb; v4[i1] = vb; p4[i1] = pb;
+                if (CLIP_EMA && ema) e4[i1] = eb;
+                if (zero_g) g4[i1] = zero;
+            }
+        }
     }
+    // element-wise: the n % 4 tail of the vector form (last workgroup), or everything
+    const long long first = nv << 2;
+    const long long estride = VEC ? n : (long long)gridDim.x * 256;
+    long long i = first + (VEC ? (blockIdx.x == gridDim.x - 1 ? (long long)threadIdx.x : n) : (long long)blockIdx.x * 256 + threadIdx.x);
+    for (; i < n; i += estride) {
+        if (!skip) {
+            float pi = p[i], mi = m[i], vi = v[i];
+            adam_one(pi, CLIP_EMA ? g[i] * gscale * cs : g[i] * gscale, mi, vi, i < n_decay, c, bc1, bc2, lr);
+            p[i] = pi; m[i] = mi; v[i] = vi;
+            if (CLIP_EMA && ema) ema[i] = ema_rate * ema[i] + (1.f - ema_rate) * pi;
+        }
+        if (zero_g) g[i] = 0.f;
+    }
+}
+
+template <bool CLIP_EMA>
+int launch_adam(hipStream_t s, float* p, float* g, float* m, float* v, float* ema, long long n, long long n_decay,
+                const int* count_dev, const float* gnorm_sq, const pm_adam_cfg& c, float clip, float ema_rate, int skip) {
+    const bool vec = !((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) |
+                        reinterpret_cast<size_t>(v) | reinterpret_cast<size_t>(ema)) & 15);
+    long long blocks = vec ? ((n >> 2) + 511) / 512 : (n + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    if (vec)
+        hipLaunchKernelGGL((adam_kernel<CLIP_EMA, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, n_decay,
+                           count_dev, gnorm_sq, c, clip, ema_rate, skip);
+    else
+        hipLaunchKernelGGL((adam_kernel<CLIP_EMA, false>), dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, n_decay,
+                           count_dev, gnorm_sq, c, clip, ema_rate, skip);
+    return 0;
 }
 
 __global__ void counter_increment_kernel(int* c) { c[0] += 1; }
@@ -112,39 +203,6 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
-}
-
-// train_pm_vdvae.py:131-154: clip_by_global_norm -> scale_by_adam -> add_decayed_weights -> schedule -> scale(-1),
-// Trainer(skip_nonfinite_updates=True, ema_rate).  gnorm_sq holds sum g^2 of the (already reduced) gradient;
-// `count` is the optimizer's own update counter (it does not advance on a skipped step).
-__global__ __launch_bounds__(256) void adam_clip_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                              float* __restrict__ m, float* __restrict__ v,
-                                                              float* __restrict__ ema, long long n, long long n_decay,
-                                                              const int* __restrict__ count_dev,
-                                                              const float* __restrict__ gnorm_sq, pm_adam_cfg c,
-                                                              float clip, float ema_rate, int skip_nonfinite) {
-    const float gn = sqrtf(gnorm_sq[0]) * c.grad_scale;
-    if (skip_nonfinite && !isfinite(gn)) return;                 // every thread sees the same value
-    const float cs = (clip > 0.f && !(gn < clip)) ? clip / gn : 1.f;   // optax: where(g_norm < max_norm, g, g/g_norm*max_norm)
-    const int count = count_dev[0];
-    const float t = (float)(count + 1);
-    const float bc1 = 1.f - powf(c.b1, t);
-    const float bc2 = 1.f - powf(c.b2, t);
-    const float lr = pm_lr(c, count);
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        float gi = g[i] * c.grad_scale * cs;
-        float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
-        float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        float u = (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
-        float pi = p[i];
-        if (i < n_decay) u += c.weight_decay * pi;
-        pi -= lr * u;
-        p[i] = pi;
-        if (ema) ema[i] = ema_rate * ema[i] + (1.f - ema_rate) * pi;
-    }
 }
 
 __global__ void counter_increment_if_finite_kernel(int* c, const float* gnorm_sq) {
@@ -299,20 +357,18 @@ __global__ __launch_bounds__(256) void axpy1_kernel(const float* __restrict__ x,
 extern "C" int pm_pmvae_loss(pm_stream_t stream, const float* rec, const float* kl, const float* mll, int B,
                              const pm_loss_cfg* cfg, const int* step_dev, float* out, float* g_rec, float* g_kl,
                              float* g_mll) {
-    if (!rec || !kl || !mll || !cfg || !out || B <= 0) return PM_EINVAL;
+    if (!cfg || B <= 0) return PM_EINVAL;
+    if (rec ? (!kl || !mll || !out) : (kl || mll || out)) return PM_EINVAL;     // all four, or none of them
     if (cfg->beta_kind == 2 && cfg->period_or_steps < 2) return PM_EINVAL;
     hipLaunchKernelGGL(pmvae_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rec, kl, mll, B, *cfg, step_dev,
                        out, g_rec, g_kl, g_mll);
     return pm_check_launch("pm_pmvae_loss");
 }
 
-extern "C" int pm_adam_step(pm_stream_t stream, float* p, const float* g, float* m, float* v, long long n,
+extern "C" int pm_adam_step(pm_stream_t stream, float* p, float* g, float* m, float* v, long long n,
                             long long n_decay, const int* count_dev, const pm_adam_cfg* cfg) {
     if (!p || !g || !m || !v || !count_dev || !cfg || n <= 0) return PM_EINVAL;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, n_decay,
-                       count_dev, *cfg);
+    launch_adam<false>((hipStream_t)stream, p, g, m, v, nullptr, n, n_decay, count_dev, nullptr, *cfg, 0.f, 0.f, 0);
     return pm_check_launch("pm_adam_step");
 }
 
@@ -326,15 +382,12 @@ extern "C" int pm_sumsq(pm_stream_t stream, const float* x, long long n, float* 
     return pm_check_launch("pm_sumsq");
 }
 
-extern "C" int pm_adam_step_clip_ema(pm_stream_t stream, float* p, const float* g, float* m, float* v, float* ema,
+extern "C" int pm_adam_step_clip_ema(pm_stream_t stream, float* p, float* g, float* m, float* v, float* ema,
                                      long long n, long long n_decay, int* count_dev, const float* gnorm_sq,
                                      const pm_adam_cfg* cfg, float clip, float ema_rate, int skip_nonfinite) {
     if (!p || !g || !m || !v || !count_dev || !gnorm_sq || !cfg || n <= 0) return PM_EINVAL;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_clip_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, n_decay,
-                       count_dev, gnorm_sq, *cfg, clip, ema_rate, skip_nonfinite);
+    launch_adam<true>(s, p, g, m, v, ema, n, n_decay, count_dev, gnorm_sq, *cfg, clip, ema_rate, skip_nonfinite);
     if (skip_nonfinite) hipLaunchKernelGGL(counter_increment_if_finite_kernel, dim3(1), dim3(1), 0, s, count_dev, gnorm_sq);
     else hipLaunchKernelGGL(counter_increment_kernel, dim3(1), dim3(1), 0, s, count_dev);
     return pm_check_launch("pm_adam_step_clip_ema");

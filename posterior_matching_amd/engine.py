@@ -32,8 +32,12 @@ class _PlannedStep:
 
     def _planned(self, sequence) -> None:
         if self._plan is not None:
-            self._plan.replay()
-            return
+            store = self._grad_store()
+            if store is None or store.g_clean or not self.adam_cfg.zero_grad:
+                self._plan.replay()
+                return
+            sequence()                  # host code wrote gradients since the last step: this step zero-fills first (the
+            return                      # recorded plan relies on the optimizer kernel having zeroed the buffer)
         if self.use_plan and self._warm and ops._timer is None:
             ops.begin_recording()
             try:
@@ -47,6 +51,21 @@ class _PlannedStep:
 
     def invalidate_plan(self) -> None:
         self._plan, self._warm = None, False
+
+    def _grad_store(self):
+        return getattr(self, "store", None) or getattr(getattr(self, "model", None), "store", None)
+
+    # The optimizer kernel zeroes the gradient buffer it has just consumed (pm_adam_cfg.zero_grad): the zero-fill launch in
+    # front of the next backward pass (its weight-gradient kernels accumulate with atomics) is only needed when something
+    # else ran a backward pass in between.  `adam_cfg.zero_grad = 0` restores the separate launch (tests that read the
+    # gradient buffer after step()).
+    def _zero_grad(self, store) -> None:
+        if not store.g_clean:
+            ops.fill_zero(store.flat_g)
+        store.g_clean = False
+
+    def _grads_consumed(self, store) -> None:
+        store.g_clean = bool(self.adam_cfg.zero_grad)
 
 
 def _make_reducer(store, world_size: int, overlap: bool):
@@ -107,6 +126,7 @@ class PMVAETrainStep(_PlannedStep):
         self.world_size, self.rank, self.seed = world_size, rank, seed
         self.loss_cfg = loss_cfg_from_config(config, batch_size)
         self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.adam_cfg.zero_grad = 1
         # a captured step reduces between its two graphs: nothing may be issued from inside the capture (GradReducer.ready
         # is a no-op while capturing as well)
         self.reducer = _make_reducer(model.store, world_size, overlap_allreduce and not use_graph)
@@ -144,15 +164,22 @@ class PMVAETrainStep(_PlannedStep):
         m = self.model
         if not self.external_eps:
             ops.normal_fill(self.eps, self.seed, self.step_dev, stream_id=self.rank)
-        out = m(self.x, self.b, is_training=True, eps=self.eps)
+        self._zero_grad(m.store)
+        # d loss / d matching_ll = -matching_coef / B does not depend on the forward pass: with it on the device up front, the
+        # posterior-matching branch runs its backward pass right behind its forward pass on the side stream (beside the
+        # decoder) instead of waiting for the loss (PM_NO_EARLY_PM=1: the round-2 order, for A/B runs)
+        early = m.concurrent and not self.use_graph and not os.environ.get("PM_NO_EARLY_PM")
+        if early:
+            ops.pmvae_loss_grads(self.B, self.loss_cfg, self.step_dev, None, None, self.g_mll)
+        out = m(self.x, self.b, is_training=True, eps=self.eps, early_g_mll=self.g_mll if early else None)
         ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], self.loss_cfg, self.step_dev,
-                       self.metrics, self.g_rec, self.g_kl, self.g_mll)
-        m.zero_grad()
+                       self.metrics, self.g_rec, self.g_kl, None if early else self.g_mll)
         m.backward(self.g_rec, self.g_kl, self.g_mll)
 
     def _update(self) -> None:
         s = self.model.store
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._grads_consumed(s)
         s.split_all()                      # refresh the pre-split bf16 weight copies (one launch)
         ops.counter_increment(self.step_dev)
 
@@ -241,6 +268,7 @@ class VQVAETrainStep(_PlannedStep):
         self.model, self.opt, self.B = model, optimizer, batch_size
         self.world_size, self.rank = world_size, rank
         self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.adam_cfg.zero_grad = 1
         self.reducer = _make_reducer(model.store, world_size, overlap_allreduce)
         self.x = torch.zeros((batch_size,) + tuple(x_shape), device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -253,11 +281,12 @@ class VQVAETrainStep(_PlannedStep):
     def _sequence(self) -> None:
         m, s = self.model, self.model.store
         m(self.x, is_training=True)
-        m.zero_grad()
+        self._zero_grad(s)
         m.backward()
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)
 
@@ -320,6 +349,8 @@ class PMVQVAETrainStep(_PlannedStep):
         self.store, self.ws = pixel_cnn.store, pixel_cnn.ws
         # optimizer None: forward / evaluation only (trainer.PMVQVAELoss called as a function)
         self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size) if optimizer is not None else None
+        if self.adam_cfg is not None:
+            self.adam_cfg.zero_grad = 1
         self.reducer = _make_reducer(self.store, world_size, overlap_allreduce) if optimizer is not None else None
         x_shape = tuple(x_shape)
         self.x = torch.zeros((batch_size,) + x_shape, device=dev)
@@ -359,7 +390,7 @@ class PMVQVAETrainStep(_PlannedStep):
         flat gradient buffer holds d loss / d trainable parameters afterwards"""
         s = self.store
         self.forward(True)
-        ops.fill_zero(s.flat_g)
+        self._zero_grad(s)
         # the 4 x num_resnet gated blocks repeat a handful of layer shapes: their weight gradients (and the partial encoder's)
         # are collected and launched at the end, one table-driven grouped launch per geometry (ops.WgradBatch)
         batched = s.use_bf16 and not os.environ.get("PM_NO_WGRAD_BATCH")
@@ -386,6 +417,7 @@ class PMVQVAETrainStep(_PlannedStep):
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)
 
@@ -441,6 +473,7 @@ class VDVAETrainStep(_PlannedStep):
             c.weight_decay, c.lr_init, c.lr_decay_rate, c.lr_transition_steps = weight_decay, float(lr), 1.0, 1.0
             c.lr_kind, c.lr_end = 0, 0.0
         c.grad_scale = 1.0 / world_size
+        c.zero_grad = 1
         self.adam_cfg, self.clip, self.skip = c, float(gradient_clip or 0.0), skip_nonfinite_updates
         self.reducer = _make_reducer(s, world_size, overlap_allreduce)
         self.ema_rate = ema_rate
@@ -472,13 +505,14 @@ class VDVAETrainStep(_PlannedStep):
         if not self.external_eps:
             ops.normal_fill(self.eps_flat, self.seed, self.step_dev, stream_id=self.rank)
         m(self.x, self.b, self.eps)
-        m.zero_grad()
+        self._zero_grad(s)
         m.backward()
         if self.reducer is not None:
             self.reducer.finish()       # the clip / non-finite decision below sees the REDUCED gradient on every rank
         ops.sumsq(s.flat_g, self.gnorm_sq)
         ops.adam_step_clip_ema(s.flat_p, s.flat_g, s.flat_m, s.flat_v, self.ema, s.n_decay, self.opt_count, self.gnorm_sq,
                                self.adam_cfg, self.clip, self.ema_rate if self.ema_rate is not None else 0.0, self.skip)
+        self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)
 

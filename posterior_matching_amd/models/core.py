@@ -47,11 +47,26 @@ class Feat:
     grad_act: int = ACT_NONE
 
 
+class _GradViews(dict):
+    """name -> view of the flat gradient buffer.  Handing a view out marks the buffer as (possibly) written: the train
+    steps skip their zero-fill launch only while `store.g_clean` says that the optimizer kernel has zeroed the buffer
+    (pm_adam_cfg.zero_grad) and no host code has asked for a gradient view since."""
+
+    def __init__(self, store):
+        super().__init__()
+        self._store = store
+
+    def __getitem__(self, name):
+        self._store.g_clean = False
+        return dict.__getitem__(self, name)
+
+
 class ParamStore:
     def __init__(self):
         self.specs: "OrderedDict[str, Tuple[Tuple[int, ...], int]]" = OrderedDict()
         self.p: Dict[str, torch.Tensor] = {}
-        self.g: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = _GradViews(self)
+        self.g_clean = False           # True: flat_g is known to be all zeros (see _GradViews)
         self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
         self.n_decay = 0
         self.device = None

@@ -114,13 +114,18 @@ class ConvDecoder(Module):
             h = out
         return Feat(h, ACT_NONE, ACT_LEAKY)
 
-    def backward(self, dpre: torch.Tensor, need_input_grad: bool = True) -> Optional[torch.Tensor]:
+    def backward(self, dpre: torch.Tensor, need_input_grad: bool = True, lend=None) -> Optional[torch.Tensor]:
+        """lend = (stream, n): the weight gradients of layers 0 .. n-1 (the last n of this pass) are queued on `stream`"""
         B = dpre.shape[0]
         for i in reversed(range(len(self.geoms))):
             g = self.geoms[i]
             inp = self._outs[i - 1] if i > 0 else self._x.t
+            if lend is not None and i < lend[1]:
+                self.ws.wgrad_stream = lend[0]
             self.wgrad(g, inp, dpre, self.G(f"conv_t_{i}/w"), self.G(f"conv_t_{i}/b"),
                             in_act=ACT_NONE if i > 0 else self._x.in_act)
+            if lend is not None:
+                self.ws.wgrad_stream = None
             if i > 0:
                 dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
                 ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY,

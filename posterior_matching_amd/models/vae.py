@@ -33,7 +33,7 @@ class PosteriorMatchingVAE(Module):
         self._device = device
         self._seed = seed
         self.concurrent = True   # run the ELBO and the posterior-matching chains on two HIP streams
-        self.lend_wgrad = ""     # "dec" / "enc" / "all": weight gradients of the ELBO chain's decoder / encoder / both on the side stream
+        self.lend_wgrad = "enc"  # which weight gradients of the ELBO chain run on the side stream (see backward)
         self.store: Optional[ParamStore] = None
         if not isinstance(posterior_dist, (TriLGaussian, DiagonalGaussian)):
             raise NotImplementedError("posterior_dist must be TriLGaussian or DiagonalGaussian")
@@ -98,10 +98,16 @@ class PosteriorMatchingVAE(Module):
         return self.store.num_params
 
     def __call__(self, x: torch.Tensor, b: torch.Tensor, is_training: bool = False,
-                 eps: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                 eps: Optional[torch.Tensor] = None, early_g_mll: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """reference vae.py:120-144.  `eps` is the N(0,1) draw behind posterior.sample (required:
         the caller owns the RNG, see trainer.py).  Returns per-example `reconstruction_ll`, `kl`,
-        `matching_ll` (device tensors owned by the model, overwritten by the next call)."""
+        `matching_ll` (device tensors owned by the model, overwritten by the next call).
+
+        early_g_mll [B] (train steps, two-stream mode): d loss / d matching_ll, already on the device when the call
+        starts (it is -matching_coef / B whatever the forward computes).  The posterior-matching branch then runs its
+        BACKWARD pass on the side stream straight behind its forward pass, beside the decoder, instead of waiting for the
+        loss; backward() skips that branch.  The gradient buffer must be zero (or hold gradients to accumulate onto) before
+        the call."""
         if self.store is None:
             self.init(x.shape[1:], x.device)
         if eps is None:
@@ -121,11 +127,24 @@ class PosteriorMatchingVAE(Module):
         # the posterior-matching log-prob only needs z and the masked encoder's features: it runs on the
         # side stream beside the decoder
         ops.wait_stream(side, main)
+        self._z = z
+        self._pm_backward_done = False
+        mll_ready = None
         with torch.cuda.stream(side):
             mll = self.partial_posterior_dist.log_prob(pfeat, z)
+            if early_g_mll is not None and is_training and self.concurrent:
+                if getattr(self, "_mll_ready", None) is None:
+                    self._mll_ready = torch.cuda.Event()
+                mll_ready = self._mll_ready
+                ops.record_event(mll_ready, side)      # the loss needs matching_ll, not the backward pass queued behind it
+                self._pm_backward(early_g_mll, side)
+                self._pm_backward_done = True
         dec = self.decoder_net(Feat(z), is_training=is_training)
         rec = self.decoder_dist.log_prob_sum(dec, x)
-        ops.wait_stream(main, side)
+        if mll_ready is not None:
+            ops.wait_event(main, mll_ready)
+        else:
+            ops.wait_stream(main, side)
         self._z = z
         return {"reconstruction_ll": rec, "kl": kl, "matching_ll": mll}
 
@@ -250,6 +269,20 @@ class PosteriorMatchingVAE(Module):
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
+    def _pm_backward(self, g_mll: torch.Tensor, side) -> "torch.cuda.Event":
+        """backward pass of the posterior-matching branch (AR-GMM / TriL head + partial encoder) on the current (side) stream;
+        returns the event behind which d loss / dz of this branch is complete"""
+        want_dz = not self._matching_ll_stop_gradients                      # vae.py:136-137
+        dz_pm = self.ws.get("dz_matching", self._z.shape) if want_dz else None
+        dpenc = self.partial_posterior_dist.backward_log_prob(g_mll, dz_pm)
+        if getattr(self, "_dz_ready", None) is None:
+            self._dz_ready = torch.cuda.Event()
+        ops.record_event(self._dz_ready, side)
+        self.partial_encoder_net.backward(dpenc, need_input_grad=False)
+        self.ws.join_aux()
+        self.store.grads_ready(["partial_encoder_net", "partial_posterior_dist"])     # data-parallel: bucket is complete
+        return self._dz_ready
+
     def backward(self, g_rec: torch.Tensor, g_kl: torch.Tensor, g_mll: torch.Tensor) -> None:
         """Accumulates d loss / d params into the flat gradient buffer given the per-example
         gradients of the loss w.r.t. the three outputs (zero the buffer first: `zero_grad`)."""
@@ -258,31 +291,40 @@ class PosteriorMatchingVAE(Module):
         want_dz = not self._matching_ll_stop_gradients                      # vae.py:136-137
         dz_pm = self.ws.get("dz_matching", self._z.shape) if want_dz else None
         ops.wait_stream(side, main)
-        with torch.cuda.stream(side):     # posterior-matching branch: AR-GMM / TriL head + partial encoder
-            dpenc = self.partial_posterior_dist.backward_log_prob(g_mll, dz_pm)
-            dz_ready = torch.cuda.Event()
-            ops.record_event(dz_ready, side)
-            self.partial_encoder_net.backward(dpenc, need_input_grad=False)
-            self.ws.join_aux()
-            self.store.grads_ready(["partial_encoder_net", "partial_posterior_dist"])     # data-parallel: bucket is complete
+        if getattr(self, "_pm_backward_done", False):     # ran behind the branch's forward pass (early_g_mll)
+            self._pm_backward_done = False
+            dz_ready = self._dz_ready
+        else:
+            with torch.cuda.stream(side):     # posterior-matching branch: AR-GMM / TriL head + partial encoder
+                dz_ready = self._pm_backward(g_mll, side)
         # ELBO branch on the main stream.  It is the longer chain; its weight gradients only feed the optimizer, so
         # (lend_wgrad) they are queued on the side stream behind the posterior-matching branch instead of sitting
         # between the data-gradient kernels of the critical path.
+        # lend_wgrad: which of this chain's weight gradients are queued on the side stream (behind the posterior-matching
+        # branch, which ends long before this chain does: profiles/r03_*_timeline.txt) instead of sitting between the data-
+        # gradient kernels of the critical path.  "enc": the encoder's; "decN": those of the decoder's first N layers (the
+        # LAST N of its backward pass); "dec" / "all": every decoder layer (/ and the encoder); "": none.
         lend = os.environ.get("PM_LEND_WGRAD", self.lend_wgrad) if self.concurrent else ""
+        parts = [t for t in str(lend).replace("all", "dec,enc").split(",") if t]
+        dec_below = 0
+        for t in parts:
+            if t.startswith("dec"):
+                dec_below = int(t[3:]) if t[3:] else 1 << 30
         dpre = self.decoder_dist.backward(g_rec)
-        if lend in ("dec", "all"):
-            self.ws.wgrad_stream = side
-        dz = self.decoder_net.backward(dpre, need_input_grad=True)
-        if lend == "dec":
-            self.ws.wgrad_stream = None
-        if not lend:
+        from .networks import ConvDecoder
+
+        if dec_below and isinstance(self.decoder_net, ConvDecoder):
+            dz = self.decoder_net.backward(dpre, need_input_grad=True, lend=(side, dec_below))
+        else:
+            dz = self.decoder_net.backward(dpre, need_input_grad=True)
+        if not parts:
             self.ws.join_aux()
             self.store.grads_ready(["decoder_net", "decoder_dist"])
         if want_dz:
             ops.wait_event(main, dz_ready)
             ops.axpy1(dz_pm, dz)
         denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
-        if lend == "enc":       # the encoder's weight gradients, issued when the posterior-matching chain has long finished
+        if "enc" in parts:      # the encoder's weight gradients, issued when the posterior-matching chain has long finished
             self.ws.wgrad_stream = side
         self.encoder_net.backward(denc, need_input_grad=False)
         self.ws.wgrad_stream = None

@@ -1181,6 +1181,11 @@ def pmvae_loss(rec, kl, mll, cfg: _lib.LossCfg, step_dev, out, g_rec, g_kl, g_ml
     _call("pm_pmvae_loss", _ptr(rec), _ptr(kl), _ptr(mll), rec.shape[0], C.byref(cfg), _iptr(step_dev), _ptr(out), _ptr(g_rec), _ptr(g_kl), _ptr(g_mll))
 
 
+def pmvae_loss_grads(B: int, cfg: _lib.LossCfg, step_dev, g_rec, g_kl, g_mll) -> None:
+    """only the upstream gradients of pm_pmvae_loss (functions of the step counter, not of the forward pass)"""
+    _call("pm_pmvae_loss", None, None, None, B, C.byref(cfg), _iptr(step_dev), None, _ptr(g_rec), _ptr(g_kl), _ptr(g_mll))
+
+
 def adam_step(p, g, m, v, n_decay, count_dev, cfg: _lib.AdamCfg) -> None:
     _call("pm_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay, _iptr(count_dev), C.byref(cfg),
           tag="adam_kernel", work={"bytes": 7.0 * 4.0 * p.numel()})       # reads p, g, m, v; writes p, m, v

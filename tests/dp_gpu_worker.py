@@ -136,6 +136,7 @@ if rank == 0:
 # float32 runs drift apart on entries whose gradient is rounding noise).
 def grad_and_losses(ts, feed, steps=3):
     losses, g1 = [], None
+    ts.adam_cfg.zero_grad = 0            # keep the gradient buffer readable after step() (default: Adam zeroes it)
     for s in range(steps):
         feed(s)
         ts.step()
