@@ -71,6 +71,9 @@ CONV_CASES = [
     ("dense", 256, 1, 560, 128, 1, 1, "VALID"), ("dense", 100, 1, 128, 560, 1, 1, "VALID"),   # C % 32 != 0: part-padded last chunk
     # small images under long kernels (the PixelCNN's 7 x 7 x 256 grids): two images per workgroup share one weight pass
     ("conv", 256, 7, 256, 256, 3, 1, "SAME"), ("convT", 256, 7, 256, 128, 3, 1, "SAME"),
+    # plain-rows weight gradients with >= 1024 rows (the ResidualMLP hidden layers of a B = 256 step), ragged rows / columns
+    ("dense", 8192, 1, 256, 256, 1, 1, "VALID"), ("dense", 2100, 1, 192, 256, 1, 1, "VALID"),
+    ("dense", 1030, 1, 128, 132, 1, 1, "VALID"), ("dense", 1500, 1, 320, 200, 1, 1, "VALID"),
 ]
 
 

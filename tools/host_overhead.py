@@ -18,3 +18,15 @@ t1=time.perf_counter()
 torch.cuda.synchronize()
 t2=time.perf_counter()
 print(f"host enqueue {1e3*(t1-t0)/50:.3f} ms/step ; total {1e3*(t2-t0)/50:.3f} ms/step")
+# host time to enqueue ONE step into idle queues (median of 30), and what the plan holds
+import statistics
+ds = []
+for _ in range(30):
+    torch.cuda.synchronize()
+    t = time.perf_counter(); ts.step(); ds.append(time.perf_counter() - t)
+torch.cuda.synchronize()
+kinds = {}
+for fn, args, name in ts._plan.calls:
+    k = name if name in ("wait_stream", "event.record", "wait_event") else "launch"
+    kinds[k] = kinds.get(k, 0) + 1
+print(f"one step into idle queues: host {1e3 * statistics.median(ds):.3f} ms (min {1e3 * min(ds):.3f}); plan entries {kinds}")
