@@ -100,19 +100,24 @@ def test_embed_categorical_and_dropout_mask():
     from posterior_matching_amd import ops
 
     gen = torch.Generator().manual_seed(1)
+    # (256, 49) = pm_vqvae_mnist at B = 256, (16, 256, K = 512) = pm_vqvae_celeb_a; K = 7: hot entries, F not a power of two
+    for B, P, K, F in ((5, 49, 256, 128), (256, 49, 256, 128), (16, 256, 512, 128), (40, 30, 7, 300)):
+        R = B * P
+        idx = torch.randint(0, K, (R,), generator=gen)
+        table = torch.randn((K, F), generator=gen, dtype=F64)
+        out = torch.empty((R, F), device=dev())
+        idd = idx.to(torch.int32).to(dev())
+        ops.embed_fwd(idd, f32d(table), out)
+        assert torch.equal(out.cpu(), table.float()[idx])
+        dout = torch.randn((R, F), generator=gen, dtype=F64)
+        dt = torch.ones((K, F), device=dev())                           # accumulates
+        ops.embed_bwd(idd, f32d(dout), dt)
+        want = torch.ones((K, F), dtype=F64).index_add_(0, idx, dout)
+        assert rel_err(dt, want) < 1e-6, (B, P, K, F)
     B, P, K, F = 5, 49, 256, 128
     R = B * P
     idx = torch.randint(0, K, (R,), generator=gen)
-    table = torch.randn((K, F), generator=gen, dtype=F64)
-    out = torch.empty((R, F), device=dev())
     idd = idx.to(torch.int32).to(dev())
-    ops.embed_fwd(idd, f32d(table), out)
-    assert torch.equal(out.cpu(), table.float()[idx])
-    dout = torch.randn((R, F), generator=gen, dtype=F64)
-    dt = torch.zeros((K, F), device=dev())
-    ops.embed_bwd(idd, f32d(dout), dt)
-    want = torch.zeros((K, F), dtype=F64).index_add_(0, idx, dout)
-    assert rel_err(dt, want) < 1e-6
 
     logits = torch.randn((R, K), generator=gen, dtype=F64) * 3
     g = torch.randn((B,), generator=gen, dtype=F64)
