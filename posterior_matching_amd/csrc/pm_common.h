@@ -117,3 +117,22 @@ __device__ __forceinline__ float pm_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Philox4x32-10 (Random123), counter (c0, c1, c2, c3), key = the two words of `seed`: the generator of pm_normal_fill /
+// pm_dropout_mask / pm_gumbel_fill (pm_optim.hip), here for kernels that draw their own numbers in place.
+__device__ __forceinline__ void pm_philox4x32_10(unsigned (&c)[4], unsigned long long seed) {
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned)p1;
+        c[3] = (unsigned)p0;
+        c[0] = n0;
+        c[2] = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}

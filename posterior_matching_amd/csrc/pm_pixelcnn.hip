@@ -303,10 +303,23 @@ __global__ __launch_bounds__(256) void imputation_psnr_kernel(const float* __res
 // that is ~150 VALU instructions per element - they were VALU-bound (15 us for 38 MB), not HBM-bound.
 typedef float pc_f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool DROP>
+// hk.dropout keep mask of the 4 elements of output vector `o`, drawn in place: exactly the values pm_dropout_mask writes to
+// element quad `o` of a mask tensor (same Philox counter / key, same threshold), so the mask never exists in HBM
+struct PhiloxDrop { float rate, keep_scale; unsigned long long seed; const int* step_dev; int stream_id; };
+__device__ __forceinline__ pc_f32x4 philox_keep(const PhiloxDrop& d, unsigned step, unsigned o) {
+    unsigned c[4] = {o, 0u, step, (unsigned)d.stream_id};
+    pm_philox4x32_10(c, d.seed);
+    pc_f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = ((float)c[e] * 2.3283064365386963e-10f >= d.rate) ? d.keep_scale : 0.f;
+    return m;
+}
+
+// DROP 0: no dropout; 1: keep mask read from `drop`; 2: keep mask drawn in place (PhiloxDrop)
+template <int DROP>
 __global__ __launch_bounds__(256) void concat_elu_fwd_v4_kernel(const pc_f32x4* __restrict__ a, const pc_f32x4* __restrict__ b,
                                                                  const pc_f32x4* __restrict__ drop, pc_f32x4* __restrict__ out,
-                                                                 unsigned nv, unsigned Ca4, unsigned Cb4) {
+                                                                 unsigned nv, unsigned Ca4, unsigned Cb4, PhiloxDrop pd) {
     const unsigned C4 = Ca4 + Cb4;
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nv) return;
@@ -319,20 +332,24 @@ __global__ __launch_bounds__(256) void concat_elu_fwd_v4_kernel(const pc_f32x4* 
         pos[e] = elu_f(v[e]);
         neg[e] = elu_f(-v[e]);
     }
-    if (DROP) {
+    if (DROP == 1) {
         pos *= drop[o];
         neg *= drop[o + C4];
+    } else if (DROP == 2) {
+        const unsigned step = pd.step_dev ? (unsigned)pd.step_dev[0] : 0u;
+        pos *= philox_keep(pd, step, o);
+        neg *= philox_keep(pd, step, o + C4);
     }
     out[o] = pos;
     out[o + C4] = neg;
 }
 
-template <bool DROP>
+template <int DROP>
 __global__ __launch_bounds__(256) void concat_elu_bwd_v4_kernel(const pc_f32x4* __restrict__ a, const pc_f32x4* __restrict__ b,
                                                                  const pc_f32x4* __restrict__ drop, const pc_f32x4* __restrict__ dout,
                                                                  pc_f32x4* __restrict__ da, pc_f32x4* __restrict__ db, unsigned nv,
                                                                  unsigned Ca4, unsigned Cb4, int accumulate,
-                                                                 const pc_f32x4* __restrict__ add_a) {
+                                                                 const pc_f32x4* __restrict__ add_a, PhiloxDrop pd) {
     const unsigned C4 = Ca4 + Cb4;
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nv) return;
@@ -344,9 +361,13 @@ __global__ __launch_bounds__(256) void concat_elu_bwd_v4_kernel(const pc_f32x4* 
     const pc_f32x4 v = first ? a[src] : b[src];
     const unsigned o = r * 2u * C4 + c4;
     pc_f32x4 gp = dout[o], gn = dout[o + C4];
-    if (DROP) {
+    if (DROP == 1) {
         gp *= drop[o];
         gn *= drop[o + C4];
+    } else if (DROP == 2) {
+        const unsigned step = pd.step_dev ? (unsigned)pd.step_dev[0] : 0u;
+        gp *= philox_keep(pd, step, o);
+        gn *= philox_keep(pd, step, o + C4);
     }
     pc_f32x4 g;
 #pragma unroll
@@ -410,9 +431,10 @@ extern "C" int pm_concat_elu_fwd(pm_stream_t stream, const float* a, const float
     if (Ca % 4 == 0 && Cb % 4 == 0 && total < 0x7fffffffLL && al16(a) && al16(b) && al16(drop) && al16(out)) {
         const unsigned nv = (unsigned)(rows * (Ca + Cb) / 4);
         typedef const pc_f32x4* cp;
-        PM_KTAG("concat_elu_fwd_v4_kernel<%s>", drop ? "true" : "false");
-        if (drop) hipLaunchKernelGGL(concat_elu_fwd_v4_kernel<true>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (pc_f32x4*)out, nv, (unsigned)Ca / 4, (unsigned)Cb / 4);
-        else hipLaunchKernelGGL(concat_elu_fwd_v4_kernel<false>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (pc_f32x4*)out, nv, (unsigned)Ca / 4, (unsigned)Cb / 4);
+        PM_KTAG("concat_elu_fwd_v4_kernel<%d>", drop ? 1 : 0);
+        const PhiloxDrop none{};
+        if (drop) hipLaunchKernelGGL(concat_elu_fwd_v4_kernel<1>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (pc_f32x4*)out, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, none);
+        else hipLaunchKernelGGL(concat_elu_fwd_v4_kernel<0>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (pc_f32x4*)out, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, none);
         return pm_check_launch("pm_concat_elu_fwd");
     }
     PM_KTAG("concat_elu_fwd_kernel");
@@ -430,15 +452,53 @@ extern "C" int pm_concat_elu_bwd(pm_stream_t stream, const float* a, const float
         al16(db) && al16(add_a)) {
         const unsigned nv = (unsigned)(rows * (Ca + Cb) / 4);
         typedef const pc_f32x4* cp;
-        PM_KTAG("concat_elu_bwd_v4_kernel<%s>", drop ? "true" : "false");
-        if (drop) hipLaunchKernelGGL(concat_elu_bwd_v4_kernel<true>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (cp)dout, (pc_f32x4*)da, (pc_f32x4*)db, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, accumulate, (cp)add_a);
-        else hipLaunchKernelGGL(concat_elu_bwd_v4_kernel<false>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (cp)dout, (pc_f32x4*)da, (pc_f32x4*)db, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, accumulate, (cp)add_a);
+        PM_KTAG("concat_elu_bwd_v4_kernel<%d>", drop ? 1 : 0);
+        const PhiloxDrop none{};
+        if (drop) hipLaunchKernelGGL(concat_elu_bwd_v4_kernel<1>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (cp)dout, (pc_f32x4*)da, (pc_f32x4*)db, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, accumulate, (cp)add_a, none);
+        else hipLaunchKernelGGL(concat_elu_bwd_v4_kernel<0>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b, (cp)drop, (cp)dout, (pc_f32x4*)da, (pc_f32x4*)db, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, accumulate, (cp)add_a, none);
         return pm_check_launch("pm_concat_elu_bwd");
     }
     PM_KTAG("concat_elu_bwd_kernel");
     hipLaunchKernelGGL(concat_elu_bwd_kernel, dim3(blocks_for(rows * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, b,
                        drop, dout, da, db, rows, Ca, Cb, accumulate, add_a);
     return pm_check_launch("pm_concat_elu_bwd");
+}
+
+// concat_elu + hk.dropout with the keep mask drawn in place: out / da, db as pm_concat_elu_fwd / _bwd with the mask tensor
+// pm_dropout_mask(n = rows * 2 (Ca + Cb), rate, seed, step_dev, stream_id) would hold.  16-byte form only (Ca, Cb multiples
+// of 4, 16-byte aligned operands): callers fall back to the mask tensor otherwise (PM_EINVAL).
+extern "C" int pm_concat_elu_fwd_philox(pm_stream_t stream, const float* a, const float* b, float* out, long long rows,
+                                        int Ca, int Cb, float rate, unsigned long long seed, const int* step_dev,
+                                        int stream_id) {
+    if (!a || !out || rows <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && !b) || !(rate >= 0.f) || !(rate < 1.f)) return PM_EINVAL;
+    const long long total = rows * 2 * (Ca + Cb);
+    if (Ca % 4 || Cb % 4 || total >= 0x7fffffffLL || !al16(a) || !al16(b) || !al16(out)) return PM_EINVAL;
+    const unsigned nv = (unsigned)(rows * (Ca + Cb) / 4);
+    typedef const pc_f32x4* cp;
+    const PhiloxDrop pd{rate, 1.f / (1.f - rate), seed, step_dev, stream_id};
+    PM_KTAG("concat_elu_fwd_v4_kernel<2>");
+    hipLaunchKernelGGL(concat_elu_fwd_v4_kernel<2>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b,
+                       (cp) nullptr, (pc_f32x4*)out, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, pd);
+    return pm_check_launch("pm_concat_elu_fwd_philox");
+}
+
+extern "C" int pm_concat_elu_bwd_philox(pm_stream_t stream, const float* a, const float* b, const float* dout, float* da,
+                                        float* db, long long rows, int Ca, int Cb, int accumulate, const float* add_a,
+                                        float rate, unsigned long long seed, const int* step_dev, int stream_id) {
+    if (!a || !dout || rows <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && !b) || (add_a && !da) || !(rate >= 0.f) || !(rate < 1.f))
+        return PM_EINVAL;
+    const long long total = rows * 2 * (Ca + Cb);
+    if (Ca % 4 || Cb % 4 || total >= 0x7fffffffLL || !al16(a) || !al16(b) || !al16(dout) || !al16(da) || !al16(db) ||
+        !al16(add_a))
+        return PM_EINVAL;
+    const unsigned nv = (unsigned)(rows * (Ca + Cb) / 4);
+    typedef const pc_f32x4* cp;
+    const PhiloxDrop pd{rate, 1.f / (1.f - rate), seed, step_dev, stream_id};
+    PM_KTAG("concat_elu_bwd_v4_kernel<2>");
+    hipLaunchKernelGGL(concat_elu_bwd_v4_kernel<2>, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)a, (cp)b,
+                       (cp) nullptr, (cp)dout, (pc_f32x4*)da, (pc_f32x4*)db, nv, (unsigned)Ca / 4, (unsigned)Cb / 4, accumulate,
+                       (cp)add_a, pd);
+    return pm_check_launch("pm_concat_elu_bwd_philox");
 }
 
 extern "C" int pm_gate_fwd(pm_stream_t stream, const float* y, const float* h, const float* input, float* out,

@@ -186,6 +186,10 @@ class PixelCNN(Module):
             if rate > 0.0:
                 if dropout_masks is not None:
                     drop = dropout_masks[blk.group]
+                elif ops.PhiloxDrop.usable(x1) and not os.environ.get("PM_DROPOUT_MASK_TENSOR"):
+                    # the keep mask is drawn inside concat_elu forward AND backward (same Philox counters): it never exists
+                    # in HBM (was: one mask launch + 12.8 MB written and read twice per gated block at the mnist size)
+                    drop = ops.PhiloxDrop(rate, seed, step_dev, blk.group)
                 else:
                     drop = self.buf(f"{n}/drop", sh(2 * F))
                     ops.dropout_mask(drop, rate, seed, step_dev, stream_id=blk.group)

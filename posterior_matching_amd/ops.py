@@ -761,8 +761,29 @@ def embed_bwd(idx, dout, dtable) -> None:
     _call("pm_embed_bwd", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K)
 
 
+@dataclass
+class PhiloxDrop:
+    """hk.dropout keep mask that is never materialised: concat_elu_fwd / _bwd draw it in place from the Philox stream
+    (seed, step counter on the device, stream_id) - the values dropout_mask() would write with the same arguments"""
+
+    rate: float
+    seed: int
+    step_dev: "torch.Tensor"
+    stream_id: int
+
+    @staticmethod
+    def usable(*tensors) -> bool:
+        """the in-place form is the 16-byte kernel: channel counts % 4 == 0, 16-byte aligned operands"""
+        return all(t is None or (t.shape[-1] % 4 == 0 and t.data_ptr() % 16 == 0) for t in tensors)
+
+
 def concat_elu_fwd(a, b, drop, out) -> None:
+    """drop: None, a pre-scaled keep-mask tensor shaped like `out`, or a PhiloxDrop (mask drawn in place)"""
     Ca, Cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
+    if isinstance(drop, PhiloxDrop):
+        _call("pm_concat_elu_fwd_philox", _ptr(a), _ptr(b), _ptr(out), a.numel() // Ca, Ca, Cb, drop.rate,
+              drop.seed & (2 ** 64 - 1), _iptr(drop.step_dev), drop.stream_id, work={"bytes": _nbytes(a, b, out)})
+        return
     _call("pm_concat_elu_fwd", _ptr(a), _ptr(b), _ptr(drop), _ptr(out), a.numel() // Ca, Ca, Cb,
           work={"bytes": _nbytes(a, b, drop, out)})
 
@@ -770,6 +791,11 @@ def concat_elu_fwd(a, b, drop, out) -> None:
 def concat_elu_bwd(a, b, drop, dout, da, db, accumulate: bool, add_a=None) -> None:
     """add_a (same shape as a): added to da in the same pass (a gated block's residual path d_in += dout)"""
     Ca, Cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
+    if isinstance(drop, PhiloxDrop):
+        _call("pm_concat_elu_bwd_philox", _ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), a.numel() // Ca, Ca, Cb,
+              int(accumulate), _ptr(add_a), drop.rate, drop.seed & (2 ** 64 - 1), _iptr(drop.step_dev), drop.stream_id,
+              work={"bytes": _nbytes(a, b, dout, da, db, add_a)})
+        return
     _call("pm_concat_elu_bwd", _ptr(a), _ptr(b), _ptr(drop), _ptr(dout), _ptr(da), _ptr(db), a.numel() // Ca, Ca, Cb,
           int(accumulate), _ptr(add_a), work={"bytes": _nbytes(a, b, drop, dout, da, db, add_a)})
 

@@ -146,6 +146,40 @@ def test_embed_categorical_and_dropout_mask():
     assert not torch.equal(m, m2)
 
 
+@pytest.mark.parametrize("R,Ca,Cb", [(12544, 128, 0), (245, 64, 32), (4096, 128, 128)])
+def test_concat_elu_with_the_keep_mask_drawn_in_place(R, Ca, Cb):
+    """pm_concat_elu_{fwd,bwd}_philox (the train step's form: hk.dropout's keep mask never exists in HBM) against the
+    two-launch form it replaces - pm_dropout_mask into a tensor, then pm_concat_elu_{fwd,bwd} with that tensor, which the
+    PixelCNN parity tests check against the oracle with explicit masks: BIT-identical outputs and gradients, for several
+    steps / stream ids (same Philox counters), with and without the second input, accumulate / add_a."""
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(R + Ca)
+    d = dev()
+    a = torch.randn((R, Ca), generator=gen).to(d)
+    b = torch.randn((R, Cb), generator=gen).to(d) if Cb else None
+    dout = torch.randn((R, 2 * (Ca + Cb)), generator=gen).to(d)
+    add_a = torch.randn((R, Ca), generator=gen).to(d)
+    for step, sid, rate in ((0, 0, 0.5), (7, 3, 0.5), (123456, 31, 0.1)):
+        step_dev = torch.tensor([step], dtype=torch.int32, device=d)
+        mask = torch.empty((R, 2 * (Ca + Cb)), device=d)
+        ops.dropout_mask(mask, rate, 99, step_dev, stream_id=sid)
+        pd = ops.PhiloxDrop(rate, 99, step_dev, sid)
+        assert ops.PhiloxDrop.usable(a, b)
+        want, got = torch.empty_like(dout), torch.empty_like(dout)
+        ops.concat_elu_fwd(a, b, mask, want)
+        ops.concat_elu_fwd(a, b, pd, got)
+        assert torch.equal(got, want) and 0.0 < (got == 0).float().mean() < 1.0
+        for acc, add in ((False, None), (True, add_a)):
+            da_w, da_g = torch.ones((R, Ca), device=d), torch.ones((R, Ca), device=d)
+            db_w = torch.ones((R, Cb), device=d) if Cb else None
+            db_g = torch.ones((R, Cb), device=d) if Cb else None
+            ops.concat_elu_bwd(a, b, mask, dout, da_w, db_w, accumulate=acc, add_a=add)
+            ops.concat_elu_bwd(a, b, pd, dout, da_g, db_g, accumulate=acc, add_a=add)
+            assert torch.equal(da_g, da_w) and (not Cb or torch.equal(db_g, db_w))
+    torch.cuda.synchronize()
+
+
 # ----------------------------------------------------------------------------------------------
 # the network
 # ----------------------------------------------------------------------------------------------
