@@ -402,6 +402,45 @@ __global__ __launch_bounds__(256) void gate_v4_kernel(const pc_f32x4* __restrict
     }
 }
 
+// gate backward AND the conditional projection's gradient in one pass: dy as gate_v4_kernel<true>, dh[b] = sum over the P
+// positions of image b of dy (what pm_rows_sum makes of dy afterwards: 12.8 MB re-read and one more launch per gated block
+// at the mnist PixelCNN's size).  One workgroup per image: thread (fq, rg) owns the activation / gate quads fq of the rows
+// rg, rg + RG, ... and keeps their sums in registers; the RG partial sums meet in LDS.  F4 = F / 4 divides 256, F4 <= 64.
+__global__ __launch_bounds__(256) void gate_bwd_rows_sum_kernel(const pc_f32x4* __restrict__ y, const pc_f32x4* __restrict__ h,
+                                                                 const pc_f32x4* __restrict__ dout, pc_f32x4* __restrict__ dy,
+                                                                 pc_f32x4* __restrict__ dh, unsigned F4, unsigned P) {
+    __shared__ pc_f32x4 red[256][2];
+    const unsigned b = blockIdx.x, RG = 256u / F4;
+    const unsigned fq = threadIdx.x % F4, rg = threadIdx.x / F4;
+    pc_f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hg = ha, sa = ha, sg = ha;
+    if (h) {
+        ha = h[b * 2u * F4 + fq];
+        hg = h[b * 2u * F4 + F4 + fq];
+    }
+    for (unsigned j = rg; j < P; j += RG) {
+        const unsigned r = b * P + j;
+        const pc_f32x4 act = y[r * 2u * F4 + fq] + ha, gate = y[r * 2u * F4 + F4 + fq] + hg;
+        pc_f32x4 s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = pm_sigmoid(gate[e]);
+        const pc_f32x4 x = dout[r * F4 + fq];
+        const pc_f32x4 da = x * s, dg = x * act * s * (1.f - s);
+        dy[r * 2u * F4 + fq] = da;
+        dy[r * 2u * F4 + F4 + fq] = dg;
+        sa += da;
+        sg += dg;
+    }
+    red[threadIdx.x][0] = sa;
+    red[threadIdx.x][1] = sg;
+    __syncthreads();
+    if (threadIdx.x < 2u * F4) {                 // quad q of dh[b]: activation half first, then the gate half
+        const unsigned half = threadIdx.x / F4, q = threadIdx.x % F4;
+        pc_f32x4 t = red[q][half];
+        for (unsigned g = 1; g < RG; ++g) t += red[g * F4 + q][half];
+        dh[b * 2u * F4 + half * F4 + q] = t;
+    }
+}
+
 // anonymous-namespace helpers of the launchers
 inline bool al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
@@ -531,6 +570,20 @@ extern "C" int pm_gate_bwd(pm_stream_t stream, const float* y, const float* h, c
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, y, h, dout, dy,
                        rows, F, P);
     return pm_check_launch("pm_gate_bwd");
+}
+
+extern "C" int pm_gate_bwd_rows_sum(pm_stream_t stream, const float* y, const float* h, const float* dout, float* dy,
+                                    float* dh, long long B, int F, int P) {
+    if (!y || !dout || !dy || !dh || B <= 0 || F <= 0 || P <= 0) return PM_EINVAL;
+    const int F4 = F / 4;
+    if (F % 4 || F4 > 64 || 256 % F4 || B * P * 2 * F >= 0x7fffffffLL || B > 0x7fffffffLL || !al16(y) || !al16(h) ||
+        !al16(dout) || !al16(dy) || !al16(dh))
+        return PM_EINVAL;
+    typedef const pc_f32x4* cp;
+    PM_KTAG("gate_bwd_rows_sum_kernel");
+    hipLaunchKernelGGL(gate_bwd_rows_sum_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (cp)y, (cp)h, (cp)dout,
+                       (pc_f32x4*)dy, (pc_f32x4*)dh, (unsigned)F4, (unsigned)P);
+    return pm_check_launch("pm_gate_bwd_rows_sum");
 }
 
 extern "C" int pm_rows_sum(pm_stream_t stream, const float* x, float* out, long long B, int N, int P) {

@@ -308,9 +308,13 @@ class PixelCNN(Module):
         d_in = gbuf(input_x, gname(input_x))                                  # (+= dout, the residual branch: folded into the
         y = self.buf(f"{n}/y", sh(2 * F))                                      #  last concat_elu_bwd of the block)
         dy = self.buf(f"{n}/dy", sh(2 * F))
-        ops.gate_bwd(y, self._hproj[blk.group] if self._hproj is not None else None, dout, dy, P)
-        if dh_all is not None:
-            ops.rows_sum(dy.view(R, 2 * F), dh_all[blk.group], P)
+        hp = self._hproj[blk.group] if self._hproj is not None else None
+        if dh_all is not None and ops.gate_bwd_rows_sum_ok(dout, R // P) and not os.environ.get("PM_NO_GATE_ROWS_SUM"):
+            ops.gate_bwd_rows_sum(y, hp, dout, dy, dh_all[blk.group], P)     # dy and its sum over positions in one pass
+        else:
+            ops.gate_bwd(y, hp, dout, dy, P)
+            if dh_all is not None:
+                ops.rows_sum(dy.view(R, 2 * F), dh_all[blk.group], P)
         ce2 = self.buf(f"{n}/ce2", sh(2 * F))
         self._wg(blk.conv2, ce2, dy)
         dce2 = self.buf(f"{n}/dce2", sh(2 * F))
@@ -355,15 +359,31 @@ class PixelCNN(Module):
         dx_out = self.buf("dx_out", sh(F))
         self._dg(self.out_conv, dlogits, dx_out)
 
-        # gradient accumulators of every tensor that has several consumers: block outputs + the two inits
+        # gradient accumulators of every tensor that has several consumers: block outputs + the two inits.  They all have the
+        # shape [B, H, W, F] and live in ONE slab that a single launch zeroes when the pass starts (was: one zero-fill launch
+        # per accumulator, ~50 per pm_vqvae_mnist step, each in front of its first use on the dependent chains)
         grads: Dict[int, torch.Tensor] = {}
+        cap = 2 * G + 4
+        slab = self.buf("grad_slab", (cap,) + sh(F))
+        used = [0]
+        n_zero = getattr(self, "_gslab_used", {}).get(B, cap)       # entries the previous pass of this batch size handed out
+        if os.environ.get("PM_NO_GRAD_SLAB"):                       # A/B switch: one zero-fill launch per accumulator, at first use
+            n_zero = 0
+        else:
+            ops.fill_zero(slab[:n_zero])
+
+        def take(t: torch.Tensor) -> torch.Tensor:
+            assert tuple(t.shape) == sh(F) and used[0] < cap, (tuple(t.shape), used[0])
+            gb = slab[used[0]]
+            used[0] += 1
+            if used[0] > n_zero:                                    # first pass only: beyond what the slab fill covered
+                ops.fill_zero(gb)
+            return gb
 
         def gbuf(t: torch.Tensor, name: str) -> torch.Tensor:
             key = t.data_ptr()
             if key not in grads:
-                gb = self.buf(f"grad/{name}", tuple(t.shape))
-                ops.fill_zero(gb)
-                grads[key] = gb
+                grads[key] = take(t)
             return grads[key]
 
         names = {self._v0.data_ptr(): "v_init", self._h0.data_ptr(): "h_init"}
@@ -389,9 +409,7 @@ class PixelCNN(Module):
         def gbuf_h(t: torch.Tensor, name: str) -> torch.Tensor:
             key = t.data_ptr()
             if key not in from_h:
-                gb = self.buf(f"grad_h/{name}", tuple(t.shape))
-                ops.fill_zero(gb)
-                from_h[key] = gb
+                from_h[key] = take(t)
             return from_h[key]
 
         if two:
@@ -439,6 +457,9 @@ class PixelCNN(Module):
         self._dg(self.h_up, dh0, de2, res=de1)
         self._dg(self.h_left, dh0, de1, res=de2)
         ops.embed_bwd(self._value.reshape(-1), de1, self.G("embed/embeddings"))
+        if getattr(self, "_gslab_used", None) is None:
+            self._gslab_used = {}
+        self._gslab_used[B] = used[0]
         if dh_all is None:
             return None
         gw, gb_ = self._cond_params("g")

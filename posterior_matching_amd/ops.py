@@ -805,6 +805,19 @@ def gate_fwd(y, h, inp, out, P: int) -> None:
     _call("pm_gate_fwd", _ptr(y), _ptr(h), _ptr(inp), _ptr(out), inp.numel() // F, F, P, work={"bytes": _nbytes(y, inp, out)})
 
 
+def gate_bwd_rows_sum_ok(dout, B: int) -> bool:
+    """pm_gate_bwd_rows_sum's preconditions, and enough images to fill the chip with one workgroup each"""
+    F = dout.shape[-1]
+    return F % 4 == 0 and F // 4 <= 64 and 256 % (F // 4) == 0 and B >= 128 and dout.data_ptr() % 16 == 0
+
+
+def gate_bwd_rows_sum(y, h, dout, dy, dh, P: int) -> None:
+    """gate_bwd + rows_sum(dy) in one launch: dh [B, 2F] = sum over the P positions of dy"""
+    F = dout.shape[-1]
+    _call("pm_gate_bwd_rows_sum", _ptr(y), _ptr(h), _ptr(dout), _ptr(dy), _ptr(dh), dout.numel() // F // P, F, P,
+          work={"bytes": _nbytes(y, dout, dy)})
+
+
 def gate_bwd(y, h, dout, dy, P: int) -> None:
     F = dout.shape[-1]
     _call("pm_gate_bwd", _ptr(y), _ptr(h), _ptr(dout), _ptr(dy), dout.numel() // F, F, P, work={"bytes": _nbytes(y, dout, dy)})

@@ -146,6 +146,26 @@ def test_embed_categorical_and_dropout_mask():
     assert not torch.equal(m, m2)
 
 
+@pytest.mark.parametrize("B,P,F,cond", [(256, 49, 128, True), (130, 9, 32, True), (128, 49, 128, False), (129, 5, 256, True)])
+def test_gate_bwd_with_rows_sum(B, P, F, cond):
+    """pm_gate_bwd_rows_sum (the train step's form at B >= 128) vs float64: dy of the gated residual (pixel_cnn.py:455-460)
+    and dh = its sum over the positions of each image (the conditional projection's gradient, :565-569)."""
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(B + P + F)
+    R = B * P
+    y, h = torch.randn((R, 2 * F), generator=gen, dtype=F64), torch.randn((B, 2 * F), generator=gen, dtype=F64)
+    g = torch.randn((R, F), generator=gen, dtype=F64)
+    yr, hr = y.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    x = yr.reshape(B, P, 2 * F) + (hr[:, None, :] if cond else 0.0)
+    (torch.sigmoid(x[..., F:]) * x[..., :F]).backward(g.reshape(B, P, F))
+    assert ops.gate_bwd_rows_sum_ok(f32d(g), B)
+    dy, dh = torch.empty((R, 2 * F), device=dev()), torch.full((B, 2 * F), 7.0, device=dev())
+    ops.gate_bwd_rows_sum(f32d(y), f32d(h) if cond else None, f32d(g), dy, dh, P)
+    assert rel_err(dy, yr.grad) < 2e-6
+    assert rel_err(dh, hr.grad if cond else yr.grad.reshape(B, P, 2 * F).sum(1)) < 2e-6
+
+
 @pytest.mark.parametrize("R,Ca,Cb", [(12544, 128, 0), (245, 64, 32), (4096, 128, 128)])
 def test_concat_elu_with_the_keep_mask_drawn_in_place(R, Ca, Cb):
     """pm_concat_elu_{fwd,bwd}_philox (the train step's form: hk.dropout's keep mask never exists in HBM) against the
