@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step (single stream) "
                                                         "instead of eager launches on two overlapping streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-kernel HIP events")
+    ap.add_argument("--profile-steps", type=int, default=5, help="eager steps with per-kernel HIP events")
     ap.add_argument("--f32", action="store_true", help="every GEMM on the f32 MFMA (strict-parity mode) instead of the "
                                                       "default bf16x3 split on the bf16 matrix cores")
     ap.add_argument("--wgrad-streams", action="store_true", help="weight-gradient kernels on companion streams")
@@ -174,7 +174,7 @@ def main():
         traffic = measured_traffic()
         traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes, 2*FETCH_SIZE + WRITE_SIZE per launch"
     if traffic is None and world == 1 and args.profile_steps > 0:
-        for name in ("r02_final_pmc_traffic.json", "r01_final_pmc_traffic.json"):
+        for name in ("r03_final_pmc_traffic.json", "r02_final_pmc_traffic.json", "r01_final_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fp:
                     traffic = {k: v.get("traffic_bytes") for k, v in json.load(fp).items()}

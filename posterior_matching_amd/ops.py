@@ -43,12 +43,27 @@ class KernelTimer:
             rows.append((tag, work.get("detail", ""), e0.elapsed_ms(e1), work.get("flops", 0.0)))
         return rows
 
-    def summary(self):
-        out = {}
+    def summary(self, robust: bool = True):
+        """per kernel name: calls, total ms, algorithmic flops / bytes.  robust: a launch whose event-to-event time exceeds
+        3x the median of its (name, shape) group is counted at that median - an event pair also spans whatever delayed
+        the launch (one 400 us reading among 26 us ones was seen on an otherwise idle stream); `outliers` says how many"""
+        rows = []
         for tag, work, e0, e1 in self.records:
             e1.synchronize()
-            ms = e0.elapsed_ms(e1)
-            r = out.setdefault(tag, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            rows.append((tag, work, e0.elapsed_ms(e1)))
+        med = {}
+        if robust:
+            groups = {}
+            for tag, work, ms in rows:
+                groups.setdefault((tag, work.get("detail", "")), []).append(ms)
+            med = {k: sorted(v)[len(v) // 2] for k, v in groups.items()}
+        out = {}
+        for tag, work, ms in rows:
+            r = out.setdefault(tag, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "outliers": 0})
+            m = med.get((tag, work.get("detail", "")))
+            if m is not None and ms > 3.0 * m:
+                ms = m
+                r["outliers"] += 1
             r["calls"] += 1
             r["ms"] += ms
             r["flops"] += work.get("flops", 0.0)
@@ -1226,8 +1241,9 @@ def pmvae_loss_grads(B: int, cfg: _lib.LossCfg, step_dev, g_rec, g_kl, g_mll) ->
 
 
 def adam_step(p, g, m, v, n_decay, count_dev, cfg: _lib.AdamCfg) -> None:
+    passes = 8.0 if cfg.zero_grad else 7.0                      # reads p, g, m, v; writes p, m, v (and zeroes g)
     _call("pm_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay, _iptr(count_dev), C.byref(cfg),
-          tag="adam_kernel", work={"bytes": 7.0 * 4.0 * p.numel()})       # reads p, g, m, v; writes p, m, v
+          tag="adam_kernel<false, true>", work={"bytes": passes * 4.0 * p.numel()})
 
 
 def counter_increment(count_dev) -> None:
