@@ -266,7 +266,7 @@ class PosteriorMatchingVAE(Module):
         if not self.concurrent:
             return torch.cuda.current_stream(device)
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=device)
+            self._side = torch.cuda.Stream(device=device, priority=int(os.environ.get("PM_SIDE_PRIO", "0")))
         return self._side
 
     def _pm_backward(self, g_mll: torch.Tensor, side) -> "torch.cuda.Event":
@@ -317,7 +317,7 @@ class PosteriorMatchingVAE(Module):
             dz = self.decoder_net.backward(dpre, need_input_grad=True, lend=(side, dec_below))
         else:
             dz = self.decoder_net.backward(dpre, need_input_grad=True)
-        if not parts:
+        if not dec_below:               # the decoder's weight gradients ran on this stream: its bucket is complete (data-parallel)
             self.ws.join_aux()
             self.store.grads_ready(["decoder_net", "decoder_dist"])
         if want_dz:
