@@ -100,6 +100,58 @@ __device__ __forceinline__ void pm_epilogue_tile(const pm_f32x16& acc, const int
     }
 }
 
+// The same epilogue for a TRANSPOSED accumulator tile: the kernel issued its MFMAs with the operands swapped (weights as A,
+// activations as B), so this lane holds ONE output row (position) and its 16 registers are the columns
+// c(e) = (e & 3) + 8 * (e >> 2) + 4 * h of the 32-column tile starting at n0 - four runs of 4 consecutive columns.  Every
+// aux / res load and every store is then a 16-byte access (4 + 4 loads, 4 stores per lane instead of 16 + 16 + 16 dwords):
+// the store tail of a GEMM-class kernel is store-ISSUE bound (MI355X_MICROARCH.md, cycle constants, "epilogue store tail").
+// row_off: offset of the row's first column in out / aux / res (< 0: no such row); N % 4 == 0, 16-byte aligned tensors.
+typedef float pm_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pm_epilogue_tile_t(const pm_f32x16& acc, long long row_off, int n0, int h, int N,
+                                                   const float* __restrict__ bias, const float* __restrict__ aux,
+                                                   const float* __restrict__ res, float* __restrict__ out,
+                                                   float* __restrict__ out2, int act2, int aux_act, int out_act, float slope) {
+    pm_f32x4 av[4], rv[4], bv[4];
+    const bool row_ok = row_off >= 0;
+    const long long ro = row_ok ? row_off : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = n0 + 8 * g + 4 * h;
+        const int cc = c < N ? c : 0;                        // N % 4 == 0: a run of 4 columns is all there or not at all
+        bv[g] = bias ? *reinterpret_cast<const pm_f32x4*>(bias + cc) : pm_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (aux) av[g] = *reinterpret_cast<const pm_f32x4*>(aux + ro + cc);
+        if (res) rv[g] = *reinterpret_cast<const pm_f32x4*>(res + ro + cc);
+    }
+    const bool after = (aux_act & PM_AUX_AFTER_RES) != 0;
+    const int dact = aux_act & (PM_AUX_AFTER_RES - 1);
+    pm_f32x4 v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = acc[4 * g + q] + bv[g][q];
+            if (res && after) x += rv[g][q];
+            if (aux) x *= pm_dact(av[g][q], dact, slope);
+            if (res && !after) x += rv[g][q];
+            x = pm_act(x, out_act, slope);
+            asm volatile("" : "+v"(x));
+            v[g][q] = x;
+        }
+    if (!row_ok) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = n0 + 8 * g + 4 * h;
+        if (c >= N) continue;
+        *reinterpret_cast<pm_f32x4*>(out + ro + c) = v[g];
+        if (out2) {
+            pm_f32x4 w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = pm_act(v[g][q], act2, slope);
+            *reinterpret_cast<pm_f32x4*>(out2 + ro + c) = w;
+        }
+    }
+}
+
 __device__ __forceinline__ float pm_softplus(float x) {  // logaddexp(x, 0)
     return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
 }

@@ -1678,7 +1678,9 @@ bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
 //    when the whole image is resident); a wave owns one 32-column tile and up to T row tiles, and a B fragment - loaded
 //    straight from the pre-split weights, four k-steps ahead, like patch_conv_bd - feeds all T of them;
 //  * one barrier (after staging); waves run the k-loop and their epilogues independently.
-template <int NW, int T>
+// TR: the MFMAs take the weights as A and the activations as B, so a lane's accumulators are ONE output position x 16
+// columns and the epilogue moves 16-byte vectors (pm_epilogue_tile_t); N % 4 == 0.  TR = false: rows in registers, dword epilogue.
+template <int NW, int T, bool TR>
 __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
                                                                      long long plane, int nct) {
     constexpr int NSET = 4;
@@ -1811,12 +1813,21 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
             const int cur = (u * T + j) & 3;
             const int jn = j + 2;                                       // the item two ahead: (s + jn / T, jn % T)
             read_a(jn / T == 0 ? t0 : jn / T == 1 ? t1 : t2, jn % T, a[(cur + 2) & 3]);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][1], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], bq[u][0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][2], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][3], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][3], bq[u][2], acc[j], 0, 0, 0);
+            if (TR) {           // D^T = W^T X^T: same products, the accumulator tile comes out transposed
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u][0], a[cur][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u][1], a[cur][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u][0], a[cur][2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u][2], a[cur][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u][3], a[cur][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u][2], a[cur][3], acc[j], 0, 0, 0);
+            } else {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], bq[u][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], bq[u][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], bq[u][3], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][3], bq[u][2], acc[j], 0, 0, 0);
+            }
         }
         t0 = t1;
         t1 = t2;
@@ -1855,7 +1866,15 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
 #if defined(PM_EXP) && PM_EXP == 33
         if (acc[0][0] == 12345.f)
 #endif
-        if (n < g.N) {
+        if (TR) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const int m = 32 * (rt0 + j * wct) + i;                 // this lane's output position
+                const long long ro = m < Mi ? ((long long)b * Mi + m) * g.N : -1;
+                pm_epilogue_tile_t(acc[j], ro, ct * 32, h, g.N, p.bias, p.aux, p.res, p.out, p.out2, p.act2, g.aux_act,
+                                   g.out_act, g.slope);
+            }
+        } else if (n < g.N) {
 #pragma unroll
             for (int j = 0; j < T; ++j) {
                 int ro[16];
@@ -1898,17 +1917,25 @@ bool plan_image(const Geom& g, int groups, ImagePlan& ip) {
     return true;
 }
 
-template <int NW, int T>
-void launch_image(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const __bf16* ws, int npad, long long plane) {
+template <int NW, int T, bool TR>
+void launch_image_tr(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const __bf16* ws, int npad, long long plane) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&image_conv_bf16_kernel<NW, T>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&image_conv_bf16_kernel<NW, T, TR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    PM_KTAG("image_conv_bf16_kernel<%d, %d>", NW, T);
-    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T>), dim3((unsigned)a.g.B), dim3(64 * NW), ip.lds, s, a, ws, npad, plane,
+    PM_KTAG("image_conv_bf16_kernel<%d, %d, %s>", NW, T, TR ? "true" : "false");
+    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T, TR>), dim3((unsigned)a.g.B), dim3(64 * NW), ip.lds, s, a, ws, npad, plane,
                        ip.nct);
+}
+template <int NW, int T>
+void launch_image(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const __bf16* ws, int npad, long long plane) {
+    static const bool tr_off = getenv("PM_IMAGE_NO_TR") != nullptr;      // A/B switch for measurements
+    const bool al = !((reinterpret_cast<size_t>(a.out) | reinterpret_cast<size_t>(a.aux) | reinterpret_cast<size_t>(a.res) |
+                       reinterpret_cast<size_t>(a.out2) | reinterpret_cast<size_t>(a.bias)) & 15);
+    if (!tr_off && a.g.N % 4 == 0 && al) launch_image_tr<NW, T, true>(ip, s, a, ws, npad, plane);
+    else launch_image_tr<NW, T, false>(ip, s, a, ws, npad, plane);
 }
 
 // ------------- the same residence for the zero-dilated (d = 2, a = 1) problems: stride-2 transposed convolutions forward and
