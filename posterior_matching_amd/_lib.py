@@ -208,6 +208,9 @@ SIGNATURES = {
     "pm_gather_u8_rows": [_P, _P, _P, _P, _I, _LL, _F],
     "pm_vdvae_blocks_fwd": [_P, C.POINTER(VdvaeBlockIO), _I, _I, _I, _I, _I, _I],
     "pm_vdvae_blocks_bwd": [_P, C.POINTER(VdvaeBlockIO), _I, _I, _I, _I, _I, _I],
+    "pm_vade_prior_fwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_vade_prior_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_vade_cluster_probs": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I],
     "pm_graph_begin": [_P],
     "pm_graph_end": [_P, C.POINTER(_P)],
     "pm_graph_launch": [_P, _P],

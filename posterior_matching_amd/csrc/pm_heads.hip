@@ -377,16 +377,19 @@ __global__ __launch_bounds__(256) void argmm_input_bwd_kernel(const float* __res
 
 constexpr int GMM_MAXC = 16;
 
-// one thread per (example b, latent dim i); k lanes of a wave hold one example (k power of two <= 64)
+// one thread per (example b, latent dim i); kp = k rounded up to a power of two lanes of a wave hold one example (k <= 64; the
+// lanes i >= k of a group only take part in the shuffles: configs/pm_vade_mnist.py has latent_dim = 10)
 template <bool BWD>
 __global__ __launch_bounds__(256) void gmm_logprob_kernel(const float* __restrict__ head, const float* __restrict__ z,
                                                             const float* __restrict__ g, float* __restrict__ mll,
                                                             float* __restrict__ dhead, float* __restrict__ dz, int B,
-                                                            int k, int nc, int accumulate_dz) {
+                                                            int k, int kp, int nc, int accumulate_dz) {
     long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = idx < (long long)B * k;
-    int b = ok ? (int)(idx / k) : 0;
-    int i = ok ? (int)(idx - (long long)b * k) : 0;
+    const long long bb = idx / kp;
+    const int ii = (int)(idx - bb * kp);
+    const bool ok = bb < B && ii < k;
+    int b = ok ? (int)bb : 0;
+    int i = ok ? ii : 0;
     const float* hrow = head + ((size_t)i * B + b) * 3 * nc;
     const float zi = z[(size_t)b * k + i];
     float term[GMM_MAXC];
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void gmm_logprob_kernel(const float* __restric
     float lpv = mx + logf(se);
     if (!BWD) {
         float v = ok ? lpv : 0.f;
-        for (int o = k >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        for (int o = kp >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (ok && i == 0) mll[b] = v;
         return;
     }
@@ -536,25 +539,32 @@ extern "C" int pm_argmm_input_bwd(pm_stream_t stream, const float* dinp, float* 
 }
 
 static bool gmm_shape_ok(int B, int k, int nc) {
-    return B > 0 && k > 0 && k <= 64 && (k & (k - 1)) == 0 && nc > 0 && nc <= GMM_MAXC;
+    return B > 0 && k > 0 && k <= 64 && nc > 0 && nc <= GMM_MAXC;
+}
+static int gmm_pow2(int k) {
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    return kp;
 }
 
 extern "C" int pm_gmm_logprob_fwd(pm_stream_t stream, const float* head, const float* z, float* mll, int B, int k,
                                   int nc) {
     if (!head || !z || !mll || !gmm_shape_ok(B, k, nc)) return PM_EINVAL;
-    long long total = (long long)B * k;
+    const int kp = gmm_pow2(k);
+    long long total = (long long)B * kp;
     hipLaunchKernelGGL(gmm_logprob_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, head, z, (const float*)nullptr, mll, (float*)nullptr, (float*)nullptr, B, k,
-                       nc, 0);
+                       kp, nc, 0);
     return pm_check_launch("pm_gmm_logprob_fwd");
 }
 
 extern "C" int pm_gmm_logprob_bwd(pm_stream_t stream, const float* head, const float* z, const float* g, float* dhead,
                                   float* dz, int B, int k, int nc, int accumulate_dz) {
     if (!head || !z || !g || !dhead || !gmm_shape_ok(B, k, nc)) return PM_EINVAL;
-    long long total = (long long)B * k;
+    const int kp = gmm_pow2(k);
+    long long total = (long long)B * kp;
     hipLaunchKernelGGL(gmm_logprob_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, head, z, g, (float*)nullptr, dhead, dz, B, k, nc, accumulate_dz);
+                       (hipStream_t)stream, head, z, g, (float*)nullptr, dhead, dz, B, k, kp, nc, accumulate_dz);
     return pm_check_launch("pm_gmm_logprob_bwd");
 }
 

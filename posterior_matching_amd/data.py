@@ -25,7 +25,7 @@ class SyntheticDataset:
 
     def __init__(self, config: Mapping, batch_size: int, num_batches: int = 64, seed: int = 0, device="cpu",
                  training: bool = True, arrays: Optional[np.ndarray] = None, normalize_images: bool = True,
-                 device_masks: bool = False):
+                 device_masks: bool = False, labels=None):
         """device_masks: draw a FRESH mask for every yielded batch on the GPU (masking.DeviceMaskGenerator, SURVEY.md
         8(f)-1) instead of cycling the masks generated on the host with the pool."""
         rng = np.random.default_rng(seed)
@@ -56,6 +56,10 @@ class SyntheticDataset:
                 if training and "training_noise" in config:          # utils.py:108-116
                     x = x + rng.normal(scale=config["training_noise"], size=x.shape).astype(np.float32)
             batch = {self.key: torch.from_numpy(x).to(device)}
+            if labels is not None:          # "label" of the tfds examples (train_vade.py:105-108): an int array aligned with
+                # `arrays`, or True for synthetic class labels 0..9
+                lab = labels[idx] if (arrays is not None and not isinstance(labels, bool)) else rng.integers(0, 10, size=batch_size)
+                batch["label"] = torch.from_numpy(np.asarray(lab, dtype=np.int64))
             if gen is not None:
                 mshape = (batch_size,) + shape
                 batch["mask"] = torch.from_numpy(np.ascontiguousarray(gen(mshape))).to(device)
@@ -159,13 +163,15 @@ class DeviceUint8Dataset:
 
 
 def make_dataset(config: Mapping, batch_size: int, num_batches: int, seed: int, device, training: bool = True, arrays=None,
-                 normalize_images: bool = True, device_masks: bool = False):
+                 normalize_images: bool = True, device_masks: bool = False, labels=None):
     """What the train scripts call: a uint8 image .npy stays in HBM as uint8 (DeviceUint8Dataset); anything else (float
     arrays, feature tables, no array at all) goes through SyntheticDataset's pre-generated pool."""
-    if arrays is not None and getattr(arrays, "dtype", None) == np.uint8 and arrays.ndim == 4:
+    if arrays is not None and getattr(arrays, "dtype", None) == np.uint8 and arrays.ndim == 4 and labels is None:
         return DeviceUint8Dataset(config, arrays, batch_size, seed, device, normalize_images, training)
+    if arrays is not None and getattr(arrays, "dtype", None) == np.uint8:
+        arrays = arrays.astype(np.float32) / (255.0 if normalize_images else 1.0)
     return SyntheticDataset(config, batch_size, num_batches, seed, device, training=training, arrays=arrays,
-                            normalize_images=normalize_images, device_masks=device_masks)
+                            normalize_images=normalize_images, device_masks=device_masks, labels=labels)
 
 
 def load_datasets(config: Mapping, device="cpu", seed: int = 0, num_batches: int = 64):

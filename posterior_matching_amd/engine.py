@@ -572,3 +572,159 @@ class VDVAETrainStep(_PlannedStep):
         self.swap_in_ema()
         out.pop("grad_norm", None)
         return out
+
+
+class VADETrainStep(_PlannedStep):
+    """train_vade.py as launch sequences: `mode="pretrain"` is pretrain_loss_fn (:45-49: loss = -mean decoder(encoder(x).mean())
+    .log_prob(x)) under optax.adam(pretrain_lr); `mode="elbo"` is loss_fn (:51-55: loss = -mean VADE.elbo(x)) under
+    optax.chain(scale_by_adam(**adam), scale_by_schedule(exponential_decay), scale(-1)).  eps -> forward -> loss -> backward ->
+    [gradient all-reduce] -> Adam -> step += 1; one stream (the model is one chain)."""
+
+    def __init__(self, model, optimizer: Chain, batch_size: int, x_shape, mode: str = "elbo", seed: int = 0,
+                 world_size: int = 1, rank: int = 0, external_eps: bool = False, use_plan: bool = True):
+        if mode not in ("pretrain", "elbo"):
+            raise ValueError(mode)
+        if model.store is None:
+            model.init(x_shape)
+        dev = model.store.device
+        self.model, self.mode, self.B, self.seed, self.rank, self.world_size = model, mode, batch_size, seed, rank, world_size
+        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.adam_cfg.zero_grad = 1
+        # a new Trainer = a fresh optimizer state (train_vade.py builds one for pre-training and another for the ELBO phase on the
+        # same model): the store's Adam moments restart from zero
+        ops.fill_zero(model.store.flat_m)
+        ops.fill_zero(model.store.flat_v)
+        self.reducer = _make_reducer(model.store, world_size, False)
+        self.x = torch.zeros((batch_size,) + tuple(x_shape), device=dev)
+        self.eps = torch.zeros((batch_size, model.latent_dim), device=dev)
+        self.external_eps = external_eps
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.metrics = torch.zeros(8, device=dev)
+        self.g = torch.zeros(batch_size, device=dev)
+        self.use_plan = use_plan
+        self.stream = _step_stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+
+    def _sequence(self) -> None:
+        m, s = self.model, self.model.store
+        if self.mode == "elbo":
+            if not self.external_eps:
+                ops.normal_fill(self.eps, self.seed, self.step_dev, stream_id=self.rank)
+            value = m.elbo(self.x, self.eps, is_training=True)
+        else:
+            value = m.reconstruction_ll_at_mean(self.x, is_training=True)
+        ops.neg_mean_loss(value, 1.0 / self.B, self.metrics, self.g)        # loss = -mean(value); g = d loss / d value
+        self._zero_grad(s)
+        if self.mode == "elbo":
+            m.backward_elbo(self.g)
+        else:
+            m.backward_reconstruction_at_mean(self.g)
+        if self.reducer is not None:
+            self.reducer.finish()
+        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._grads_consumed(s)
+        s.split_all()
+        ops.counter_increment(self.step_dev)
+
+    def step(self) -> None:
+        with torch.cuda.stream(self.stream):
+            self._planned(self._sequence)
+
+    def set_batch(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+            if eps is not None:
+                self.eps.copy_(eps, non_blocking=True)
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def read_metrics(self) -> Dict[str, float]:
+        self.stream.synchronize()
+        return {"loss": self.metrics[0].item()}
+
+    def evaluate(self, x: torch.Tensor) -> Dict[str, float]:
+        """loss_fn with is_training=False on a validation batch (fresh posterior noise)"""
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(self.stream):
+            m = self.model
+            x = x.reshape((x.shape[0],) + tuple(self.x.shape[1:])).contiguous()
+            value = m.elbo(x, None, seed=self.seed + 104729) if self.mode == "elbo" else m.reconstruction_ll_at_mean(x)
+            metrics = torch.zeros(8, device=x.device)
+            ops.neg_mean_loss(value, 1.0 / x.shape[0], metrics, None)
+        self.stream.synchronize()
+        return {"loss": metrics[0].item()}
+
+
+class PMVADETrainStep(_PlannedStep):
+    """train_pm_vade.py:40-83 as one launch sequence: z ~ q(z | x) of the frozen VaDE encoder, loss = -mean log q(z | x_o) of the
+    partial encoder; backward through the partial encoder and its distribution only (trainable_predicate: "partial_" in
+    module_name - they live on model.partial_store, the only buffer the optimizer touches); Adam with the exponential-decay
+    schedule; step += 1."""
+
+    def __init__(self, model, optimizer: Chain, batch_size: int, x_shape, seed: int = 0, world_size: int = 1, rank: int = 0,
+                 external_eps: bool = False, use_plan: bool = True):
+        if model.store is None:
+            model.init(x_shape)
+        dev = model.store.device
+        self.model, self.store = model, model.partial_store
+        self.B, self.seed, self.rank, self.world_size = batch_size, seed, rank, world_size
+        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.adam_cfg.zero_grad = 1
+        self.reducer = _make_reducer(self.store, world_size, False)
+        x_shape = tuple(x_shape)
+        b_shape = x_shape[:-1] + (1,) if len(x_shape) == 3 else x_shape
+        self.x = torch.zeros((batch_size,) + x_shape, device=dev)
+        self.b = torch.zeros((batch_size,) + b_shape, device=dev)
+        self.eps = torch.zeros((batch_size, model.latent_dim), device=dev)
+        self.external_eps = external_eps
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.metrics = torch.zeros(8, device=dev)
+        self.g = torch.zeros(batch_size, device=dev)
+        self.use_plan = use_plan
+        self.stream = _step_stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+
+    def _sequence(self) -> None:
+        m, s = self.model, self.store
+        if not self.external_eps:
+            ops.normal_fill(self.eps, self.seed, self.step_dev, stream_id=self.rank)
+        ll = m.posterior_matching_ll(self.x, self.b, self.eps, is_training=True)
+        ops.neg_mean_loss(ll, 1.0 / self.B, self.metrics, self.g)
+        self._zero_grad(s)
+        m.backward_posterior_matching_ll(self.g)
+        if self.reducer is not None:
+            self.reducer.finish()
+        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._grads_consumed(s)
+        s.split_all()
+        ops.counter_increment(self.step_dev)
+
+    def step(self) -> None:
+        with torch.cuda.stream(self.stream):
+            self._planned(self._sequence)
+
+    def set_batch(self, x: torch.Tensor, b: torch.Tensor, eps: Optional[torch.Tensor] = None) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+            self.b.copy_(b.reshape(self.b.shape), non_blocking=True)
+            if eps is not None:
+                self.eps.copy_(eps, non_blocking=True)
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def read_metrics(self) -> Dict[str, float]:
+        self.stream.synchronize()
+        return {"loss": self.metrics[0].item()}
+
+    def evaluate(self, x: torch.Tensor, b: torch.Tensor) -> Dict[str, float]:
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(self.stream):
+            ll = self.model.posterior_matching_ll(x.contiguous(), b.contiguous(), None, seed=self.seed + 104729)
+            metrics = torch.zeros(8, device=x.device)
+            ops.neg_mean_loss(ll, 1.0 / x.shape[0], metrics, None)
+        self.stream.synchronize()
+        return {"loss": metrics[0].item()}

@@ -216,6 +216,45 @@ class DiagonalGaussian(_LinearHead):
         ops.diag_gaussian_logprob_bwd(self._prm, self._z, g, dprm, dz)
         return self._linear_bwd(dprm)
 
+    # -- VaDE's encoder (vade.py:60-62, 128-140): a sample AND the density of that sample under the same parameters
+    def sample_and_log_prob(self, feat: Feat, eps: torch.Tensor):
+        """z = loc + scale * eps and log q(z | x) [B] (posterior.sample(...), posterior.log_prob(z))"""
+        z, _ = self.sample_and_kl(feat, eps)
+        self._z = z
+        lq = self.buf("lq", (z.shape[0],))
+        ops.diag_gaussian_logprob_fwd(self._prm, z, lq)
+        return z, lq
+
+    def backward_sample_log_prob(self, dz: torch.Tensor, g_lq: torch.Tensor) -> torch.Tensor:
+        """dz: gradient w.r.t. the sample from its other consumers; g_lq [B]: d loss / d log q.  The density's gradient has
+        an explicit part (parameters) and a part through z = loc + scale * eps; both go through the existing kernels."""
+        dprm = self.buf("dparams", self._prm.shape)
+        dz_q = self.buf("dz_lq", self._z.shape)
+        ops.diag_gaussian_logprob_bwd(self._prm, self._z, g_lq, dprm, dz_q)          # explicit part, d log q / dz
+        ops.axpy1(dz, dz_q)                                                          # total d loss / dz
+        dprm_z = self.buf("dparams_z", self._prm.shape)
+        zero = self.buf("zero_b", (dz.shape[0],))
+        ops.fill_zero(zero)
+        ops.diag_gaussian_sample_kl_bwd(self._prm, self._eps, dz_q, zero, dprm_z)    # through the reparameterisation
+        ops.axpy1(dprm_z, dprm)
+        return self._linear_bwd(dprm)
+
+    def mean(self, feat: Feat) -> torch.Tensor:
+        """posterior.mean() = loc [B, k] (train_vade.py:47, 65)"""
+        prm = self._linear_fwd(feat)
+        self._prm = prm
+        k = self._event_size
+        loc, zero = self.buf("loc", (prm.shape[0], k)), self.buf("zero_loc", (prm.shape[0], k))
+        ops.fill_zero(zero)
+        ops.add_cols(zero, prm, 0, loc)                                              # loc = prm[:, :k]
+        return loc
+
+    def backward_mean(self, dloc: torch.Tensor) -> torch.Tensor:
+        dprm = self.buf("dparams", self._prm.shape)
+        ops.fill_zero(dprm)
+        ops.copy_cols(dloc, dprm, 0)
+        return self._linear_bwd(dprm)
+
     # -- evaluation paths (vae.py:146-226): S samples per example, rows b*S + s
     def sample_n(self, feat: Feat, eps: torch.Tensor, S: int, tag: str):
         """eps [B*S, k] -> (z [B*S, k], repeated head parameters for log_prob_n)"""

@@ -1235,6 +1235,23 @@ def pmvae_loss(rec, kl, mll, cfg: _lib.LossCfg, step_dev, out, g_rec, g_kl, g_ml
     _call("pm_pmvae_loss", _ptr(rec), _ptr(kl), _ptr(mll), rec.shape[0], C.byref(cfg), _iptr(step_dev), _ptr(out), _ptr(g_rec), _ptr(g_kl), _ptr(g_mll))
 
 
+# ---- VaDE mixture prior (reference vade.py) -----------------------------------------------------------------------------
+def vade_prior_fwd(z, mu, log_scale, logits, lp) -> None:
+    C_, k = mu.shape
+    _call("pm_vade_prior_fwd", _ptr(z), _ptr(mu), _ptr(log_scale), _ptr(logits), _ptr(lp), z.numel() // k, k, C_)
+
+
+def vade_prior_bwd(z, mu, log_scale, logits, g, dz, dmu, dlog_scale, dlogits) -> None:
+    C_, k = mu.shape
+    _call("pm_vade_prior_bwd", _ptr(z), _ptr(mu), _ptr(log_scale), _ptr(logits), _ptr(g), _ptr(dz), _ptr(dmu), _ptr(dlog_scale),
+          _ptr(dlogits), z.numel() // k, k, C_)
+
+
+def vade_cluster_probs(z, mu, log_scale, logits, probs, S: int) -> None:
+    C_, k = mu.shape
+    _call("pm_vade_cluster_probs", _ptr(z), _ptr(mu), _ptr(log_scale), _ptr(logits), _ptr(probs), z.numel() // k // S, S, k, C_)
+
+
 def pmvae_loss_grads(B: int, cfg: _lib.LossCfg, step_dev, g_rec, g_kl, g_mll) -> None:
     """only the upstream gradients of pm_pmvae_loss (functions of the step counter, not of the forward pass)"""
     _call("pm_pmvae_loss", None, None, None, B, C.byref(cfg), _iptr(step_dev), None, _ptr(g_rec), _ptr(g_kl), _ptr(g_mll))

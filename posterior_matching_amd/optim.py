@@ -22,7 +22,9 @@ class ExponentialDecay:
         return self.init_value * self.decay_rate ** (count / self.transition_steps)
 
 
-def exponential_decay(init_value, transition_steps, decay_rate, **unsupported) -> ExponentialDecay:
+def exponential_decay(init_value, transition_steps, decay_rate, staircase=False, **unsupported) -> ExponentialDecay:
+    if staircase:                                   # configs/vade_mnist.py passes staircase=False explicitly
+        unsupported["staircase"] = staircase
     if unsupported:
         raise NotImplementedError(f"exponential_decay options {sorted(unsupported)} have no HIP path")
     return ExponentialDecay(float(init_value), float(transition_steps), float(decay_rate))

@@ -16,7 +16,7 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional
 import torch
 
 from . import ops
-from .engine import PMVAETrainStep, PMVQVAETrainStep, VDVAETrainStep, VQVAETrainStep
+from .engine import PMVADETrainStep, PMVAETrainStep, PMVQVAETrainStep, VADETrainStep, VDVAETrainStep, VQVAETrainStep
 from .models.vae import PosteriorMatchingVAE
 from .models.vqvae import VQVAE
 from .optim import Chain
@@ -143,6 +143,62 @@ class VDVAELoss:
         return aux.pop("loss"), aux
 
 
+class VADEPretrainLoss:
+    """pretrain_loss_fn of train_vade.py:45-49: loss = -mean decoder(encoder(x).mean()).log_prob(x), aux = {}.  Lowered to
+    engine.VADETrainStep(mode="pretrain") by Trainer; callable like the reference's function."""
+
+    mode = "pretrain"
+
+    def __init__(self, config: Mapping[str, Any], model, data_key: str = "image", seed: int = 0):
+        self.config, self.model, self.data_key, self.seed = config, model, data_key, seed
+
+    def _value(self, step, is_training, x):
+        return self.model.reconstruction_ll_at_mean(x, is_training=bool(is_training))
+
+    def __call__(self, step, is_training, batch):
+        m = self.model
+        x = batch[self.data_key]
+        if m.store is None:
+            m.init(tuple(x.shape[1:]), seed=self.seed)
+        x = x.to(m.store.device).float().contiguous()
+        metrics = torch.zeros(8, device=m.store.device)
+        ops.neg_mean_loss(self._value(step, is_training, x), 1.0 / x.shape[0], metrics, None)
+        return metrics[0], {}
+
+
+class VADELoss(VADEPretrainLoss):
+    """loss_fn of train_vade.py:51-55: loss = -mean VADE.elbo(x), aux = {} (posterior noise: device Philox keyed by (seed, step))"""
+
+    mode = "elbo"
+
+    def _value(self, step, is_training, x):
+        m = self.model
+        eps = torch.empty((x.shape[0], m.latent_dim), device=x.device)
+        ops.normal_fill(eps, self.seed, _step_counter(step, x.device), stream_id=0)
+        return m.elbo(x, eps, is_training=bool(is_training))
+
+
+class PMVADELoss:
+    """loss_fn of train_pm_vade.py:40-43: loss = -mean PosteriorMatchingVADE.posterior_matching_ll(x, mask), aux = {}.  Lowered
+    to engine.PMVADETrainStep by Trainer (only the "partial_" modules train, :59-60); callable."""
+
+    def __init__(self, config: Mapping[str, Any], model, data_key: str = "image", seed: int = 0):
+        self.config, self.model, self.data_key, self.seed = config, model, data_key, seed
+
+    def __call__(self, step, is_training, batch):
+        m = self.model
+        x = batch[self.data_key]
+        if m.store is None:
+            m.init(tuple(x.shape[1:]), seed=self.seed)
+        dev = m.store.device
+        x, b = x.to(dev).float().contiguous(), batch["mask"].to(dev).float().contiguous()
+        eps = torch.empty((x.shape[0], m.latent_dim), device=dev)
+        ops.normal_fill(eps, self.seed, _step_counter(step, dev), stream_id=0)
+        metrics = torch.zeros(8, device=dev)
+        ops.neg_mean_loss(m.posterior_matching_ll(x, b, eps, is_training=bool(is_training)), 1.0 / x.shape[0], metrics, None)
+        return metrics[0], {}
+
+
 @dataclass
 class TrainState:
     step: int = 0
@@ -186,7 +242,14 @@ class Trainer:
         self.ema_rate, self.skip_nonfinite = ema_rate, skip_nonfinite_updates
         if isinstance(loss_fn, VDVAELoss):     # train_pm_vdvae.py:146-154: the flags the fused VDVAE step implements
             skip_nonfinite_updates, ema_rate, use_ema_for_eval = False, None, False
-        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss, PMVQVAELoss, VDVAELoss)):
+        if isinstance(loss_fn, PMVADELoss):
+            # train_pm_vade.py:59-60: the only predicate the reference uses trains the modules whose name contains "partial_";
+            # that is what PMVADETrainStep does (they live on their own store, the VaDE's is never updated)
+            if trainable_predicate is not None and (trainable_predicate("vade", "mu", None)
+                                                    or not trainable_predicate("partial_encoder_net", "w", None)):
+                raise NotImplementedError("only the reference's predicate ('partial_' in module_name) is lowered")
+            trainable_predicate = None
+        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss, PMVQVAELoss, VDVAELoss, VADEPretrainLoss, PMVADELoss)):
             raise NotImplementedError("Trainer lowers PMVAELoss / VQVAELoss (the loss_fn of train_pm_vae.py / "
                                       "train_vqvae.py) to the fused HIP step; arbitrary Python loss functions have "
                                       "no HIP path")
@@ -206,6 +269,11 @@ class Trainer:
             return TrainState(step=int(ts.step_dev.item()), params={k: v.cpu() for k, v in store.to_dict("p").items()},
                               opt_state={"mu": store.flat_m.cpu(), "nu": store.flat_v.cpu(),
                                          "count": int(ts.opt_count.item())}, ema_params=ema)
+        if isinstance(ts, PMVADETrainStep):      # frozen VaDE + trainable partial encoder in one tree, as in the reference
+            params = {k: v.cpu() for k, v in ts.model.store.to_dict("p").items()}
+            params.update({k: v.cpu() for k, v in ts.store.to_dict("p").items()})
+            return TrainState(step=int(ts.step_dev.item()), params=params,
+                              opt_state={"mu": ts.store.flat_m.cpu(), "nu": ts.store.flat_v.cpu()})
         if isinstance(ts, PMVQVAETrainStep):
             # the reference's TrainState holds frozen and trainable parameters in one tree (vqvae/ prefix, :123)
             params = {f"vqvae/{k}": v.cpu() for k, v in ts.vqvae.params_dict().items()}
@@ -227,6 +295,7 @@ class Trainer:
         first = next(it)
         x0 = first[key]
         B, x_shape = x0.shape[0], tuple(x0.shape[1:])
+        is_vade, is_pmvade = isinstance(lf, VADEPretrainLoss), isinstance(lf, PMVADELoss)
         if model.store is None:                                                              # same init on all ranks
             if isinstance(lf, VDVAELoss):
                 model.init(device=torch.device("cuda", self.local_rank), seed=self.seed)
@@ -242,7 +311,12 @@ class Trainer:
         dev = model.store.device
         is_vq = isinstance(lf, VQVAELoss)
         is_pmvq = isinstance(lf, PMVQVAELoss)
-        if isinstance(lf, VDVAELoss):
+        if is_vade:
+            ts = VADETrainStep(model, self.optimizer, B, x_shape, mode=lf.mode, seed=self.seed, world_size=self.world,
+                               rank=self.rank)
+        elif is_pmvade:
+            ts = PMVADETrainStep(model, self.optimizer, B, x_shape, seed=self.seed, world_size=self.world, rank=self.rank)
+        elif isinstance(lf, VDVAELoss):
             opt = self.optimizer
             from .optim import LinearSchedule
 
@@ -265,7 +339,7 @@ class Trainer:
         callbacks = callbacks or []
         batch = first
         for step in range(steps):
-            if is_vq:
+            if is_vq or is_vade:
                 ts.set_batch(batch[key].to(dev, non_blocking=True))
             else:
                 ts.set_batch(batch[key].to(dev, non_blocking=True), batch["mask"].to(dev, non_blocking=True))
@@ -277,7 +351,7 @@ class Trainer:
                 logs = dict(ts.read_metrics())
                 logs = {f"train_{k}": v for k, v in logs.items()}
                 if val_dataset is not None:
-                    logs.update(self._validate(ts, val_dataset, key, dev))
+                    logs.update(self._validate(ts, val_dataset, key, dev, callbacks))
                 state = self._state(ts)
                 if self.rank == 0:
                     for cb in callbacks:
@@ -289,15 +363,18 @@ class Trainer:
         ts.synchronize()
         return self._state(ts)
 
-    def _validate(self, ts, val_dataset, key: str, dev) -> Dict[str, float]:
-        """loss_fn with is_training=False averaged over the validation batches (bax semantics)."""
+    def _validate(self, ts, val_dataset, key: str, dev, callbacks=()) -> Dict[str, float]:
+        """loss_fn with is_training=False averaged over the validation batches (bax semantics); every callback sees each
+        validation batch first (bax: on_validation_step - the clustering-accuracy callback of train_vade.py collects there)."""
         sums: Dict[str, float] = {}
         n = 0
         batches = getattr(val_dataset, "batches", None) or list(val_dataset)
         for i, vb in enumerate(batches):
-            if isinstance(ts, VQVAETrainStep):
+            for cb in callbacks or ():
+                cb.on_validation_step(None, None, vb)
+            if isinstance(ts, (VQVAETrainStep, VADETrainStep)):
                 out = ts.evaluate(vb[key].to(dev))
-            elif isinstance(ts, (PMVQVAETrainStep, VDVAETrainStep)):
+            elif isinstance(ts, (PMVQVAETrainStep, VDVAETrainStep, PMVADETrainStep)):
                 out = ts.evaluate(vb[key].to(dev), vb["mask"].to(dev))
             else:
                 x, b = vb[key].to(dev), vb["mask"].to(dev)

@@ -127,3 +127,31 @@ def pm_vae_miniboone():
         "steps": 22000, "validation_freq": 1000, "save_final_state": True, "weight_decay": 0.00001,
         "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 1000},
     }
+
+
+def vade_mnist():
+    """configs/vade_mnist.py:4-55 of the reference (VaDE: conv encoder / decoder, 10 latent dimensions, 10 components)."""
+    return {
+        "data": {"dataset": "mnist", "train_split": "train", "validation_split": "test",
+                 "train_batch_size": 128, "val_batch_size": 128},
+        "model": {"encoder_net": "ConvEncoder", "decoder_net": "ConvDecoder", "decoder_dist": "Bernoulli",
+                  "latent_dim": 10, "num_components": 10,
+                  "encoder_net_config": {"conv_layers": [(32, 5, 1), (32, 5, 2), (64, 5, 1), (64, 5, 2), (128, 7, 1)]},
+                  "decoder_net_config": {"conv_layers": [(64, 7, 1), (64, 5, 2), (32, 5, 1), (32, 5, 2), (32, 5, 1), (1, 5, 1)]}},
+        "pretrain_steps": int(60000 / 128 * 150), "steps": int(60000 / 128 * 300), "validation_freq": 1000,
+        "cluster_pred_num_samples": 50, "pretrain_lr": 0.002,
+        "lr_schedule": {"init_value": 0.002, "decay_rate": 0.9, "staircase": False, "transition_steps": int(60000 / 128 * 10)},
+        "adam": {"eps": 1e-4},
+    }
+
+
+def pm_vade_mnist():
+    """configs/pm_vade_mnist.py:4-62 of the reference (partial encoder + AutoregressiveGMM on a frozen VaDE)."""
+    m = dict(vade_mnist()["model"], partial_posterior_dist="AutoregressiveGMM",
+             partial_posterior_dist_config={"num_components": 10, "residual_blocks": 2, "hidden_units": 256})
+    return {
+        "data": {"dataset": "mnist", "train_split": "train", "validation_split": "test",
+                 "train_batch_size": 128, "val_batch_size": 128},
+        "vade_dir": "runs/vade-mnist-20220305-121540", "model": m, "steps": 160000, "validation_freq": 5000,
+        "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "staircase": False, "transition_steps": int(60000 / 128 * 10)},
+    }

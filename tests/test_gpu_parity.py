@@ -279,11 +279,12 @@ def test_bernoulli_and_normal_ll():
     assert rel_err(dloc, lr_.grad) < 2e-6 and rel_err(dls, lsr.grad) < 2e-6
 
 
-def test_gmm_logprob_and_argmm_input():
+@pytest.mark.parametrize("B,k,nc", [(6, 32, 10), (37, 10, 10), (5, 3, 4), (130, 50, 16)])   # k = 10: configs/pm_vade_mnist.py
+def test_gmm_logprob_and_argmm_input(B, k, nc):
     from posterior_matching_amd import ops
 
-    gen = torch.Generator().manual_seed(40)
-    B, k, nc, cd = 6, 32, 10, 128
+    gen = torch.Generator().manual_seed(40 + k)
+    cd = 128
     head, z, g = g32((k * B, 3 * nc), gen), g32((B, k), gen), g32((B,), gen)
     hr, zr = head.clone().requires_grad_(True), z.clone().requires_grad_(True)
     # row i*B+b holds the 30 parameters of latent dim i at step i

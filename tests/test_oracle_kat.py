@@ -606,3 +606,66 @@ def test_expected_info_gains_oracle_properties():
     # everything observed: every gain is -inf
     g1 = O.pm_vae_expected_info_gains(p, cfg["model"], x, torch.ones(8, dtype=torch.float64), noise)
     assert torch.isinf(g1).all()
+
+
+# ----------------------------------------------------------------------------------------------
+# VaDE (oracle/vade_oracle.py; reference models/vade.py, clustering.py)
+# ----------------------------------------------------------------------------------------------
+def _tiny_vade():
+    from oracle import vade_oracle as V
+
+    cfg = {"encoder_net": "ResidualMLP", "decoder_net": "ResidualMLP", "decoder_dist": "IdentityGaussian",
+           "decoder_dist_config": {"event_size": 8}, "latent_dim": 4, "num_components": 3,
+           "encoder_net_config": {"residual_blocks": 1, "hidden_units": 32},
+           "decoder_net_config": {"residual_blocks": 1, "hidden_units": 32},
+           "partial_posterior_dist": "AutoregressiveGMM",
+           "partial_posterior_dist_config": {"num_components": 3, "residual_blocks": 1, "hidden_units": 32}}
+    return V, cfg, V.init_params(cfg, (8,), seed=1, partial=True)
+
+
+def test_vade_elbo_equals_the_mixture_marginal_form():
+    """VADE.elbo written term by term with the responsibilities (vade.py:117-150) == log p(x|z) + log sum_c pi_c p(z|c)
+    - log q(z|x): the identity the HIP path relies on; and the single-component case is a plain diagonal-Gaussian prior."""
+    V, cfg, p = _tiny_vade()
+    g = torch.Generator().manual_seed(0)
+    x, eps = torch.randn((6, 8), generator=g, dtype=torch.float64), torch.randn((6, 4), generator=g, dtype=torch.float64)
+    p["vade/logits"] = torch.tensor([0.3, -1.0, 2.0], dtype=torch.float64)
+    assert torch.allclose(V.elbo(p, cfg, x, eps), V.elbo_marginal_form(p, cfg, x, eps), rtol=1e-12, atol=1e-12)
+    one = dict(cfg, num_components=1)
+    p1 = {k: (v[:1] if k.startswith("vade/") else v) for k, v in p.items()}
+    loc, scale = V.encoder_params(p1, one, x)
+    z = loc + scale * eps
+    prior = torch.distributions.Normal(p1["vade/mu"][0], torch.exp(p1["vade/log_scale"][0])).log_prob(z).sum(-1)
+    want = V.decoder_log_prob(p1, one, z, x) + prior - V.diag_log_prob(z, loc, scale)
+    assert torch.allclose(V.elbo(p1, one, x, eps), want, rtol=1e-12, atol=1e-12)
+
+
+def test_vade_cluster_probabilities_and_matching_ll():
+    V, cfg, p = _tiny_vade()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((5, 8), generator=g, dtype=torch.float64)
+    b = (torch.rand((5, 8), generator=g) < 0.5).double()
+    probs = V.predict_cluster(p, cfg, x, torch.randn((9, 5, 4), generator=g, dtype=torch.float64))
+    assert probs.shape == (5, 3) and torch.allclose(probs.sum(-1), torch.ones(5, dtype=torch.float64)) and (probs >= 0).all()
+    # far-apart, tight components: a sample sitting on component 2's mean is assigned to it
+    p["vade/mu"] = torch.tensor([[10.0] * 4, [-10.0] * 4, [0.0] * 4], dtype=torch.float64)
+    p["vade/log_scale"] = torch.zeros((3, 4), dtype=torch.float64)
+    h = V.component_log_probs(p, torch.zeros((1, 4), dtype=torch.float64)) + V.log_pi(p)
+    assert int(h.argmax()) == 2
+    # posterior_matching_ll: no gradient reaches the VaDE's own parameters (stop_gradient on z, frozen modules)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ll = V.posterior_matching_ll(leaves, cfg, x, b, torch.randn((5, 4), generator=g, dtype=torch.float64))
+    grads = torch.autograd.grad(ll.sum(), list(leaves.values()), allow_unused=True)
+    for (name, _), gr in zip(leaves.items(), grads):
+        assert (gr is None or float(gr.abs().max()) == 0.0) == (not name.startswith("partial_")), name
+
+
+def test_clustering_accuracy_known_answers():
+    """clustering.py:14-37: invariant under relabelling the clusters; one of four points in the wrong cluster -> 0.75"""
+    from oracle import vade_oracle as V
+    from posterior_matching_amd.clustering import clustering_accuracy
+
+    for fn in (V.clustering_accuracy, clustering_accuracy):
+        assert fn([0, 0, 1, 1, 2, 2], [1, 1, 2, 2, 0, 0]) == 1.0
+        assert fn([0, 0, 1, 1], [0, 1, 1, 1]) == 0.75
+        assert fn([3, 3, 7, 7, 7], [0, 0, 0, 1, 1]) == 0.8
