@@ -377,11 +377,21 @@ class PMVQVAETrainStep(_PlannedStep):
         return self.store.num_params
 
     def forward(self, is_training: bool) -> torch.Tensor:
-        out = self.vqvae(self.x, is_training=False)                       # frozen: no EMA update, no gradient
-        idx = out["vq_output"]["encoding_indices"]
+        # frozen VQ-VAE (no EMA update, no gradient): only its code indices are read, and they do not depend on the partial
+        # encoder - the two run side by side (the frozen encoder on the PixelCNN's second stream)
         xob = self.ws.get("x_o_b", tuple(self.x.shape[:-1]) + (self.x.shape[-1] + self.b.shape[-1],))
+        side = None if os.environ.get("PM_PX_SERIAL_HEAD") else self.pcnn.side_stream(self.x.device)
+        if side is None:
+            idx = self.vqvae.encoding_indices(self.x)
+        else:
+            main = torch.cuda.current_stream(self.x.device)
+            ops.wait_stream(side, main)
+            with torch.cuda.stream(side):
+                idx = self.vqvae.encoding_indices(self.x)
         ops.mask_concat(self.x, self.b, xob)
         cond = self.penc(xob, is_training=is_training)
+        if side is not None:
+            ops.wait_stream(main, side)
         masks = self.dropout_masks if (self.external_dropout and is_training) else None
         ll = self.pcnn.log_prob(idx, training=is_training, conditional_input=cond, dropout_masks=masks,
                                 seed=self.seed + self.rank, step_dev=self.step_dev)
@@ -408,8 +418,22 @@ class PMVQVAETrainStep(_PlannedStep):
             self._wgrad_batch.reducer = self.reducer
             self.ws.wgrad_batch = self._wgrad_batch
         try:
-            dcond = self.pcnn.backward(self.g_ll)
-            self.penc.backward(dcond)
+            # the PixelCNN's grouped weight gradients (3 ms of chip-filling launches at the mnist size) start on the main stream
+            # as soon as its data gradients are done; the latency-bound rest of the pass (embedding scatter, conditional
+            # projection, the partial encoder's chain) runs beside them on the second stream
+            tail = batched and not self.reducer and not os.environ.get("PM_PX_SERIAL_TAIL")
+            dcond = self.pcnn.backward(self.g_ll, overlap_tail=tail)
+            ts = self.pcnn.tail_stream if tail else None
+            if ts is not None:
+                self.ws.wgrad_stream = ts               # a weight gradient that cannot join a grouped launch stays on `ts`
+                try:
+                    with torch.cuda.stream(ts):
+                        self.penc.backward(dcond)
+                finally:
+                    self.ws.wgrad_stream = None
+                ops.wait_stream(torch.cuda.current_stream(self.x.device), ts)
+            else:
+                self.penc.backward(dcond)
             if batched:
                 self.ws.wgrad_batch.flush()
         finally:

@@ -211,10 +211,7 @@ class PixelCNN(Module):
         two = self.two_streams and not os.environ.get("PM_PIXELCNN_ONE_STREAM")
         vs = main
         if two:
-            if getattr(self, "_vstream", None) is None:
-                self._vstream = torch.cuda.Stream(device=value.device)
-                self._vev = [torch.cuda.Event() for _ in range(2 * nres)]
-            vs = self._vstream
+            vs = self.side_stream(value.device)
             ops.wait_stream(vs, main)                           # embeddings, v_init, conditional projections
 
         def vblock(k, blk, *args, **kw):
@@ -240,12 +237,33 @@ class PixelCNN(Module):
                 ops.wait_event(main, self._vev[nres + i])
             up_h = run_block(self.blocks[2 * nres + 2 * i + 1], up_h, extra_a=up_v, extra_b=Hs.pop())
         self._up_h = up_h
+        self._slab_zeroed = None
+        if two and training and not os.environ.get("PM_NO_GRAD_SLAB") and not os.environ.get("PM_PX_LATE_SLAB_ZERO"):
+            # the backward pass's gradient accumulators (one slab) are zeroed here, on the second stream, which has finished
+            # its chain while the main stream still runs the last horizontal block, the output layer and the loss
+            n_zero = getattr(self, "_gslab_used", {}).get(B)
+            if n_zero:
+                if getattr(self, "_zev", None) is None:
+                    self._zev = torch.cuda.Event()
+                with torch.cuda.stream(vs):
+                    ops.fill_zero(self.buf("grad_slab", (2 * len(self.blocks) + 4,) + sh(F))[:n_zero])
+                    ops.record_event(self._zev, vs)
+                self._slab_zeroed = (B, n_zero)
         x_out = self.buf("x_out", sh(F))
         ops.elu_fwd(up_h, x_out)
         logits = self.buf("logits", sh(K))
         self._fwd(self.out_conv, x_out, logits)
         self._emb, self._v0, self._h0 = emb, self.buf("v_init", sh(F)), self.buf("h_init", sh(F))
         return logits
+
+    def side_stream(self, device) -> Optional["torch.cuda.Stream"]:
+        """the second stream of the two-chain schedule (None when the network runs on one stream)"""
+        if not self.two_streams or os.environ.get("PM_PIXELCNN_ONE_STREAM"):
+            return None
+        if getattr(self, "_vstream", None) is None:
+            self._vstream = torch.cuda.Stream(device=device)
+            self._vev = [torch.cuda.Event() for _ in range(2 * self._num_resnet)]
+        return self._vstream
 
     def log_prob(self, value: torch.Tensor, training: bool = False, conditional_input: Optional[torch.Tensor] = None,
                  dropout_masks=None, seed: int = 0, step_dev=None) -> torch.Tensor:
@@ -341,9 +359,12 @@ class PixelCNN(Module):
             self.ws.join_aux()
             self.store.grads_ready([f"{self.prefix}/{n}/{leaf}" for leaf in ("conv1", "linear", "conv2")])
 
-    def backward(self, g_ll: torch.Tensor) -> Optional[torch.Tensor]:
+    def backward(self, g_ll: torch.Tensor, overlap_tail: bool = False) -> Optional[torch.Tensor]:
         """g_ll [B] = d loss / d log_prob.  Accumulates parameter gradients; returns d loss / d
-        conditional_input [B, cond_dim] (None without conditioning)."""
+        conditional_input [B, cond_dim] (None without conditioning).  overlap_tail (grouped weight gradients + two chains
+        only): the queued weight gradients are launched on the current stream once the blocks' data gradients are done, and
+        the rest of the pass - with the returned tensor - is issued on `self.tail_stream`, which the caller must join."""
+        self.tail_stream = None
         H, W = self._event_shape
         F, K = self._num_filters, self._num_indices
         B = self._B
@@ -369,6 +390,9 @@ class PixelCNN(Module):
         n_zero = getattr(self, "_gslab_used", {}).get(B, cap)       # entries the previous pass of this batch size handed out
         if os.environ.get("PM_NO_GRAD_SLAB"):                       # A/B switch: one zero-fill launch per accumulator, at first use
             n_zero = 0
+        elif getattr(self, "_slab_zeroed", None) == (B, n_zero):    # done by the forward pass on the second stream
+            ops.wait_event(torch.cuda.current_stream(dlogits.device), self._zev)
+            self._slab_zeroed = None
         else:
             ops.fill_zero(slab[:n_zero])
 
@@ -452,6 +476,16 @@ class PixelCNN(Module):
         self._wg(self.v_init, emb, dv0)
         self._wg(self.h_up, emb, dh0)
         self._wg(self.h_left, emb, dh0)
+        if overlap_tail and two and fs is None:
+            self.tail_stream = vs
+            ops.wait_stream(vs, main)
+            self.ws.wgrad_batch.flush()                      # main: every convolution's weight gradient of this network
+            with torch.cuda.stream(vs):
+                return self._backward_tail(dv0, dh0, dh_all, used, sh, B, F, G)
+        return self._backward_tail(dv0, dh0, dh_all, used, sh, B, F, G)
+
+    def _backward_tail(self, dv0, dh0, dh_all, used, sh, B: int, F: int, G: int) -> Optional[torch.Tensor]:
+        """input convolutions' data gradients -> embedding table gradient; conditional projection's gradients"""
         de1, de2 = self.buf("demb1", sh(F)), self.buf("demb2", sh(F))
         self._dg(self.v_init, dv0, de1)
         self._dg(self.h_up, dh0, de2, res=de1)

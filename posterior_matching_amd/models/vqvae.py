@@ -436,6 +436,19 @@ class VQVAE(Module):
         return _LazyDict({"scale": lambda: torch.exp(log_scale) + ConvResidualDecoder.SCALE_EPS},
                          loss=m[0], vq_output=vq_out, z=z, reconstruction=loc, reconstruction_loss=m[1], ll=ll)
 
+    def encoding_indices(self, inputs: torch.Tensor) -> torch.Tensor:
+        """`self(inputs, is_training=False)["vq_output"]["encoding_indices"]` without the decoder and the losses (what XLA's
+        dead-code elimination leaves of the frozen model in train_pm_vqvae.py:81-86): encoder -> pre_vq -> nearest code."""
+        if self.store is None:
+            self.init(inputs.shape[1:], inputs.device)
+        B = inputs.shape[0]
+        feat = self.encoder(Feat(inputs), is_training=False)
+        g = self.pre_vq.g
+        z = self.buf("z", (B, g.OH, g.OW, g.CO))
+        ops.layer_forward(g, feat.t, self.store.p[self.pre_vq.w], self.store.p[self.pre_vq.b], z, in_act=feat.in_act,
+                          wsplit=self.store.split_view(self.pre_vq.ws_f))
+        return self.vq(z, False)["encoding_indices"]
+
     def backward(self) -> None:
         """Accumulates d loss / d params of the last is_training=True call into the flat gradient
         buffer (zero it first).  Straight-through estimator: d/dz = d/dquantize + commitment term."""
