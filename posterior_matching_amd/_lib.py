@@ -102,6 +102,8 @@ SIGNATURES = {
     "pm_gather_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
     "pm_gather_gemm_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
     "pm_gather_gemm_bf16_dual": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P, _P, _I],
+    "pm_gather_gemm_bf16_insum": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P, _P],
+    "pm_image_conv_insum_applies": [C.POINTER(GatherDesc)],
     "pm_split_weights": [_P, _P, _P, _P, _I, _I],
     "pm_gather_wgrad_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
     "pm_gather_wgrad_table": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _I, _I],

@@ -49,6 +49,7 @@ struct GemmArgs {
     int ksplit;
     float* out2;   // optional second store: out2 = act2(out) (a layer's pre-activation AND its activation in one launch)
     int act2;
+    float* in_colsum;   // image-resident form only: in_colsum[c] += sum over every position of in[.., c] (a bias gradient)
 };
 
 struct WgradArgs {
@@ -1734,7 +1735,8 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         const bool in_relu = g.in_act == PM_ACT_RELU;
         const float in_ns = g.in_act == PM_ACT_LEAKY ? g.slope : 1.f;
         constexpr int PB = NW == 8 ? 13 : 8;                             // 28 x 28 x 32 on 512 threads: 12.25 per thread
-        for (int e0 = tid; e0 < total; e0 += 64 * NW * PB) {
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};                               // in_colsum: this thread's channel quad never changes
+        for (int e0 = tid; e0 < total; e0 += 64 * NW * PB) {             // (c4n divides 64: the launcher checks)
             f32x4 v[PB];
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
@@ -1746,6 +1748,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
                 const int e = e0 + 64 * NW * j;
                 const int ee = e < total ? e : total - 1;               // the overhang rewrites the last piece: harmless
                 const int pos = ee / c4n, c4 = ee - pos * c4n;
+                if (e < total) csum += v[j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float x = v[j][q];
@@ -1757,6 +1760,13 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
                 *reinterpret_cast<u32x2*>(Ph + pos * PS + 4 * c4) = h2;
                 *reinterpret_cast<u32x2*>(Pl + pos * PS + 4 * c4) = l2;
             }
+        }
+        if (p.in_colsum) {           // lanes l, l + c4n, ... of a wave hold the same channel quad: one row of sums per wave
+            for (int o = c4n; o < 64; o <<= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) csum[q] += __shfl_xor(csum[q], o, 64);
+            float* cs = reinterpret_cast<float*>(Pl + (size_t)npos * PS + 64);
+            if (lane < c4n) *reinterpret_cast<f32x4*>(cs + wave * g.C + 4 * lane) = csum;
         }
     }
 
@@ -1778,6 +1788,13 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     __syncthreads();                 // image visible; the only barrier of the kernel
+    if (p.in_colsum && tid < g.C) {  // the image's channel sums (the NW waves' rows) -> one atomic per channel and image
+        const float* cs = reinterpret_cast<const float*>(Pl + (size_t)npos * PS + 64);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += cs[w * g.C + tid];
+        atomicAdd(p.in_colsum + tid, t);
+    }
 
     // A fragments run TWO (k-step, row tile) items ahead of the MFMAs in four static register sets (item index mod 4); the
     // tap walk (ky, kx, channel chunk) of the three k-steps in flight is kept in scalar registers - with the table lookup
@@ -1926,7 +1943,9 @@ void launch_image_tr(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, cons
         attr = true;
     }
     PM_KTAG("image_conv_bf16_kernel<%d, %d, %s>", NW, T, TR ? "true" : "false");
-    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T, TR>), dim3((unsigned)a.g.B), dim3(64 * NW), ip.lds, s, a, ws, npad, plane,
+    if (a.in_colsum) PM_KVAR("insum");
+    const size_t lds = ip.lds + (a.in_colsum ? (size_t)NW * a.g.C * sizeof(float) : 0);
+    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T, TR>), dim3((unsigned)a.g.B), dim3(64 * NW), lds, s, a, ws, npad, plane,
                        ip.nct);
 }
 template <int NW, int T>
@@ -3715,7 +3734,7 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
     GemmArgs a;
     if (!fill_geom(d, a.g, true) || !in || !w || !out) return PM_EINVAL;
     a.in = in; a.w = w; a.bias = bias; a.aux = aux; a.res = res; a.out = out;
-    a.out2 = nullptr; a.act2 = PM_ACT_NONE;
+    a.out2 = nullptr; a.act2 = PM_ACT_NONE; a.in_colsum = nullptr;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
     const bool vec4 = (d->C % 4 == 0) && aligned16(in) && (d->in_gs % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
@@ -3798,10 +3817,18 @@ extern "C" int pm_query_wgrad_plan(const pm_gather_desc* d, int gathered_aligned
 }
 
 // ---- bf16x3 ("split bf16") direct path ----
+// in_colsum != NULL: only the image-resident form can produce it (pm_image_conv_applies); PM_EINVAL otherwise
+static bool image_insum_ok(const Geom& g, const ImagePlan& ip) {
+    const int c4n = g.C / 4;
+    return g.C % 4 == 0 && c4n <= 64 && 64 % c4n == 0 && g.in_act == PM_ACT_NONE &&
+           ip.lds + (size_t)ip.nw * g.C * sizeof(float) <= 160 * 1024;
+}
+
 static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
-                                 const float* bias, const float* aux, const float* res, float* out, float* out2, int act2) {
+                                 const float* bias, const float* aux, const float* res, float* out, float* out2, int act2,
+                                 float* in_colsum = nullptr) {
     GemmArgs a;
-    a.out2 = out2; a.act2 = act2;
+    a.out2 = out2; a.act2 = act2; a.in_colsum = in_colsum;
     if (!fill_geom(d, a.g, true) || !in || !wsplit || !out) return PM_EINVAL;
     if (d->C % 8 != 0 || (d->groups != 1 && d->w_gs % 8 != 0)) return PM_EINVAL;   // C % 32 != 0: zero-padded weight chunks
     if (!aligned16(in) || !aligned16(wsplit) || (d->in_gs % 4) != 0) return PM_EINVAL;
@@ -3823,6 +3850,11 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
         if (rn == 2 && wgs64 < rn2_min) rn = 1;
     }
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
+    if (in_colsum) {
+        ImagePlan ipc;
+        if (plan_skinny(a.g, G) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, G, ipc) || !image_insum_ok(a.g, ipc))
+            return PM_EINVAL;
+    }
     if (plan_skinny(a.g, G)) {                         // one output position, few rows, long K: one launch, K over the waves
         a.ksplit = 1;
         PM_KTAG("skinny_gemm_bf16_kernel");
@@ -3921,6 +3953,20 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
 extern "C" int pm_gather_gemm_bf16(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
                                    const float* bias, const float* aux, const float* res, float* out) {
     return gather_gemm_bf16_impl(stream, d, in, wsplit, bias, aux, res, out, nullptr, PM_ACT_NONE);
+}
+
+extern "C" int pm_gather_gemm_bf16_insum(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
+                                         const float* bias, const float* aux, const float* res, float* out, float* in_colsum) {
+    if (!in_colsum) return PM_EINVAL;
+    return gather_gemm_bf16_impl(stream, d, in, wsplit, bias, aux, res, out, nullptr, PM_ACT_NONE, in_colsum);
+}
+
+extern "C" int pm_image_conv_insum_applies(const pm_gather_desc* d) {
+    GemmArgs a;
+    ImagePlan ip;
+    if (!d || !fill_geom(d, a.g, true) || d->C % 8 != 0 || d->d != 1) return 0;
+    if (plan_skinny(a.g, d->groups) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, d->groups, ip)) return 0;
+    return image_insum_ok(a.g, ip) ? 1 : 0;
 }
 
 extern "C" int pm_gather_gemm_bf16_dual(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,

@@ -157,6 +157,11 @@ __device__ __forceinline__ int band_off(int il, int yl, int x, int rows, int W) 
 #define PM_VB_PD 6
 #endif
 constexpr int PD = PM_VB_PD;    // k-steps of weights in flight per thread (even: ring slot = step & 1)
+#ifndef PM_VB_AD
+#define PM_VB_AD 3
+#endif
+constexpr int AD = PM_VB_AD;    // k-steps of global A rows in flight per wave in the 1x1-from-global stage (divides PD): width
+                                // 192 = 6 k-steps, so the whole operand of the stage is requested before the first MFMA
 constexpr int BROWP = 40;        // ring row: 32 bf16 + 16 B pad (80-byte pitch: conflict-free 16-byte fragment reads)
 constexpr int RING_SLOT = 2 * 64 * BROWP;   // bf16 elements of one slot (2 planes x 64 columns)
 
@@ -195,7 +200,7 @@ __device__ __forceinline__ void ring_b(const __bf16* slot, int nt, int lane, vb_
 }
 
 // ---- 1x1 stage with A from GLOBAL memory: C[p][n] = sum_k A[p][k] W[k][n],  N <= 48 (mid-wide) ------------------------------
-// A rows are [K] floats at ain + ((img*H + y)*W + x) * K; rows outside the image contribute zeros.  A rows are prefetched three
+// A rows are [K] floats at ain + ((img*H + y)*W + x) * K; rows outside the image contribute zeros.  A rows are prefetched AD
 // k-steps ahead in registers (each wave reads its own rows).
 // GELU_IN (forward stage 1): the rows are the Block's raw input x = [ain | ain2] (Ca channels from ain, K - Ca from ain2, Ca a
 // multiple of 32 when there are two sources); gelu is applied as the rows arrive and gelu(x) of the rows the band owns
@@ -231,7 +236,7 @@ __device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __res
     // index clamped): the body is straight-line code, so the compiler counts the loads in flight exactly (s_waitcnt vmcnt(N))
     // instead of draining them all at a control-flow join
     vb_u32x4 pre[PD];
-    f32x4 xa[3][MAXMT][2];
+    f32x4 xa[AD][MAXMT][2];
     auto load_a = [&](int kc, f32x4 (&x)[MAXMT][2]) {
         kc = kc < kch ? kc : kch - 1;
         const bool kin = 32 * kc + kg + 8 <= K;              // K % 8 == 0: a lane's 8 channels are all inside or all outside
@@ -245,9 +250,8 @@ __device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __res
     auto kclamp = [&](int k) { return k < kch ? k : kch - 1; };
 #pragma unroll
     for (int j = 0; j < PD; ++j) pre[j] = feed_load(fd, kclamp(j), 0);
-    load_a(0, xa[0]);
-    load_a(1, xa[1]);
-    load_a(2, xa[2]);
+#pragma unroll
+    for (int j = 0; j < AD; ++j) load_a(j, xa[j]);
     for (int ks0 = 0; ks0 < kch; ks0 += PD) {
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
@@ -261,7 +265,7 @@ __device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __res
 #pragma unroll
                 for (int t = 0; t < MAXMT; ++t) {
                     if (wave + NW * t >= nmt) continue;      // wave-uniform
-                    f32x4 v0 = xa[j % 3][t][0], v1 = xa[j % 3][t][1];
+                    f32x4 v0 = xa[j % AD][t][0], v1 = xa[j % AD][t][1];
                     if (!(rok[t] && kin)) {
                         v0 = f32x4{0.f, 0.f, 0.f, 0.f};
                         v1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -287,7 +291,7 @@ __device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __res
                     }
                 }
             }
-            load_a(ks + 3, xa[j % 3]);                       // refill the set just consumed
+            load_a(ks + AD, xa[j % AD]);                     // refill the set just consumed
         }
     }
     __syncthreads();                                        // the ring is free for the next stage

@@ -10,6 +10,7 @@ batch size.
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -113,13 +114,19 @@ class ParamStore:
                 host[name] = np.zeros(shape, np.float32)
         decayed = [n for n, (s, _) in self.specs.items() if len(s) != 1]
         plain = [n for n, (s, _) in self.specs.items() if len(s) == 1]
-        total = self.num_params
+        # every tensor starts on a 16-byte boundary (its size rounded up to 4 floats; the pad stays zero in all four buffers:
+        # zero gradient -> zero update): a 30-wide bias in the middle of the buffer used to leave everything behind it 8-byte
+        # aligned, which sent those layers to the dword epilogues / scalar loads of every kernel that checks alignment
+        pad4 = (lambda n: n) if os.environ.get("PM_NO_PARAM_PAD") else (lambda n: (n + 3) // 4 * 4)   # (A/B switch)
+        total = sum(pad4(int(np.prod(self.specs[n][0]))) for n in decayed + plain)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         off = 0
         self.offsets = {}
+        self.n_decay = 0
+        decayed_set = set(decayed)
         for name in decayed + plain:
             shape = self.specs[name][0]
             n = int(np.prod(shape))
@@ -127,8 +134,10 @@ class ParamStore:
             self.p[name] = self.flat_p[off:off + n].view(shape)
             self.g[name] = self.flat_g[off:off + n].view(shape)
             self.p[name].copy_(torch.from_numpy(host[name]))
-            off += n
-        self.n_decay = sum(self.offsets[n][1] for n in decayed)
+            off += pad4(n)
+            if name in decayed_set:
+                self.n_decay = off                            # weights first: the decayed prefix ends behind the last of them
+        assert off == total
         self._build_split_plan()
         self.split_all()
 

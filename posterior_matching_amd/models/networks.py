@@ -122,14 +122,18 @@ class ConvDecoder(Module):
             inp = self._outs[i - 1] if i > 0 else self._x.t
             if lend is not None and i < lend[1]:
                 self.ws.wgrad_stream = lend[0]
-            self.wgrad(g, inp, dpre, self.G(f"conv_t_{i}/w"), self.G(f"conv_t_{i}/b"),
+            # the bias gradient (column sums of dpre) comes out of the data-gradient launch when that one stages the dpre images
+            # in LDS anyway (ops.dgrad_insum_ok): no pm_colsum launch, no second read of dpre
+            wsd = self.store.split_view(self._ws[i][1])
+            db_in_dgrad = i > 0 and ops.dgrad_insum_ok(g, B, wsd)
+            self.wgrad(g, inp, dpre, self.G(f"conv_t_{i}/w"), None if db_in_dgrad else self.G(f"conv_t_{i}/b"),
                             in_act=ACT_NONE if i > 0 else self._x.in_act)
             if lend is not None:
                 self.ws.wgrad_stream = None
             if i > 0:
                 dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
-                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY,
-                                wsplit=self.store.split_view(self._ws[i][1]))
+                ops.layer_dgrad(g, dpre, self.P(f"conv_t_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY, wsplit=wsd,
+                                in_colsum=self.G(f"conv_t_{i}/b") if db_in_dgrad else None)
                 dpre = dprev
             elif need_input_grad:
                 dz = self.buf("dz", (B, g.CI))

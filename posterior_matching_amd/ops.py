@@ -415,8 +415,9 @@ def _patch_d2_form(d: GatherDesc) -> bool:
     return nsteps <= 2048 and lds <= 150 * 1024
 
 
-def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=None, act2=ACT_NONE) -> None:
-    """out2 (optional): a second store out2 = act2(out) from the same launch (pm_gather_gemm_bf16_dual)"""
+def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=None, act2=ACT_NONE, in_colsum=None) -> None:
+    """out2 (optional): a second store out2 = act2(out) from the same launch (pm_gather_gemm_bf16_dual)
+    in_colsum (optional, dgrad_insum_ok only): += the column sums of `inp` from the same launch (pm_gather_gemm_bf16_insum)"""
     tag = work = None
     if _timer is not None:
         dense = (desc.KH == desc.KW == 1 and desc.IH == desc.OH and desc.IW == desc.OW and desc.d == 1 and desc.a == 1
@@ -430,8 +431,13 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=No
             tag = f"patch_d2_bf16_kernel<{2 if desc.N > 32 else 1}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
     if out2 is not None:
+        assert in_colsum is None
         _call("pm_gather_gemm_bf16_dual", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
               _ptr(out), _ptr(out2), act2, tag=tag, work=work)
+        return
+    if in_colsum is not None:
+        _call("pm_gather_gemm_bf16_insum", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
+              _ptr(out), _ptr(in_colsum), tag=tag, work=work)
         return
     _call("pm_gather_gemm_bf16", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
           _ptr(out), tag=tag, work=work)
@@ -550,11 +556,28 @@ def layer_forward(g: LayerGeom, x, w, b, out, in_act=ACT_NONE, out_act=ACT_NONE,
             gelu_fwd(out, None, out2)
 
 
-def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, wsplit=None, **group_kw) -> None:
+def dgrad_insum_ok(g: LayerGeom, B: int, wsplit, force: bool = False) -> bool:
+    """True when layer_dgrad(g, dy, ..., in_colsum=db) can also produce db = column sums of dy (the bias gradient of a
+    transposed convolution) - its dy images are staged in LDS by the image-resident kernel anyway.  Measured on the PM-VAE step
+    (same box, 300 steps each): 189.8 / 191.6 k img/s with it against 193.8 / 192.7 k with the separate pm_colsum launches - the
+    column sums ride on the weight-gradient stream, the data gradient is the critical chain, and five launches fewer do not pay
+    for the atomics and the longer staging loop there.  So the models only use it when PM_DGRAD_INSUM=1 (`force`: tests)."""
+    if wsplit is None or not (force or os.environ.get("PM_DGRAD_INSUM")):
+        return False
+    d = g._desc(B, "dgrad")
+    if _thin_ok(d) or not bf16_supported(d):
+        return False
+    return bool(_lib.load().pm_image_conv_insum_applies(C.byref(d)))
+
+
+def layer_dgrad(g: LayerGeom, dy, w, dx, aux=None, aux_act=ACT_NONE, res=None, wsplit=None, in_colsum=None, **group_kw) -> None:
     B = group_kw.pop("B", None) or dy.shape[0]
     d = g._desc(B, "dgrad", **group_kw)
     d.aux_act = aux_act if aux is not None else ACT_NONE
     aux = aux if aux_act != ACT_NONE else None
+    if in_colsum is not None:                       # the caller asked dgrad_insum_ok first
+        gather_gemm_bf16(d, dy, wsplit, None, aux, res, dx, in_colsum=in_colsum)
+        return
     if _thin_ok(d):
         thin_conv(d, dy, w, None, aux, res, dx)
         return

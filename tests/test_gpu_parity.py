@@ -135,6 +135,15 @@ def test_layer_fwd_dgrad_wgrad(kind, B, H, ci, co, k, s, padding):
         dx2 = torch.empty_like(dxd)
         ops.layer_dgrad(geom, dpre, wd, dx2, wsplit=st.split_view(hd))
         assert rel_err(dx2, xr.grad) < 3e-5
+        if ops.dgrad_insum_ok(geom, B, st.split_view(hd), force=True):
+            # the data-gradient launch that also leaves the bias gradient (column sums of dpre; accumulates): same dx, bit for bit
+            dx3, db3 = torch.empty_like(dxd), torch.full_like(bd, 0.5)
+            ops.layer_dgrad(geom, dpre, wd, dx3, wsplit=st.split_view(hd), in_colsum=db3)
+            assert torch.equal(dx3, dx2)
+            sc = (dy * torch.where(pre >= 0, 1.0, 0.01)).abs().sum((0, 1, 2)).max().item()
+            assert (db3.cpu().double() - 0.5 - br.grad).abs().max().item() < 2e-6 * sc
+        elif kind == "convT" and B >= 128 and s == 1 and H >= k:
+            raise AssertionError("the image-resident data gradient should take the bias gradient along here")
     dwd, dbd = torch.zeros_like(wd), torch.zeros_like(bd)
     ops.layer_wgrad(geom, xd, dpre, dwd, dbd, bf16=False)          # f32 MFMA
     assert rel_err(dwd, wr.grad) < 2e-6
