@@ -213,6 +213,10 @@ SIGNATURES = {
     "pm_vade_prior_fwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_vade_prior_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_vade_cluster_probs": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I],
+    "pm_lookahead_inputs": [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _I],
+    "pm_lookahead_ll_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "pm_lookahead_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "pm_lookahead_info_gains": [_P, _P, _P, _P, _P, _I, _I],
     "pm_graph_begin": [_P],
     "pm_graph_end": [_P, C.POINTER(_P)],
     "pm_graph_launch": [_P, _P],

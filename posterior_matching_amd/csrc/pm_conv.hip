@@ -2509,7 +2509,7 @@ struct SplitJob {
 // All 4 x SPLIT_TPB loads of a thread are issued before the first is used, the job of the first tile is found with one
 // parallel pass over the job table (not a 9-deep chain of dependent loads per 1024 elements, which is what made this kernel
 // 1.1 ms at the 35 M-parameter PixelCNN: 0.5 TB/s), and a thread stores 4 bf16 = 8 bytes per plane and tile.
-constexpr int SPLIT_TPB = 8;
+// SPLIT_TPB = 8 for large stores, 2 for small ones (the PM-VAE's 4 k tiles are 2 k workgroups instead of 500).
 
 struct SplitTile {
     long long base, dst0, plane;
@@ -2533,6 +2533,7 @@ __device__ __forceinline__ SplitTile split_tile_of(const SplitJob& job, int t) {
     return r;
 }
 
+template <int SPLIT_TPB>
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ params, __bf16* __restrict__ out,
                                                               const SplitJob* __restrict__ jobs, int njobs,
                                                               int total_tiles) {
@@ -3980,9 +3981,13 @@ extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* o
                                 int njobs, int total_blocks) {
     if (!params || !out_bf16 || !jobs_dev || njobs <= 0 || total_blocks <= 0) return PM_EINVAL;
     static_assert(sizeof(pm_split_job) == sizeof(SplitJob), "pm_split_job layout");
-    hipLaunchKernelGGL(split_weights_kernel, dim3((total_blocks + SPLIT_TPB - 1) / SPLIT_TPB), dim3(256), 0,
-                       (hipStream_t)stream, params, reinterpret_cast<__bf16*>(out_bf16),
-                       reinterpret_cast<const SplitJob*>(jobs_dev), njobs, total_blocks);
+    PM_KTAG("split_weights_kernel<%d>", total_blocks >= 32768 ? 8 : 2);
+    if (total_blocks >= 32768)
+        hipLaunchKernelGGL(split_weights_kernel<8>, dim3((total_blocks + 7) / 8), dim3(256), 0, (hipStream_t)stream, params,
+                           reinterpret_cast<__bf16*>(out_bf16), reinterpret_cast<const SplitJob*>(jobs_dev), njobs, total_blocks);
+    else
+        hipLaunchKernelGGL(split_weights_kernel<2>, dim3((total_blocks + 1) / 2), dim3(256), 0, (hipStream_t)stream, params,
+                           reinterpret_cast<__bf16*>(out_bf16), reinterpret_cast<const SplitJob*>(jobs_dev), njobs, total_blocks);
     return pm_check_launch("pm_split_weights");
 }
 

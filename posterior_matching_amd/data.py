@@ -12,6 +12,8 @@ from .masking import get_mask_generator
 
 
 def data_shape(dataset: str):
+    if dataset == "mnist16":
+        return (16, 16, 1)                  # datasets/mnist16.py: MNIST resized to 16 x 16 (configs/{pm_vae,lookahead}_mnist16.py)
     if "mnist" in dataset:
         return (28, 28, 1)
     if dataset == "celeb_a":

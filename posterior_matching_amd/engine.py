@@ -752,3 +752,82 @@ class PMVADETrainStep(_PlannedStep):
             ops.neg_mean_loss(ll, 1.0 / x.shape[0], metrics, None)
         self.stream.synchronize()
         return {"loss": metrics[0].item()}
+
+
+class LookaheadTrainStep(_PlannedStep):
+    """train_lookahead_posterior.py:46-96 as one launch sequence: the frozen PM-VAE produces the one-step-ahead latent samples
+    (LookaheadPosterior.model_one_step_z), loss = -mean lookahead_lls; backward through the lookahead encoder only
+    (trainable_predicate: "lookahead" in module_name - its parameters live on model.store, the only buffer the optimizer
+    touches); Adam with the exponential-decay schedule; step += 1.  The subsampled feature indices are drawn on the host every
+    step (jax.random.choice without replacement, lookahead.py:151-156), so the step is issued eagerly (no launch plan)."""
+
+    use_plan = False
+
+    def __init__(self, model, optimizer: Chain, batch_size: int, x_shape, seed: int = 0, world_size: int = 1, rank: int = 0,
+                 external_noise: bool = False):
+        import numpy as np
+
+        if model.store is None:
+            model.init(x_shape)
+        dev = model.store.device
+        self.model, self.store = model, model.store
+        self.B, self.seed, self.rank, self.world_size = batch_size, seed, rank, world_size
+        self.adam_cfg = optimizer.adam_cfg(grad_scale=1.0 / world_size)
+        self.adam_cfg.zero_grad = 1
+        self.reducer = _make_reducer(self.store, world_size, False)
+        x_shape = tuple(x_shape)
+        self.x = torch.zeros((batch_size,) + x_shape, device=dev)
+        self.b = torch.zeros((batch_size,) + x_shape[:-1] + (1,), device=dev)
+        self.external_noise = external_noise
+        self.noise, self.inds = None, None          # external_noise: set through set_batch
+        self._rng = np.random.default_rng(seed + 7 * rank)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.metrics = torch.zeros(8, device=dev)
+        self.g = torch.zeros(batch_size, device=dev)
+        self.stream = _step_stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+
+    def _sequence(self) -> None:
+        m, s = self.model, self.store
+        if self.external_noise:
+            noise, inds = self.noise, self.inds
+        else:
+            noise, inds = None, m.draw_indices(self._rng)
+        ll = m(self.x, self.b, is_training=True, noise=noise, inds=inds, seed=self.seed + self.rank)
+        ops.neg_mean_loss(ll, 1.0 / self.B, self.metrics, self.g)
+        self._zero_grad(s)
+        m.backward(self.g)
+        if self.reducer is not None:
+            self.reducer.finish()
+        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._grads_consumed(s)
+        s.split_all()
+        ops.counter_increment(self.step_dev)
+
+    def step(self) -> None:
+        with torch.cuda.stream(self.stream):
+            self._planned(self._sequence)
+
+    def set_batch(self, x: torch.Tensor, b: torch.Tensor, noise=None, inds=None) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+            self.b.copy_(b.reshape(self.b.shape), non_blocking=True)
+        if noise is not None:
+            self.noise, self.inds = noise, inds
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def read_metrics(self) -> Dict[str, float]:
+        self.stream.synchronize()
+        return {"loss": self.metrics[0].item()}
+
+    def evaluate(self, x: torch.Tensor, b: torch.Tensor) -> Dict[str, float]:
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(self.stream):
+            ll = self.model(x.contiguous(), b.contiguous(), is_training=False, seed=self.seed + 104729)
+            metrics = torch.zeros(8, device=x.device)
+            ops.neg_mean_loss(ll, 1.0 / x.shape[0], metrics, None)
+        self.stream.synchronize()
+        return {"loss": metrics[0].item()}

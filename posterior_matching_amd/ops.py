@@ -1362,3 +1362,37 @@ class Event:
             _lib.load().pm_event_destroy(self._ev)
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------
+# lookahead posteriors (reference models/lookahead.py)
+# ------------------------------------------------------------------------------------------
+def lookahead_inputs(imp, b, inds, out) -> None:
+    """imp [B,Z,P,C], b [B,P] (or [B,H,W,1]), inds int32 [S] -> out [B*Z*S, P, C+1] = [imp * b_look | b_look]"""
+    B, Z = imp.shape[0], imp.shape[1]
+    C_ = imp.shape[-1]
+    P = imp.numel() // (B * Z * C_)
+    S = inds.numel()
+    assert b.numel() == B * P and out.numel() == B * Z * S * P * (C_ + 1)
+    _call("pm_lookahead_inputs", _ptr(imp), _ptr(b), _iptr(inds), _ptr(out), B, Z, S, P, C_)
+
+
+def lookahead_ll_fwd(params, inds, zs, b, ll) -> None:
+    """params [B,F,2k], inds int32 [S], zs [B,Z,S,k], b [B,F] -> ll [B]"""
+    B, F, k2 = params.shape
+    Z, S = zs.shape[1], zs.shape[2]
+    assert b.numel() == B * F and zs.shape[0] == B and zs.shape[3] * 2 == k2 and inds.numel() == S
+    _call("pm_lookahead_ll_fwd", _ptr(params), _iptr(inds), _ptr(zs), _ptr(b), _ptr(ll), B, F, Z, S, k2 // 2)
+
+
+def lookahead_ll_bwd(params, inds, zs, b, g, dparams) -> None:
+    B, F, k2 = params.shape
+    Z, S = zs.shape[1], zs.shape[2]
+    assert dparams.shape == params.shape and b.numel() == B * F
+    _call("pm_lookahead_ll_bwd", _ptr(params), _iptr(inds), _ptr(zs), _ptr(b), _ptr(g), _ptr(dparams), B, F, Z, S, k2 // 2)
+
+
+def lookahead_info_gains(params, cur_ent, b, gains) -> None:
+    """params [F,2k], cur_ent [1], b [F] -> gains [F]"""
+    F, k2 = params.shape
+    _call("pm_lookahead_info_gains", _ptr(params), _ptr(cur_ent), _ptr(b), _ptr(gains), F, k2 // 2)

@@ -16,7 +16,7 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional
 import torch
 
 from . import ops
-from .engine import PMVADETrainStep, PMVAETrainStep, PMVQVAETrainStep, VADETrainStep, VDVAETrainStep, VQVAETrainStep
+from .engine import LookaheadTrainStep, PMVADETrainStep, PMVAETrainStep, PMVQVAETrainStep, VADETrainStep, VDVAETrainStep, VQVAETrainStep
 from .models.vae import PosteriorMatchingVAE
 from .models.vqvae import VQVAE
 from .optim import Chain
@@ -199,6 +199,26 @@ class PMVADELoss:
         return metrics[0], {}
 
 
+class LookaheadLoss:
+    """loss_fn of train_lookahead_posterior.py:46-52: loss = -mean LookaheadPosterior(...)(x, mask), aux = {}.  Lowered to
+    engine.LookaheadTrainStep by Trainer (only the "lookahead" modules train, :61-62); callable."""
+
+    def __init__(self, config: Mapping[str, Any], model, data_key: str = "image", seed: int = 0):
+        self.config, self.model, self.data_key, self.seed = config, model, data_key, seed
+
+    def __call__(self, step, is_training, batch):
+        m = self.model
+        x = batch[self.data_key]
+        if m.store is None:
+            m.init(tuple(x.shape[1:]), seed=self.seed)
+        dev = m.store.device
+        x, b = x.to(dev).float().contiguous(), batch["mask"].to(dev).float().contiguous()
+        metrics = torch.zeros(8, device=dev)
+        s = int(step.item()) if isinstance(step, torch.Tensor) else int(step)
+        ops.neg_mean_loss(m(x, b, is_training=bool(is_training), seed=self.seed + s), 1.0 / x.shape[0], metrics, None)
+        return metrics[0], {}
+
+
 @dataclass
 class TrainState:
     step: int = 0
@@ -249,7 +269,13 @@ class Trainer:
                                                     or not trainable_predicate("partial_encoder_net", "w", None)):
                 raise NotImplementedError("only the reference's predicate ('partial_' in module_name) is lowered")
             trainable_predicate = None
-        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss, PMVQVAELoss, VDVAELoss, VADEPretrainLoss, PMVADELoss)):
+        if isinstance(loss_fn, LookaheadLoss):
+            # train_lookahead_posterior.py:61-62: "lookahead" in module_name - what LookaheadTrainStep does (own store)
+            if trainable_predicate is not None and (trainable_predicate("partial_encoder_net", "w", None)
+                                                    or not trainable_predicate("lookahead_encoder_net", "w", None)):
+                raise NotImplementedError("only the reference's predicate ('lookahead' in module_name) is lowered")
+            trainable_predicate = None
+        if not isinstance(loss_fn, (PMVAELoss, VQVAELoss, PMVQVAELoss, VDVAELoss, VADEPretrainLoss, PMVADELoss, LookaheadLoss)):
             raise NotImplementedError("Trainer lowers PMVAELoss / VQVAELoss (the loss_fn of train_pm_vae.py / "
                                       "train_vqvae.py) to the fused HIP step; arbitrary Python loss functions have "
                                       "no HIP path")
@@ -269,6 +295,9 @@ class Trainer:
             return TrainState(step=int(ts.step_dev.item()), params={k: v.cpu() for k, v in store.to_dict("p").items()},
                               opt_state={"mu": store.flat_m.cpu(), "nu": store.flat_v.cpu(),
                                          "count": int(ts.opt_count.item())}, ema_params=ema)
+        if isinstance(ts, LookaheadTrainStep):   # frozen PM-VAE + trainable lookahead encoder in one tree
+            return TrainState(step=int(ts.step_dev.item()), params={k: v.cpu() for k, v in ts.model.params_dict().items()},
+                              opt_state={"mu": ts.store.flat_m.cpu(), "nu": ts.store.flat_v.cpu()})
         if isinstance(ts, PMVADETrainStep):      # frozen VaDE + trainable partial encoder in one tree, as in the reference
             params = {k: v.cpu() for k, v in ts.model.store.to_dict("p").items()}
             params.update({k: v.cpu() for k, v in ts.store.to_dict("p").items()})
@@ -316,6 +345,8 @@ class Trainer:
                                rank=self.rank)
         elif is_pmvade:
             ts = PMVADETrainStep(model, self.optimizer, B, x_shape, seed=self.seed, world_size=self.world, rank=self.rank)
+        elif isinstance(lf, LookaheadLoss):
+            ts = LookaheadTrainStep(model, self.optimizer, B, x_shape, seed=self.seed, world_size=self.world, rank=self.rank)
         elif isinstance(lf, VDVAELoss):
             opt = self.optimizer
             from .optim import LinearSchedule
@@ -374,7 +405,7 @@ class Trainer:
                 cb.on_validation_step(None, None, vb)
             if isinstance(ts, (VQVAETrainStep, VADETrainStep)):
                 out = ts.evaluate(vb[key].to(dev))
-            elif isinstance(ts, (PMVQVAETrainStep, VDVAETrainStep, PMVADETrainStep)):
+            elif isinstance(ts, (PMVQVAETrainStep, VDVAETrainStep, PMVADETrainStep, LookaheadTrainStep)):
                 out = ts.evaluate(vb[key].to(dev), vb["mask"].to(dev))
             else:
                 x, b = vb[key].to(dev), vb["mask"].to(dev)

@@ -52,7 +52,7 @@ def _seed_global_rngs():
 # the kernels one optimizer step of every benchmarked workload launches: a kernel that only the benchmark reaches (a
 # dispatch rule keyed on the batch size, say) fails the suite instead of producing an unverified number.
 PARITY_MODULES = ("test_gpu_parity", "test_gpu_pixelcnn", "test_gpu_vdvae", "test_gpu_vqvae", "test_gpu_celeba",
-                  "test_gpu_masking", "test_gpu_data", "test_gpu_eval_paths", "test_gpu_importer", "test_gpu_vade")
+                  "test_gpu_masking", "test_gpu_data", "test_gpu_eval_paths", "test_gpu_importer", "test_gpu_vade", "test_gpu_lookahead")
 PARITY_KERNELS = {}          # kernel key -> first test that launched it
 
 

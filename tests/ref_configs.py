@@ -155,3 +155,29 @@ def pm_vade_mnist():
         "vade_dir": "runs/vade-mnist-20220305-121540", "model": m, "steps": 160000, "validation_freq": 5000,
         "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "staircase": False, "transition_steps": int(60000 / 128 * 10)},
     }
+
+
+def pm_vae_mnist16():
+    """configs/pm_vae_mnist16.py:4-53 of the reference (the PM-VAE the lookahead posteriors are trained for; 16 x 16 MNIST)."""
+    return {
+        "data": {"dataset": "mnist16", "train_split": "train", "validation_split": "test", "train_batch_size": 128,
+                 "val_batch_size": 128, "mask_generator": "UniformMaskGenerator", "mask_generator_kwargs": {"bounds": (0.0, 0.2)}},
+        "model": {"latent_dim": 10, "encoder_net": "ConvEncoder", "decoder_net": "ConvDecoder", "posterior_dist": "TriLGaussian",
+                  "decoder_dist": "Bernoulli",
+                  "encoder_net_config": {"conv_layers": [(32, 3, 1), (32, 3, 2), (64, 3, 2), (64, 1, 1)]},
+                  "decoder_net_config": {"conv_layers": [(64, 8, 1), (64, 5, 2), (32, 5, 1), (32, 5, 1), (1, 3, 1)]}},
+        "steps": 200000, "validation_freq": 10000,
+        "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 5000},
+    }
+
+
+def lookahead_mnist16():
+    """configs/lookahead_mnist16.py:4-36 of the reference."""
+    return {
+        "data": {"dataset": "mnist16", "train_split": "train", "validation_split": "test", "train_batch_size": 32,
+                 "val_batch_size": 32, "mask_generator": "UniformMaskGenerator", "mask_generator_kwargs": {"bounds": (0.0, 0.20)}},
+        "pm_vae_dir": "runs/pm-vae-mnist16-20220302-160842",
+        "model": {"lookahead_subsample": 16, "model_samples": 64},
+        "steps": 40000, "validation_freq": 5000,
+        "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 5000},
+    }

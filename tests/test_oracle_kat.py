@@ -669,3 +669,78 @@ def test_clustering_accuracy_known_answers():
         assert fn([0, 0, 1, 1, 2, 2], [1, 1, 2, 2, 0, 0]) == 1.0
         assert fn([0, 0, 1, 1], [0, 1, 1, 1]) == 0.75
         assert fn([3, 3, 7, 7, 7], [0, 0, 0, 1, 1]) == 0.8
+
+
+# ----------------------------------------------------------------------------------------------
+# lookahead posteriors (oracle/lookahead_oracle.py; reference models/lookahead.py)
+# ----------------------------------------------------------------------------------------------
+def test_lookahead_masked_mean_ll_against_scipy():
+    """lookahead.py:188-203: mean over the model samples of MultivariateNormalDiag.log_prob, masked by `valid`, averaged over the
+    valid subsampled features; 0 when none is valid"""
+    from scipy.stats import norm
+
+    from oracle import lookahead_oracle as L
+
+    rng = np.random.default_rng(5)
+    B, F, Z, S, k = 3, 7, 4, 3, 2
+    params = torch.tensor(rng.normal(size=(B, F, 2 * k)))
+    zs = torch.tensor(rng.normal(size=(B, Z, S, k)))
+    inds = [5, 0, 3]
+    valid = torch.tensor([[True, False, True], [False, False, False], [True, True, True]])
+    got = L.masked_mean_ll(params, zs, valid, inds).numpy()
+    want = np.zeros(B)
+    for b in range(B):
+        acc, n = 0.0, 0
+        for s, f in enumerate(inds):
+            if not valid[b, s]:
+                continue
+            loc = params[b, f, :k].numpy()
+            scale = np.log1p(np.exp(params[b, f, k:].numpy())) + 1e-5
+            acc += np.mean([norm.logpdf(zs[b, z, s].numpy(), loc, scale).sum() for z in range(Z)])
+            n += 1
+        want[b] = acc / n if n else 0.0
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12) and got[1] == 0.0
+
+
+def test_lookahead_one_step_masks_and_validity():
+    """lookahead.py:147-176 on a 2 x 2 image: b_look = max(b, one-hot), valid <=> the subsampled feature is unobserved; the
+    model samples keep the observed values (where(b == 1, x_o, sample))"""
+    from oracle import lookahead_oracle as L
+    from oracle import pm_vae_oracle as O
+
+    cfg = {"latent_dim": 2, "encoder_net": "ConvEncoder", "decoder_net": "ConvDecoder", "posterior_dist": "TriLGaussian",
+           "decoder_dist": "Bernoulli", "encoder_net_config": {"conv_layers": [(4, 2, 1), (4, 2, 1)]},
+           "decoder_net_config": {"conv_layers": [(4, 2, 1), (1, 1, 1)]}}
+    p = O.init_params(cfg, (2, 2, 1), seed=3)
+    rng = np.random.default_rng(0)
+    x = torch.tensor(rng.uniform(size=(2, 2, 2, 1)))
+    b = torch.tensor([[[[1.0], [0.0]], [[0.0], [0.0]]], [[[0.0], [1.0]], [[1.0], [0.0]]]])
+    noise = {"eps": torch.tensor(rng.normal(size=(2, 3, 2))), "eps_look": torch.tensor(rng.normal(size=(2, 3, 2, 2)))}
+    zs, valid = L.model_one_step_z(p, cfg, x, b, noise, [0, 3])
+    assert tuple(zs.shape) == (2, 3, 2, 2) and torch.isfinite(zs).all()
+    assert valid.tolist() == [[False, True], [True, True]]            # feature 0 of example 0 is already observed
+
+
+def test_lookahead_info_gains_closed_form():
+    """lookahead.py:205-227: entropy of q(z | x) minus the lookahead entropies (diagonal Gaussians), -inf where observed"""
+    from oracle import lookahead_oracle as L
+    from oracle import pm_vae_oracle as O
+
+    cfg = {"latent_dim": 2, "encoder_net": "ConvEncoder", "decoder_net": "ConvDecoder", "posterior_dist": "TriLGaussian",
+           "decoder_dist": "Bernoulli", "encoder_net_config": {"conv_layers": [(4, 2, 1), (4, 2, 1)]},
+           "decoder_net_config": {"conv_layers": [(4, 2, 1), (1, 1, 1)]}}
+    look = {"num_features": 4, "lookahead_subsample": 2, "model_samples": 3}
+    pv, pl = O.init_params(cfg, (2, 2, 1), seed=3), L.init_params(look, cfg, (2, 2, 1), seed=4)
+    pl["lookahead_block/linear/b"] = torch.linspace(-1.0, 1.0, 16, dtype=torch.float64)
+    rng = np.random.default_rng(1)
+    x, b = torch.tensor(rng.uniform(size=(2, 2, 1))), torch.tensor([[[1.0], [0.0]], [[0.0], [1.0]]])
+    g = L.expected_info_gains(pl, pv, look, cfg, x, b)
+    assert g[0] == -math.inf and g[3] == -math.inf and torch.isfinite(g[1]) and torch.isfinite(g[2])
+    prm = L.lookahead_params(pl, look, cfg, x[None], b[None])[0]
+    feats = O._net(pv, "ConvEncoder", cfg["encoder_net_config"], "encoder_net", x[None])
+    _, tril = O.tril_gaussian_params(pv, "posterior_dist", feats, 2)
+    cov_logdet = 2.0 * torch.log(torch.diagonal(tril[0])).sum()
+    h_cur = 0.5 * (2 * (1 + math.log(2 * math.pi)) + cov_logdet)
+    sc = torch.log1p(torch.exp(prm[1, 2:])) + 1e-5
+    h1 = 0.5 * (2 * (1 + math.log(2 * math.pi)) + 2.0 * torch.log(sc).sum())
+    assert abs(float(g[1] - (h_cur - h1))) < 1e-12
