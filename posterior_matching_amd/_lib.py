@@ -217,6 +217,8 @@ SIGNATURES = {
     "pm_lookahead_ll_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pm_lookahead_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pm_lookahead_info_gains": [_P, _P, _P, _P, _P, _I, _I],
+    "pm_acquisition_policy": [_P, _P, _P, _P, _I],
+    "pm_reconstruction_rmse": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "pm_graph_begin": [_P],
     "pm_graph_end": [_P, C.POINTER(_P)],
     "pm_graph_launch": [_P, _P],

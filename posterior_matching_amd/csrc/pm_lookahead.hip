@@ -92,7 +92,82 @@ __global__ __launch_bounds__(256) void lookahead_info_gains_kernel(const float* 
     if (lane == 0) gains[f] = b[f] == 0.f ? cur_ent[0] - h : -INFINITY;
 }
 
+// Greedy acquisition (reference posterior_matching/acquisition.py:38-58): logits = where(gains == -inf, -1e10, gains);
+// action = distrax.Categorical(logits).mode() = argmax (lowest index among ties); probs = softmax(logits).  One workgroup.
+__global__ __launch_bounds__(256) void acquisition_policy_kernel(const float* __restrict__ gains, float* __restrict__ probs,
+                                                                  int* __restrict__ action, int F) {
+    __shared__ float smax[4], ssum[4];
+    __shared__ int sarg[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        const float g = gains[f];
+        const float l = g == -INFINITY ? -1e10f : g;
+        if (l > m) { m = l; am = f; }                    // ascending f per thread: the first maximum stays
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    if (lane == 0) { smax[wave] = m; sarg[wave] = am; }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w)
+        if (smax[w] > m || (smax[w] == m && sarg[w] < am)) { m = smax[w]; am = sarg[w]; }
+    float t = 0.f;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        const float g = gains[f];
+        t += expf((g == -INFINITY ? -1e10f : g) - m);
+    }
+    t = pm_wave_sum(t);
+    if (lane == 0) ssum[wave] = t;
+    __syncthreads();
+    const float z = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    for (int f = threadIdx.x; f < F; f += 256) {
+        const float g = gains[f];
+        probs[f] = expf((g == -INFINITY ? -1e10f : g) - m) / z;
+    }
+    if (threadIdx.x == 0) action[0] = am;
+}
+
+// recon[d] = mean_s imp[s, d];  rmse = sqrt(mean_d (x[d] - recon[d])^2 (1 - b[d / C]))   (acquisition.py:13-15, 50-53); one workgroup
+__global__ __launch_bounds__(256) void reconstruction_rmse_kernel(const float* __restrict__ imp, const float* __restrict__ x,
+                                                                   const float* __restrict__ b, float* __restrict__ recon,
+                                                                   float* __restrict__ rmse, int S, int D, int Cr) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float m = 0.f;
+        for (int s = 0; s < S; ++s) m += imp[(size_t)s * D + d];
+        m /= (float)S;
+        recon[d] = m;
+        const float e = x[d] - m;
+        acc += e * e * (1.f - b[d / Cr]);
+    }
+    acc = pm_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) rmse[0] = sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D);
+}
+
 }  // namespace
+
+extern "C" int pm_acquisition_policy(pm_stream_t stream, const float* gains, float* probs, int* action, int F) {
+    if (!gains || !probs || !action || F <= 0) return PM_EINVAL;
+    PM_KTAG("acquisition_policy_kernel");
+    hipLaunchKernelGGL(acquisition_policy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gains, probs, action, F);
+    return pm_check_launch("pm_acquisition_policy");
+}
+
+extern "C" int pm_reconstruction_rmse(pm_stream_t stream, const float* imp, const float* x, const float* b, float* recon,
+                                      float* rmse, int S, int D, int C, int Cm) {
+    if (!imp || !x || !b || !recon || !rmse || S <= 0 || D <= 0 || C <= 0 || (Cm != C && Cm != 1) || D % C != 0) return PM_EINVAL;
+    PM_KTAG("reconstruction_rmse_kernel");
+    hipLaunchKernelGGL(reconstruction_rmse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, imp, x, b, recon, rmse, S, D,
+                       Cm == 1 ? C : 1);
+    return pm_check_launch("pm_reconstruction_rmse");
+}
 
 extern "C" int pm_lookahead_inputs(pm_stream_t stream, const float* imp, const float* b, const int* inds, float* out,
                                    long long B, int Z, int S, int P, int C) {

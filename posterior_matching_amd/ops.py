@@ -1396,3 +1396,15 @@ def lookahead_info_gains(params, cur_ent, b, gains) -> None:
     """params [F,2k], cur_ent [1], b [F] -> gains [F]"""
     F, k2 = params.shape
     _call("pm_lookahead_info_gains", _ptr(params), _ptr(cur_ent), _ptr(b), _ptr(gains), F, k2 // 2)
+
+
+def acquisition_policy(gains, probs, action) -> None:
+    """gains [F] -> probs [F] (softmax of where(gains == -inf, -1e10, gains)), action int32 [1] (argmax, first among ties)"""
+    _call("pm_acquisition_policy", _ptr(gains), _ptr(probs), _iptr(action), gains.numel())
+
+
+def reconstruction_rmse(imp, x, b, recon, rmse) -> None:
+    """imp [S, *x.shape], x, b (x's shape, or one mask channel) -> recon = mean_s imp, rmse [1] over the unobserved entries"""
+    S, D = imp.shape[0], x.numel()
+    assert imp.numel() == S * D and recon.numel() == D
+    _call("pm_reconstruction_rmse", _ptr(imp), _ptr(x), _ptr(b), _ptr(recon), _ptr(rmse), S, D, x.shape[-1], b.shape[-1])

@@ -178,6 +178,73 @@ def test_lookahead_train_steps_match_oracle():
     assert worst[0] < 1e-3, worst
 
 
+def test_acquisition_kernels():
+    """pm_acquisition_policy (argmax with ties and -inf entries, softmax of the -1e10-filled logits) and pm_reconstruction_rmse
+    vs numpy"""
+    from posterior_matching_amd import ops
+
+    rng = np.random.default_rng(9)
+    for F in (9, 256, 700):
+        g = rng.normal(size=F).astype(np.float32)
+        g[rng.uniform(size=F) < 0.3] = -np.inf
+        g[[F // 2, F // 3]] = 5.0                                              # a tie: the lower index wins
+        gd, probs, act = torch.tensor(g, device=dev()), torch.empty(F, device=dev()), torch.empty(1, dtype=torch.int32, device=dev())
+        ops.acquisition_policy(gd, probs, act)
+        logits = np.where(np.isinf(g), -1e10, g).astype(np.float64)
+        want = np.exp(logits - logits.max())
+        want /= want.sum()
+        assert act.item() == F // 3 and np.allclose(probs.cpu().numpy(), want, rtol=2e-6, atol=1e-12)
+    allobs = torch.full((6,), -np.inf, device=dev())
+    probs, act = torch.empty(6, device=dev()), torch.empty(1, dtype=torch.int32, device=dev())
+    ops.acquisition_policy(allobs, probs, act)
+    assert act.item() == 0 and np.allclose(probs.cpu().numpy(), 1.0 / 6)
+    for shape, mshape in (((5, 7, 3), (5, 7, 1)), ((11,), (11,))):
+        S = 4
+        imp, x = rng.uniform(size=(S,) + shape).astype(np.float32), rng.uniform(size=shape).astype(np.float32)
+        b = (rng.uniform(size=mshape) < 0.4).astype(np.float32)
+        rec, err = torch.empty(shape, device=dev()), torch.empty(1, device=dev())
+        ops.reconstruction_rmse(torch.tensor(imp, device=dev()), torch.tensor(x, device=dev()), torch.tensor(b, device=dev()), rec, err)
+        m = imp.astype(np.float64).mean(0)
+        assert np.allclose(rec.cpu().numpy(), m, rtol=1e-6) and abs(err.item() - np.sqrt(np.mean((x - m) ** 2 * (1 - b)))) < 1e-6
+
+
+def test_acquisition_eval_fn_and_trajectories():
+    """acquisition.make_acquisition_eval_fn on one instance with explicit draws vs the oracle (sampling-based and lookahead
+    information gains -> policies, mean imputation), then two 3-step episodes: masks grow by the chosen one-hots"""
+    from posterior_matching_amd.acquisition import make_acquisition_eval_fn, make_collect_trajectory_fn, rmse
+
+    m, pm_cfg, look, xs, pv, pl = _setup("small", seed=12)
+    k, S = pm_cfg["latent_dim"], 6
+    x, b, _, _ = _inputs(xs, look, k, 1, 21)
+    x, b = x[0], b[0]
+    noise = {"eps": torch.tensor(np.random.default_rng(4).normal(size=(1, S, k)))}
+    eval_fn = make_acquisition_eval_fn(look, pm_cfg, S, model=m)
+    out = eval_fn(f32d(x * b), f32d(b), noise={n: f32d(t) for n, t in noise.items()})
+    gs = O.pm_vae_expected_info_gains(pv, pm_cfg, x * b, b, noise)
+    gl = L.expected_info_gains(pl, pv, look, pm_cfg, x * b, b)
+    for name, g in (("sampling", gs), ("lookahead", gl)):
+        logits = torch.where(torch.isinf(g), torch.full_like(g, -1e10), g)
+        assert rel_err(out[f"{name}_probs"], torch.softmax(logits, 0)) < 2e-4, name
+        top = torch.sort(logits, descending=True).values
+        if (top[0] - top[1]).item() > 1e-4:
+            assert out[f"{name}_action"].item() == int(torch.argmax(logits)), name
+    want_rec = O.pm_vae_impute(pv, pm_cfg, (x * b)[None], b[None], noise).mean(0)[0]
+    assert rel_err(out["reconstruction"], want_rec) < 1e-4
+    want_rmse = torch.sqrt(((x - want_rec) ** 2 * (1 - b)).mean())
+    assert abs(rmse(f32d(x), out["reconstruction"], f32d(b)).item() - want_rmse.item()) < 1e-4
+    T = 3
+    samp, lk = make_collect_trajectory_fn(eval_fn, T)(f32d(x))
+    for traj, which in ((samp, "sampling"), (lk, "lookahead")):
+        assert traj["mask"].shape == (T,) + tuple(b.shape) and traj["reconstruction"].shape == (T,) + tuple(x.shape)
+        assert traj["sampling_probs"].shape == (T, look["num_features"]) and np.isfinite(traj["rmse"]).all()
+        assert traj["mask"][0].sum() == 0
+        for t in range(T - 1):
+            one = np.zeros(look["num_features"], np.float32)
+            one[traj[f"{which}_action"][t]] = 1.0
+            assert np.array_equal(traj["mask"][t + 1], traj["mask"][t] + one.reshape(b.shape))
+        assert len(set(traj[f"{which}_action"].tolist())) == T                      # never re-acquires an observed feature
+
+
 def test_lookahead_scripts_end_to_end(tmp_path):
     """train_pm_vae.py on configs/pm_vae_mnist16.py, then train_lookahead_posterior.py on its run directory with the reference's
     configuration (batch 32, 64 model samples, 16 lookahead features), a few steps each; device Philox noise"""
@@ -196,3 +263,13 @@ def test_lookahead_scripts_end_to_end(tmp_path):
     assert all(np.isfinite(l["train_loss"]) and np.isfinite(l["val_loss"]) for l in lines)
     assert os.path.exists(os.path.join(run2, "lookahead_config.json")) and os.path.exists(os.path.join(run2, "pm_vae_config.json"))
     assert json.load(open(os.path.join(run2, "lookahead_config.json")))["num_features"] == 256
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "eval_greedy_acquisition.py"), "--run_dir", run2, "--dataset", "mnist16",
+                          "--num_instances", "2", "--num_samples", "3", "--episode_length", "3"], cwd=tmp_path, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    import pickle
+
+    for kind in ("sampling", "lookahead"):
+        trajs = pickle.load(open(os.path.join(run2, "trajectories", f"{kind}_trajectories.pkl"), "rb"))
+        assert len(trajs) == 2 and trajs[0]["truth"].shape == (16, 16, 1) and trajs[0]["mask"].shape == (3, 16, 16, 1)
+        assert trajs[0]["lookahead_probs"].shape == (3, 256) and np.isfinite(trajs[1]["rmse"]).all()

@@ -111,6 +111,9 @@ def test_reference_import_paths_resolve():
         "posterior_matching.models.pixel_cnn": ["PixelCNN"],
         "posterior_matching.models.vdvae": ["PosteriorMatchingVDVAE", "Encoder", "Block", "PosteriorMatchingDecoderBlock",
                                             "parse_layer_string"],
+        "posterior_matching.models.vade": ["VADE", "PosteriorMatchingVADE"],
+        "posterior_matching.models.lookahead": ["LookaheadPosterior", "LookaheadBlock"],
+        "posterior_matching.acquisition": ["rmse", "make_acquisition_eval_fn", "make_collect_trajectory_fn"],
         "posterior_matching.masking": ["get_mask_generator", "MNISTMaskGenerator", "CelebAMaskGenerator",
                                        "BernoulliMaskGenerator", "UniformMaskGenerator"],
         "posterior_matching.utils": ["load_datasets", "cyclical_annealing_schedule", "make_run_dir",
