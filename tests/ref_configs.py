@@ -181,3 +181,30 @@ def lookahead_mnist16():
         "steps": 40000, "validation_freq": 5000,
         "lr_schedule": {"init_value": 0.001, "decay_rate": 0.9, "transition_steps": 5000},
     }
+
+
+def _uci(dataset, event_size):
+    c = pm_vae_gas()
+    c["data"]["dataset"] = dataset
+    c["model"]["decoder_dist_config"]["event_size"] = event_size
+    return c
+
+
+def pm_vae_power():
+    """configs/pm_vae_power.py of the reference: the gas configuration with 6 features"""
+    return _uci("power", 6)
+
+
+def pm_vae_hepmass():
+    """configs/pm_vae_hepmass.py of the reference: the gas configuration with 21 features"""
+    return _uci("hepmass", 21)
+
+
+def pm_vae_bsds():
+    """configs/pm_vae_bsds.py of the reference: 63 features, latent 64, 5-block LayerNorm MLPs, the monotonic beta schedule"""
+    c = _uci("bsds", 63)
+    c["model"]["latent_dim"] = 64
+    for net in ("encoder_net_config", "decoder_net_config"):
+        c["model"][net].update(residual_blocks=5, layer_norm=True)
+    c["beta"] = {"schedule": "monotonic", "low_value": 0.0, "high_value": 1.0, "transition_steps": 200000, "transition_begin": 30000}
+    return c

@@ -15,14 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_configs_match_reference_values():
     from posterior_matching_amd.config_dict import load_config_file
-    from tests.ref_configs import (lookahead_mnist16, pm_vae_mnist16, pm_vade_mnist, pm_vae_gas, pm_vae_miniboone, pm_vae_mnist, pm_vdvae_mnist,
+    from tests.ref_configs import (lookahead_mnist16, pm_vae_bsds, pm_vae_hepmass, pm_vae_mnist16, pm_vae_power, pm_vade_mnist, pm_vae_gas, pm_vae_miniboone, pm_vae_mnist, pm_vdvae_mnist,
                                    pm_vqvae_celeb_a, pm_vqvae_mnist, vade_mnist, vqvae_celeb_a, vqvae_mnist)
 
     for name, ref in (("pm_vae_mnist", pm_vae_mnist()), ("pm_vae_gas", pm_vae_gas()), ("vqvae_mnist", vqvae_mnist()),
                       ("pm_vqvae_mnist", pm_vqvae_mnist()), ("pm_vdvae_mnist", pm_vdvae_mnist()),
                       ("vqvae_celeb_a", vqvae_celeb_a()), ("pm_vqvae_celeb_a", pm_vqvae_celeb_a()),
                       ("pm_vae_miniboone", pm_vae_miniboone()), ("vade_mnist", vade_mnist()), ("pm_vade_mnist", pm_vade_mnist()),
-                      ("pm_vae_mnist16", pm_vae_mnist16()), ("lookahead_mnist16", lookahead_mnist16())):
+                      ("pm_vae_mnist16", pm_vae_mnist16()), ("lookahead_mnist16", lookahead_mnist16()),
+                      ("pm_vae_power", pm_vae_power()), ("pm_vae_hepmass", pm_vae_hepmass()), ("pm_vae_bsds", pm_vae_bsds())):
         cfg = load_config_file(os.path.join(ROOT, "configs", name + ".py")).to_dict()
         assert cfg == ref, name
 
