@@ -140,6 +140,7 @@ SIGNATURES = {
     "pm_concat_elu_fwd_philox": [_P, _P, _P, _P, _LL, _I, _I, _F, C.c_ulonglong, _P, _I],
     "pm_concat_elu_bwd_philox": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P, _F, C.c_ulonglong, _P, _I],
     "pm_gate_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
+    "pm_gate_fwd_ce": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_gate_bwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_rows_sum": [_P, _P, _P, _LL, _I, _I],
     "pm_groups_sum": [_P, _P, _P, _LL, _I, _LL, _I],

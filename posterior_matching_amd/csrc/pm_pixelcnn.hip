@@ -402,6 +402,36 @@ __global__ __launch_bounds__(256) void gate_v4_kernel(const pc_f32x4* __restrict
     }
 }
 
+// gate forward AND the next block's concat_elu in one pass: out as gate_v4_kernel<false>, ce [R, 2F] = (elu(out) | elu(-out)) - the
+// tensor the next gated block of the same stack opens with (pixel_cnn.py:429-431): its separate launch and its re-read of `out`
+// (one link of a dependent chain of ~10 us launches per block) go away.
+__global__ __launch_bounds__(256) void gate_ce_v4_kernel(const pc_f32x4* __restrict__ y, const pc_f32x4* __restrict__ h,
+                                                          const pc_f32x4* __restrict__ in, pc_f32x4* __restrict__ out,
+                                                          pc_f32x4* __restrict__ ce, unsigned nv, unsigned F4, unsigned P) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nv) return;
+    const unsigned r = i / F4, f4 = i - r * F4;
+    pc_f32x4 act = y[r * 2u * F4 + f4], gate = y[r * 2u * F4 + F4 + f4];
+    if (h) {
+        const unsigned bb = r / P;
+        act += h[bb * 2u * F4 + f4];
+        gate += h[bb * 2u * F4 + F4 + f4];
+    }
+    pc_f32x4 s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = pm_sigmoid(gate[e]);
+    const pc_f32x4 v = in[i] + s * act;
+    out[i] = v;
+    pc_f32x4 pos, neg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        pos[e] = elu_f(v[e]);
+        neg[e] = elu_f(-v[e]);
+    }
+    ce[r * 2u * F4 + f4] = pos;
+    ce[r * 2u * F4 + F4 + f4] = neg;
+}
+
 // gate backward AND the conditional projection's gradient in one pass: dy as gate_v4_kernel<true>, dh[b] = sum over the P
 // positions of image b of dy (what pm_rows_sum makes of dy afterwards: 12.8 MB re-read and one more launch per gated block
 // at the mnist PixelCNN's size).  One workgroup per image: thread (fq, rg) owns the activation / gate quads fq of the rows
@@ -554,6 +584,19 @@ extern "C" int pm_gate_fwd(pm_stream_t stream, const float* y, const float* h, c
     hipLaunchKernelGGL(gate_fwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, y, h, input, out,
                        rows, F, P);
     return pm_check_launch("pm_gate_fwd");
+}
+
+extern "C" int pm_gate_fwd_ce(pm_stream_t stream, const float* y, const float* h, const float* input, float* out, float* ce,
+                              long long rows, int F, int P) {
+    if (!y || !input || !out || !ce || rows <= 0 || F <= 0 || P <= 0) return PM_EINVAL;
+    if (F % 4 != 0 || rows * 2 * F >= 0x7fffffffLL || !al16(y) || !al16(h) || !al16(input) || !al16(out) || !al16(ce))
+        return PM_EINVAL;                                      // 16-byte form only: callers keep the two launches otherwise
+    const unsigned nv = (unsigned)(rows * F / 4);
+    typedef const pc_f32x4* cp;
+    PM_KTAG("gate_ce_v4_kernel");
+    hipLaunchKernelGGL(gate_ce_v4_kernel, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (cp)y, (cp)h, (cp)input,
+                       (pc_f32x4*)out, (pc_f32x4*)ce, nv, (unsigned)F / 4, (unsigned)P);
+    return pm_check_launch("pm_gate_fwd_ce");
 }
 
 extern "C" int pm_gate_bwd(pm_stream_t stream, const float* y, const float* h, const float* dout, float* dy,

@@ -169,10 +169,18 @@ class PixelCNN(Module):
         self._drops: List[Optional[torch.Tensor]] = []
         self._io: List[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]] = []
 
+        # the block that opens with concat_elu(out of THIS block): the next block of the same stack, in execution order
+        # (vertical: blocks 0, 2, ..; horizontal: 1, 3, ..; the up pass continues where the down pass ended).  Its ce1 comes
+        # out of this block's gate launch (ops.gate_fwd_ce) - one link less in each block's dependent chain.
+        fuse_ce = not os.environ.get("PM_NO_GATE_CE")
+        nxt = {b_.group: (self.blocks[i + 2] if i + 2 < len(self.blocks) else None) for i, b_ in enumerate(self.blocks)}
+        have_ce1 = set()
+
         def run_block(blk: _Block, input_x, extra_a=None, extra_b=None):
             n = blk.name
             ce1 = self.buf(f"{n}/ce1", sh(2 * F))
-            ops.concat_elu_fwd(input_x, None, None, ce1)
+            if n not in have_ce1:
+                ops.concat_elu_fwd(input_x, None, None, ce1)
             x1 = self.buf(f"{n}/x1", sh(F))
             if blk.linear is None:
                 self._fwd(blk.conv1, ce1, x1)
@@ -198,7 +206,14 @@ class PixelCNN(Module):
             y = self.buf(f"{n}/y", sh(2 * F))
             self._fwd(blk.conv2, ce2, y)
             out = self.buf(f"{n}/out", sh(F))
-            ops.gate_fwd(y, hproj[blk.group] if hproj is not None else None, input_x, out, P)
+            hp = hproj[blk.group] if hproj is not None else None
+            follower = nxt[blk.group]
+            ce_next = self.buf(f"{follower.name}/ce1", sh(2 * F)) if (fuse_ce and follower is not None) else None
+            if ce_next is not None and ops.gate_fwd_ce_ok(y, hp, input_x, out, ce_next):
+                ops.gate_fwd_ce(y, hp, input_x, out, ce_next, P)
+                have_ce1.add(follower.name)
+            else:
+                ops.gate_fwd(y, hp, input_x, out, P)
             self._drops.append(drop)
             self._io.append((input_x, extra_a, extra_b))
             return out

@@ -843,6 +843,19 @@ def gate_fwd(y, h, inp, out, P: int) -> None:
     _call("pm_gate_fwd", _ptr(y), _ptr(h), _ptr(inp), _ptr(out), inp.numel() // F, F, P, work={"bytes": _nbytes(y, inp, out)})
 
 
+def gate_fwd_ce_ok(y, h, inp, out, ce) -> bool:
+    F = inp.shape[-1]
+    return (F % 4 == 0 and inp.numel() * 2 < 0x7fffffff
+            and all(t is None or t.data_ptr() % 16 == 0 for t in (y, h, inp, out, ce)))
+
+
+def gate_fwd_ce(y, h, inp, out, ce, P: int) -> None:
+    """gate_fwd + concat_elu_fwd(out) -> ce [.., 2F] in one launch (gate_fwd_ce_ok)"""
+    F = inp.shape[-1]
+    _call("pm_gate_fwd_ce", _ptr(y), _ptr(h), _ptr(inp), _ptr(out), _ptr(ce), inp.numel() // F, F, P,
+          work={"bytes": _nbytes(y, inp, out, ce)})
+
+
 def gate_bwd_rows_sum_ok(dout, B: int) -> bool:
     """pm_gate_bwd_rows_sum's preconditions, and enough images to fill the chip with one workgroup each"""
     F = dout.shape[-1]

@@ -166,6 +166,27 @@ def test_gate_bwd_with_rows_sum(B, P, F, cond):
     assert rel_err(dh, hr.grad if cond else yr.grad.reshape(B, P, 2 * F).sum(1)) < 2e-6
 
 
+@pytest.mark.parametrize("B,P,F,cond", [(256, 49, 128, True), (16, 256, 128, True), (5, 9, 12, False)])
+def test_gate_forward_with_the_next_blocks_concat_elu(B, P, F, cond):
+    """pm_gate_fwd_ce (the train step's form) against the two launches it replaces - pm_gate_fwd, then pm_concat_elu_fwd of its
+    output, both checked against the oracle by the PixelCNN parity tests: BIT-identical `out` and `ce`; the whole-network tests
+    run it as well (their logits / gradients are compared with the oracle's)."""
+    from posterior_matching_amd import ops
+
+    gen = torch.Generator().manual_seed(B + F)
+    d = dev()
+    y = torch.randn((B * P, 2 * F), generator=gen).to(d)
+    h = torch.randn((B, 2 * F), generator=gen).to(d) if cond else None
+    x = torch.randn((B * P, F), generator=gen).to(d)
+    out_w, ce_w = torch.empty_like(x), torch.empty((B * P, 2 * F), device=d)
+    ops.gate_fwd(y, h, x, out_w, P)
+    ops.concat_elu_fwd(out_w, None, None, ce_w)
+    out_g, ce_g = torch.empty_like(x), torch.empty((B * P, 2 * F), device=d)
+    assert ops.gate_fwd_ce_ok(y, h, x, out_g, ce_g)
+    ops.gate_fwd_ce(y, h, x, out_g, ce_g, P)
+    assert torch.equal(out_g, out_w) and torch.equal(ce_g, ce_w)
+
+
 @pytest.mark.parametrize("R,Ca,Cb", [(12544, 128, 0), (245, 64, 32), (4096, 128, 128)])
 def test_concat_elu_with_the_keep_mask_drawn_in_place(R, Ca, Cb):
     """pm_concat_elu_{fwd,bwd}_philox (the train step's form: hk.dropout's keep mask never exists in HBM) against the
