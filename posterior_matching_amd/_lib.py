@@ -75,7 +75,7 @@ class VdvaeBlockIO(C.Structure):
         ("x", C.c_void_p), ("x2", C.c_void_p), ("res", C.c_void_p), ("xpre", C.c_void_p), ("xg_out", C.c_void_p),
         ("h", C.c_void_p * 3), ("g", C.c_void_p * 3), ("out", C.c_void_p),
         ("w", C.c_void_p * 4), ("plane", C.c_longlong * 4), ("bias", C.c_void_p * 4),
-        ("Cin", C.c_int), ("Cout", C.c_int), ("Ca", C.c_int),
+        ("Cin", C.c_int), ("Cout", C.c_int), ("Ca", C.c_int), ("dense_k3", C.c_int),
     ]
 
 
@@ -87,7 +87,7 @@ class SplitJob(C.Structure):
         ("taps", C.c_int), ("C", C.c_int), ("N", C.c_int), ("npad", C.c_int),
         ("wts", C.c_int), ("wcs", C.c_int), ("wns", C.c_int),
         ("first_block", C.c_int), ("num_blocks", C.c_int),
-        ("kw", C.c_int), ("kws", C.c_int),
+        ("kw", C.c_int), ("kws", C.c_int), ("dense_k", C.c_int),
     ]
 
 

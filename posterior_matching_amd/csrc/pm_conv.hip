@@ -2501,6 +2501,7 @@ struct SplitJob {
     int wts, wcs, wns;
     int first_block, num_blocks;
     int kw, kws;         // compact tap t reads weight-layout tap (t / kw) * kws + t % kw
+    int dense_k;         // 1: K runs over (tap, c) WITHOUT per-tap padding: dst[plane][ceil(taps*C/32)][npad][32], k = tap * C + c
 };
 
 // One workgroup = SPLIT_TPB consecutive (tap, 32-channel chunk, 32-column tile) tiles of 1024 elements each, usually of one
@@ -2514,23 +2515,35 @@ struct SplitJob {
 struct SplitTile {
     long long base, dst0, plane;
     int cc, nt, wcs, wns, C, N;
+    int dense, taps, kw, kws, wts;           // dense_k jobs: the tap of an element depends on its k (base = src_off)
     bool n_contig;
 };
 
 __device__ __forceinline__ SplitTile split_tile_of(const SplitJob& job, int t) {
     SplitTile r;
-    const int cch = (job.C + BK - 1) / BK;   // channel chunks per tap, the last one zero-padded
+    // channel chunks per tap, the last one zero-padded; dense_k: chunks of the whole (tap, c) range, only the very last padded
+    const int cch = job.dense_k ? (job.taps * job.C + BK - 1) / BK : (job.C + BK - 1) / BK;
     const int ntiles = job.npad / 32;
     r.nt = t % ntiles;
     t /= ntiles;
     r.cc = t % cch;
-    const int tap = t / cch;
+    const int tap = t / cch;                 // 0 for dense_k jobs
     r.base = job.src_off + (long long)((tap / job.kw) * job.kws + tap % job.kw) * job.wts;
     r.dst0 = job.dst_off + ((long long)(tap * cch + r.cc) * job.npad + 32 * r.nt) * BK;
     r.plane = job.plane;
     r.wcs = job.wcs, r.wns = job.wns, r.C = job.C, r.N = job.N;
+    r.dense = job.dense_k, r.taps = job.taps, r.kw = job.kw, r.kws = job.kws, r.wts = job.wts;
     r.n_contig = job.wns <= job.wcs;         // which source axis is the faster one
     return r;
+}
+
+// source offset (without the column term) of element k of a tile's 32-deep chunk, or -1 past the end of K
+__device__ __forceinline__ long long split_src_k(const SplitTile& t, int k) {
+    const int kk = t.cc * BK + k;
+    if (!t.dense) return kk < t.C ? t.base + (long long)kk * t.wcs : -1;
+    if (kk >= t.taps * t.C) return -1;
+    const int tap = kk / t.C, c = kk - tap * t.C;
+    return t.base + (long long)((tap / t.kw) * t.kws + tap % t.kw) * t.wts + (long long)c * t.wcs;
 }
 
 template <int SPLIT_TPB>
@@ -2567,8 +2580,8 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
                 const int k = tl[q].n_contig ? a : tx;                       // channel within the chunk
                 const int n = (tl[q].n_contig ? tx : a) + 32 * tl[q].nt;     // output column
                 v[q][pss] = 0.f;
-                if (n < tl[q].N && tl[q].cc * BK + k < tl[q].C)
-                    v[q][pss] = params[tl[q].base + (long long)(tl[q].cc * BK + k) * tl[q].wcs + (long long)n * tl[q].wns];
+                const long long so = split_src_k(tl[q], k);
+                if (n < tl[q].N && so >= 0) v[q][pss] = params[so + (long long)n * tl[q].wns];
             }
         }
     }

@@ -44,6 +44,7 @@ struct BlockArgs {
     const float* bias[4];        // forward only
     int B, H, W, Cin, Cout, mid, k3;   // k3: 3 (3x3 middle convs) or 1
     int R, NI, bands;            // rows per band, images per workgroup, bands per image
+    int dense;                   // the k3 x k3 layers' weights are dense_k split copies: K = tap * mid + c, no per-tap padding
 };
 
 __device__ __forceinline__ void vb_split8(const f32x4& x0, const f32x4& x1, vb_bf16x8& hi, vb_bf16x8& lo) {
@@ -299,10 +300,13 @@ __device__ __forceinline__ void gemm_global_mid(const Dims a, const float* __res
 
 // ---- k3 x k3 stage with A from an LDS band: C[p][n] = sum_{tap, c} band[p + tap][c] W[tap][c][n] --------------------------------
 // `sign` = +1 forward (source = p + (tap - centre)), -1 data gradient (source = p - (tap - centre)).
+// DENSE (a run-time flag, uniform over the launch: one copy of the loop in the kernel): the weights are a dense_k split copy - k-step ks holds k = 32 ks .. 32 ks + 31 of the (tap, c) range, so the four
+// 8-channel groups of a k-step (lane >> 4) may sit in two different taps: the tap shift is per lane group, not per k-step
+// (mid = 48: 14 k-steps per 3x3 layer instead of 18, none of them half empty except the last).
 template <int NT>
 __device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, const __bf16* bl_, int in_rows, int in_ys,
                                               const __bf16* w, long long plane, __bf16* ring, int img0, const Stage& s, int M,
-                                              int sign, int wave, int lane, int tid, f32x4 (&acc)[MAXMT][NT]) {
+                                              int sign, const bool DENSE, int wave, int lane, int tid, f32x4 (&acc)[MAXMT][NT]) {
     const int npad = (a.mid + 31) / 32 * 32, cch = (a.mid + 31) / 32;   // 32-channel chunks per tap (zero-padded past mid)
     const int nmt = (M + 15) / 16;
     const int taps = a.k3 * a.k3, ctr = a.k3 / 2;
@@ -316,14 +320,18 @@ __device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, c
         const int il = p / per, rem = p - il * per;
         const int yl = rem / a.W, x = rem - yl * a.W;
         // row of the input band that holds image row (s.ys + yl): yl + (s.ys - in_ys)
-        base[t] = band_off(il, yl + (s.ys - in_ys), x, in_rows, a.W) + 8 * (lane >> 4);
+        base[t] = band_off(il, yl + (s.ys - in_ys), x, in_rows, a.W) + (DENSE ? 0 : 8 * (lane >> 4));
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int nk = taps * cch;
+    const int nk = DENSE ? (taps * a.mid + 31) / 32 : taps * cch;
     const Feeder fd = make_feeder(w, plane, npad, npad, tid);
     vb_u32x4 pre[PD];
     auto kclamp = [&](int k) { return k < nk ? k : nk - 1; };
+    // DENSE: this lane group's walk over the (tap, c) range, 32 channels per k-step (mid % 8 == 0: a group of 8 never straddles taps)
+    int dk = 8 * (lane >> 4), dtap = 0;
+    if (DENSE)
+        while (dk >= a.mid) { dk -= a.mid; ++dtap; }
 #pragma unroll
     for (int j = 0; j < PD; ++j) pre[j] = feed_load(fd, kclamp(j), 0);
     for (int ks0 = 0; ks0 < nk; ks0 += PD) {
@@ -335,9 +343,18 @@ __device__ __forceinline__ void gemm_band_mid(const Dims a, const __bf16* bh_, c
             pre[j] = feed_load(fd, kclamp(ks + PD), 0);
             __syncthreads();
             if (ks < nk) {                                   // uniform
-                const int tap = ks / cch, cc = ks - tap * cch;
-                const int ky = tap / a.k3, kx = tap - ky * a.k3;
-                const int shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
+                int shift;
+                if (DENSE) {
+                    const int tp = dtap < taps ? dtap : ctr * a.k3 + ctr;        // past the end of K: zero weights, any finite A
+                    const int ky = tp / a.k3, kx = tp - ky * a.k3;
+                    shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + (dtap < taps ? dk : 0);
+                    dk += 32;                                                      // the next k-step of this lane group
+                    while (dk >= a.mid) { dk -= a.mid; ++dtap; }
+                } else {
+                    const int tap = ks / cch, cc = ks - tap * cch;
+                    const int ky = tap / a.k3, kx = tap - ky * a.k3;
+                    shift = sign * ((ky - ctr) * (a.W + 2) + (kx - ctr)) * PS + 32 * cc;
+                }
 #pragma unroll
                 for (int t = 0; t < MAXMT; ++t) {
                     if (wave + NW * t >= nmt) continue;
@@ -493,6 +510,7 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(MultiArgs multi) 
     const BlockArgs& ka = multi.b[blockIdx.y];               // independent Blocks of one geometry share a launch
     const Dims a{ka.B, ka.H, ka.W, ka.mid, ka.k3};
     const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
+    const bool dense = ka.dense != 0 && ka.k3 == 3;
     const float* __restrict__ xin = ka.xin;
     const float* __restrict__ resp = ka.res;
     [[maybe_unused]] const float* __restrict__ xpre = ka.xpre;
@@ -582,11 +600,11 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_fwd_kernel(MultiArgs multi) 
     return;
 #endif
     // ---- stage 2: h2 = c2(g1) on the rows of s2 -> g2 band ----
-    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w1, pl1, ring, img0, s2, M2, +1, wave, lane, tid, acc);
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w1, pl1, ring, img0, s2, M2, +1, dense, wave, lane, tid, acc);
     epilogue_mid(s2, M2, bs1, hh1, gg1, b2h, b2l, y0, own_hi);
     __syncthreads();
     // ---- stage 3: h3 = c3(g2) on the owned rows -> g3 into band 1 (g1 is dead) ----
-    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w2, pl2, ring, img0, s3, M3, +1, wave, lane, tid, acc);
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w2, pl2, ring, img0, s3, M3, +1, dense, wave, lane, tid, acc);
     __syncthreads();                                          // every wave is done reading band 1's successor inputs (band 2 only)
     {   // g3 goes into band 1 laid out with s3's rows; stale g1 there is overwritten or unread (c4 is 1x1: no halo, and
         // the padding channels mid..63 of every slot were zeroed once and are never written)
@@ -621,6 +639,7 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(MultiArgs multi) 
     const BlockArgs& ka = multi.b[blockIdx.y];               // independent Blocks of one geometry share a launch
     const Dims a{ka.B, ka.H, ka.W, ka.mid, ka.k3};
     const int aR = ka.R, aNI = ka.NI, abands = ka.bands, aCin = ka.Cin, aCout = ka.Cout;
+    const bool dense = ka.dense != 0 && ka.k3 == 3;
     const float* __restrict__ xin = ka.xin;
     const float* __restrict__ resp = ka.res;
     [[maybe_unused]] const float* __restrict__ xpre = ka.xpre;
@@ -693,10 +712,10 @@ __global__ __launch_bounds__(NTHR) void vdvae_block_bwd_kernel(MultiArgs multi) 
     gemm_global_mid<MAXNT, false>(a, xin, nullptr, aCout, nullptr, 0, 0, aCout, w3, pl3, ring, img0, s1, M1, wave, lane, tid, acc);
     epilogue_mid(s1, M1, hh2, gg2, b1h, b1l);
     __syncthreads();
-    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w2, pl2, ring, img0, s2, M2, -1, wave, lane, tid, acc);
+    gemm_band_mid<MAXNT>(a, b1h, b1l, s1.rows, s1.ys, w2, pl2, ring, img0, s2, M2, -1, dense, wave, lane, tid, acc);
     epilogue_mid(s2, M2, hh1, gg1, b2h, b2l);
     __syncthreads();
-    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w1, pl1, ring, img0, s3, M3, -1, wave, lane, tid, acc);
+    gemm_band_mid<MAXNT>(a, b2h, b2l, s2.rows, s2.ys, w1, pl1, ring, img0, s3, M3, -1, dense, wave, lane, tid, acc);
     __syncthreads();
     epilogue_mid(s3, M3, hh0, gg0, b1h, b1l);
     __syncthreads();
@@ -781,6 +800,7 @@ static bool fill_fwd(BlockArgs& a, const pm_vdvae_block_io& io, int B, int H, in
         if (!io.w[i] || !io.bias[i]) return false;
     }
     a.B = B; a.H = H; a.W = W; a.Cin = io.Cin; a.Cout = io.Cout; a.mid = mid; a.k3 = k3;
+    a.dense = io.dense_k3;
     return true;
 }
 
@@ -794,6 +814,7 @@ static bool fill_bwd(BlockArgs& a, const pm_vdvae_block_io& io, int B, int H, in
         if (!io.w[i]) return false;
     }
     a.B = B; a.H = H; a.W = W; a.Cin = io.Cin; a.Cout = io.Cout; a.mid = mid; a.k3 = k3;
+    a.dense = io.dense_k3;
     return true;
 }
 

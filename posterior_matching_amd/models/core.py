@@ -160,13 +160,17 @@ class ParamStore:
 
         jobs, views, off, blk = [], [], 0, 0
         for pname, geom, mode, kw in self._split_requests:
-            d = geom._desc(1, mode, **{k: v for k, v in kw.items() if k != "B"})
+            d = geom._desc(1, mode, **{k: v for k, v in kw.items() if k not in ("B", "dense_k")})
             groups = d.groups
             if d.C % 8 != 0:
                 views.append(None)
                 continue
             npad = (d.N + 31) // 32 * 32
-            plane = d.KH * d.KW * ((d.C + 31) // 32 * 32) * npad      # channels zero-padded to whole 32-chunks per tap
+            dense = bool(kw.get("dense_k"))
+            if dense:                                                   # K = (tap, c) without per-tap padding (pm_split_job.dense_k)
+                plane = ((d.KH * d.KW * d.C + 31) // 32 * 32) * npad
+            else:
+                plane = d.KH * d.KW * ((d.C + 31) // 32 * 32) * npad      # channels zero-padded to whole 32-chunks per tap
             start = off
             for gi in range(groups):
                 j = SplitJob()
@@ -175,6 +179,7 @@ class ParamStore:
                 j.taps, j.C, j.N, j.npad = d.KH * d.KW, d.C, d.N, npad
                 j.wts, j.wcs, j.wns = d.wts, d.wcs, d.wns
                 j.kw, j.kws = d.KW, d.kws
+                j.dense_k = int(dense)
                 j.first_block, j.num_blocks = blk, plane // 1024        # one workgroup per 32 x 32 tile
                 blk += j.num_blocks
                 off += 2 * plane

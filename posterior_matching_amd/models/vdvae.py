@@ -48,6 +48,12 @@ class _Conv:
         store.add(self.b, (geom.CO,))
         self.ws_f = store.request_split(self.w, geom, "fwd")
         self.ws_d = store.request_split(self.w, geom, "dgrad")
+        self.ws_fd = self.ws_dd = None
+
+    def request_dense_k(self, store: ParamStore) -> None:
+        """second pair of split copies with K = (tap, c) unpadded per tap - what the fused Block reads for its 3x3 layers"""
+        self.ws_fd = store.request_split(self.w, self.g, "fwd", dense_k=True)
+        self.ws_dd = store.request_split(self.w, self.g, "dgrad", dense_k=True)
 
 
 class Block(Module):
@@ -68,6 +74,12 @@ class Block(Module):
         # get_1x1(zero_last / init_multiple = sqrt(1/N)) (:193-205): stddev * sqrt(1/N) <=> fan_in * N
         self.c4 = _Conv(store, f"{name}/c4", LayerGeom.conv(H, W, mid, cout, 1, 1, pad), 0 if zero_last else mid * out_init_div)
         self.H, self.W, self.cin, self.mid, self.cout = H, W, cin, mid, cout
+        # mid = 48: a tap's second 32-chunk is half empty in the per-tap layout (18 k-steps per 3x3 layer); K over (tap, c) is
+        # 13.5 chunks = 14 k-steps.  PM_VB_NO_DENSE=1: the per-tap copies (A/B)
+        self._dense = k == 3 and mid % 32 != 0 and not os.environ.get("PM_VB_NO_DENSE")
+        if self._dense:
+            self.c2.request_dense_k(store)
+            self.c3.request_dense_k(store)
 
     def _f(self, L: _Conv, x, out, res=None, out2=None):
         """out2: gelu(out) from the same launch (pm_gather_gemm_bf16_dual) - the next convolution's input"""
@@ -82,8 +94,9 @@ class Block(Module):
         if os.environ.get("PM_NO_VDVAE_FUSED") or not self.store.use_bf16:
             return None
         layers = (self.c1, self.c2, self.c3, self.c4)
-        f = [self.store.split_view(L.ws_f) for L in layers]
-        d = [self.store.split_view(L.ws_d) for L in layers]
+        dn = lambda L: self._dense and L in (self.c2, self.c3)   # noqa: E731
+        f = [self.store.split_view(L.ws_fd if dn(L) else L.ws_f) for L in layers]
+        d = [self.store.split_view(L.ws_dd if dn(L) else L.ws_d) for L in layers]
         if any(v is None for v in f + d):
             return None
         if not ops.vdvae_block_fused_ok(1, self.H, self.W, self.cin, self.cout, self.mid, self.c2.g.k):
@@ -105,14 +118,14 @@ class Block(Module):
         out = self.buf("out", sh(self.cout))
         biases = [self.store.p[L.b] for L in (self.c1, self.c2, self.c3, self.c4)]
         return ops.vdvae_block_io(x, self._h, self._g, out, fused[0], biases, x2=x2, res=res,
-                                  xg_out=self._xg if raw else None), out
+                                  xg_out=self._xg if raw else None, dense_k3=self._dense), out
 
     def bwd_io(self, dout: torch.Tensor, dx: torch.Tensor, x_pre: Optional[torch.Tensor], res: Optional[torch.Tensor]):
         B = dout.shape[0]
         self._dhs = [self.buf(f"dh{i + 1}", (B, self.H, self.W, self.mid)) for i in range(3)]
         self._dout = dout
         return ops.vdvae_block_io(dout, self._h, self._dhs, dx, self._fused()[1], None, res=res if x_pre is not None else None,
-                                  xpre=x_pre, backward=True)
+                                  xpre=x_pre, backward=True, dense_k3=self._dense)
 
     def weight_grads(self) -> None:
         """the four weight / bias gradients after bwd_io's launch: deferred to the end of the backward pass (one launch per

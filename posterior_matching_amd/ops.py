@@ -1158,7 +1158,8 @@ def _dp(t):
     return t.data_ptr() if t is not None else None
 
 
-def vdvae_block_io(x, hs, gs, out, wsplits, biases=None, x2=None, res=None, xpre=None, xg_out=None, backward: bool = False):
+def vdvae_block_io(x, hs, gs, out, wsplits, biases=None, x2=None, res=None, xpre=None, xg_out=None, backward: bool = False,
+                   dense_k3: bool = False):
     """one Block's operands for vdvae_blocks_fwd / _bwd (struct pm_vdvae_block_io).  fwd: x = gelu(input) (or the raw input
     with xg_out), gs = g1..g3, out = Block output;  bwd: x = dout, gs = dh1..dh3, out = dxg."""
     io = _lib.VdvaeBlockIO()
@@ -1172,6 +1173,7 @@ def vdvae_block_io(x, hs, gs, out, wsplits, biases=None, x2=None, res=None, xpre
     for i in range(3):
         io.h[i], io.g[i] = _ptr(hs[i]), _ptr(gs[i])
     io.out = _ptr(out)
+    io.dense_k3 = int(dense_k3)
     for i in range(4):
         io.w[i] = wsplits[i].data_ptr()
         io.plane[i] = wsplits[i].numel() // 2
