@@ -1681,9 +1681,14 @@ bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
 //  * one barrier (after staging); waves run the k-loop and their epilogues independently.
 // TR: the MFMAs take the weights as A and the activations as B, so a lane's accumulators are ONE output position x 16
 // columns and the epilogue moves 16-byte vectors (pm_epilogue_tile_t); N % 4 == 0.  TR = false: rows in registers, dword epilogue.
+// Row bands (nb > 1): a 28 x 28 x 32 image is 125 KB of LDS - one workgroup per CU, and a kernel of the OTHER stream cannot
+// share the CU either.  Two workgroups per image, each staging only the input rows its half of the output rows reads
+// (16 of 28 rows for the 5x5 layers: 72 KB), fit two to a CU: the staging / epilogue phases of one overlap the MFMA phase of
+// the other, within a launch and across the two streams' launches.
 template <int NW, int T, bool TR>
 __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
-                                                                     long long plane, int nct) {
+                                                                     long long plane, int nct, int nb, int ohb,
+                                                                     int npos_alloc) {
     constexpr int NSET = 4;
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const Geom& g = p.g;
@@ -1692,19 +1697,28 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     const int wave = tid >> 6;
     const int i = lane & 31;
     const int h = lane >> 5;
-    const int b = blockIdx.x;
+    const int b = (int)blockIdx.x / nb, band = (int)blockIdx.x - b * nb;
+    const int oy0 = band * ohb, oy1 = oy0 + ohb < g.OH ? oy0 + ohb : g.OH;        // this workgroup's output rows
+    int iy0 = 0, iy1 = g.IH;                                                      // the input rows they read (clipped to the image)
+    if (nb > 1) {
+        const int span = (g.KH - 1) * g.cs;
+        const int lo = oy0 * g.a + g.off + (span < 0 ? span : 0), hi = (oy1 - 1) * g.a + g.off + (span > 0 ? span : 0);
+        iy0 = lo > 0 ? lo : 0;
+        iy1 = hi + 1 < g.IH ? hi + 1 : g.IH;
+    }
     const int PS = g.C + 8;                                             // bf16 per input position (16 B pad)
     const int cch = g.C / BK;
     const int nsteps = g.KH * g.KW * cch;
-    const int npos = g.IH * g.IW;
+    const int npos = (iy1 - iy0) * g.IW;                                // staged positions (npos_alloc: the largest band's)
     __bf16* Ph = reinterpret_cast<__bf16*>(dsm);
-    __bf16* Pl = Ph + (size_t)npos * PS + 64;                           // 64 zero elements (128 B) behind each plane
-    const int zoff = npos * PS;                                         // the zero slot of a plane
+    __bf16* Pl = Ph + (size_t)npos_alloc * PS + 64;                     // 64 zero elements (128 B) behind each plane
+    const int zoff = npos_alloc * PS;                                   // the zero slot of a plane
 
     // this wave: column tile ct, row tiles rt0 + j * wct
     const int wct = NW / nct;                                           // waves per column tile
     const int ct = wave / wct, rt0 = wave - ct * wct;
-    const int Mi = g.OH * g.OW;
+    const int Mi = (oy1 - oy0) * g.OW;                                  // output positions of this workgroup
+    const int m0 = oy0 * g.OW, Mfull = g.OH * g.OW;
     const int n = ct * 32 + i;
     const int ncl = (n < npad ? n : 0) * BK + 8 * h;
 
@@ -1729,7 +1743,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     }
 #if !(defined(PM_EXP) && PM_EXP == 31)
     {   // the image: f32 -> in_act -> hi / lo bf16; a linear read, up to 13 float4 per thread in flight
-        const float* img = p.in + (size_t)b * npos * g.C;
+        const float* img = p.in + ((size_t)b * g.IH + iy0) * g.IW * g.C;
         const int c4n = g.C >> 2;
         const int total = npos * c4n;
         const bool in_relu = g.in_act == PM_ACT_RELU;
@@ -1765,7 +1779,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
             for (int o = c4n; o < 64; o <<= 1)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) csum[q] += __shfl_xor(csum[q], o, 64);
-            float* cs = reinterpret_cast<float*>(Pl + (size_t)npos * PS + 64);
+            float* cs = reinterpret_cast<float*>(Pl + (size_t)npos_alloc * PS + 64);
             if (lane < c4n) *reinterpret_cast<f32x4*>(cs + wave * g.C + 4 * lane) = csum;
         }
     }
@@ -1777,7 +1791,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     for (int j = 0; j < T; ++j) {
         const int m = 32 * (rt0 + j * wct) + i;
         const int oy = m / g.OW, ox = m - oy * g.OW;
-        py[j] = m < Mi ? oy * g.a + g.off : ROW_INVALID;
+        py[j] = m < Mi ? (oy0 + oy) * g.a + g.off - iy0 : ROW_INVALID;    // relative to the first staged row
         px[j] = ox * g.a + g.offx;
     }
 
@@ -1789,7 +1803,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
 
     __syncthreads();                 // image visible; the only barrier of the kernel
     if (p.in_colsum && tid < g.C) {  // the image's channel sums (the NW waves' rows) -> one atomic per channel and image
-        const float* cs = reinterpret_cast<const float*>(Pl + (size_t)npos * PS + 64);
+        const float* cs = reinterpret_cast<const float*>(Pl + (size_t)npos_alloc * PS + 64);
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += cs[w * g.C + tid];
@@ -1814,8 +1828,8 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         return t;
     };
     auto read_a = [&](const Tap& k, int j, bf16x8 (&aa)[4]) {
-        const int iy = py[j] + k.dy, ix = px[j] + k.dx;
-        const bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+        const int iy = py[j] + k.dy, ix = px[j] + k.dx;                 // iy: row within the staged rows
+        const bool ok = (unsigned)(iy + iy0) < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
         const int o = (ok ? (iy * g.IW + ix) * PS + k.c0 : zoff) + 8 * h;
         aa[0] = *reinterpret_cast<const bf16x8*>(Ph + o);
         aa[1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
@@ -1886,8 +1900,8 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         if (TR) {
 #pragma unroll
             for (int j = 0; j < T; ++j) {
-                const int m = 32 * (rt0 + j * wct) + i;                 // this lane's output position
-                const long long ro = m < Mi ? ((long long)b * Mi + m) * g.N : -1;
+                const int m = 32 * (rt0 + j * wct) + i;                 // this lane's output position (within the band)
+                const long long ro = m < Mi ? ((long long)b * Mfull + m0 + m) * g.N : -1;
                 pm_epilogue_tile_t(acc[j], ro, ct * 32, h, g.N, p.bias, p.aux, p.res, p.out, p.out2, p.act2, g.aux_act,
                                    g.out_act, g.slope);
             }
@@ -1898,7 +1912,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = 32 * (rt0 + j * wct) + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    ro[e] = m < Mi ? (b * Mi + m) * g.N : -1;
+                    ro[e] = m < Mi ? (b * Mfull + m0 + m) * g.N : -1;
                 }
                 pm_epilogue_tile(acc[j], ro, n, bv, p.aux, p.res, p.out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
             }
@@ -1906,9 +1920,9 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     }
 }
 
-struct ImagePlan { int nw, t, nct; size_t lds; };
+struct ImagePlan { int nw, t, nct; size_t lds; int nb, ohb, npos_alloc; };
 // qualifies: plain d = 1 problems (any stride a) whose input image fits LDS as hi / lo planes, batches that fill the chip
-bool plan_image(const Geom& g, int groups, ImagePlan& ip) {
+bool plan_image(const Geom& g, int groups, ImagePlan& ip, bool allow_bands = true) {
     if (groups != 1 || g.d != 1 || g.C % BK != 0 || g.B < 128) return false;
     if (g.in_act != PM_ACT_NONE && g.in_act != PM_ACT_RELU && g.in_act != PM_ACT_LEAKY) return false;
     // 1x1: the dense form.  Masked sub-kernels (kws > KW: the PixelCNN's horizontal stack, 2 x 2 of a 3 x 3 kernel) qualify like
@@ -1922,9 +1936,30 @@ bool plan_image(const Geom& g, int groups, ImagePlan& ip) {
     if (nsteps > 2048) return false;
     ip.lds = 2 * ((size_t)g.IH * g.IW * (g.C + 8) + 64) * 2;
     if (ip.lds > 158 * 1024) return false;
+    ip.nb = 1; ip.ohb = g.OH; ip.npos_alloc = g.IH * g.IW;
+    // two row bands per image when that brings a workgroup from one per CU (> 80 KB) to two per CU.  MEASURED SLOWER in the
+    // PM-VAE step (180.9 - 182.5 k img/s against 186.9 - 187.4 k, three same-box pairs): the halo rows are staged twice, a weight
+    // fragment serves two row tiles instead of four, and what two resident workgroups overlap does not make up for it.  Opt-in
+    // (PM_IMAGE_BANDS=1, read per call so that the parity cases can switch it on); parity-tested.
+    const bool bands_on = getenv("PM_IMAGE_BANDS") != nullptr;
+    if (allow_bands && bands_on && ip.lds > 80 * 1024 && g.OH >= 8) {
+        const int ohb = (g.OH + 1) / 2, span = (g.KH - 1) * g.cs;
+        int rows = 0;
+        for (int band = 0; band < 2; ++band) {
+            const int oy0 = band * ohb, oy1 = oy0 + ohb < g.OH ? oy0 + ohb : g.OH;
+            int lo = oy0 * g.a + g.off + (span < 0 ? span : 0), hi = (oy1 - 1) * g.a + g.off + (span > 0 ? span : 0);
+            lo = lo > 0 ? lo : 0;
+            hi = hi + 1 < g.IH ? hi + 1 : g.IH;
+            rows = hi - lo > rows ? hi - lo : rows;
+        }
+        const size_t lds2 = 2 * ((size_t)rows * g.IW * (g.C + 8) + 64) * 2;
+        if (rows > 0 && lds2 <= 80 * 1024) {
+            ip.nb = 2; ip.ohb = ohb; ip.npos_alloc = rows * g.IW; ip.lds = lds2;
+        }
+    }
     ip.nct = (g.N + 31) / 32;
     if (ip.nct > 8 || (8 % ip.nct) != 0) return false;
-    const int rt = (g.OH * g.OW + 31) / 32;
+    const int rt = (ip.ohb * g.OW + 31) / 32;
     ip.nw = rt * ip.nct <= 4 ? 4 : 8;
     if (ip.nw % ip.nct != 0) return false;
     const int wct = ip.nw / ip.nct;
@@ -1944,9 +1979,10 @@ void launch_image_tr(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, cons
     }
     PM_KTAG("image_conv_bf16_kernel<%d, %d, %s>", NW, T, TR ? "true" : "false");
     if (a.in_colsum) PM_KVAR("insum");
+    else if (ip.nb > 1) PM_KVAR("bands");
     const size_t lds = ip.lds + (a.in_colsum ? (size_t)NW * a.g.C * sizeof(float) : 0);
-    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T, TR>), dim3((unsigned)a.g.B), dim3(64 * NW), lds, s, a, ws, npad, plane,
-                       ip.nct);
+    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T, TR>), dim3((unsigned)(a.g.B * ip.nb)), dim3(64 * NW), lds, s, a, ws, npad,
+                       plane, ip.nct, ip.nb, ip.ohb, ip.npos_alloc);
 }
 template <int NW, int T>
 void launch_image(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const __bf16* ws, int npad, long long plane) {
@@ -3866,7 +3902,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
     if (in_colsum) {
         ImagePlan ipc;
-        if (plan_skinny(a.g, G) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, G, ipc) || !image_insum_ok(a.g, ipc))
+        if (plan_skinny(a.g, G) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, G, ipc, false) || !image_insum_ok(a.g, ipc))
             return PM_EINVAL;
     }
     if (plan_skinny(a.g, G)) {                         // one output position, few rows, long K: one launch, K over the waves
@@ -3878,7 +3914,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     }
     ImagePlan ip;
     static const bool image_off = getenv("PM_NO_IMAGE_CONV") != nullptr;   // A/B switch for measurements
-    if (!image_off && plan_image(a.g, G, ip)) {       // whole input image of a workgroup resident in LDS
+    if (!image_off && plan_image(a.g, G, ip, in_colsum == nullptr)) {       // whole input image of a workgroup resident in LDS
         a.ksplit = 1;
         if (ip.nw == 8 && ip.t == 4) launch_image<8, 4>(ip, s, a, ws, npad, plane);
         else if (ip.nw == 8 && ip.t == 2) launch_image<8, 2>(ip, s, a, ws, npad, plane);
@@ -3979,7 +4015,7 @@ extern "C" int pm_image_conv_insum_applies(const pm_gather_desc* d) {
     GemmArgs a;
     ImagePlan ip;
     if (!d || !fill_geom(d, a.g, true) || d->C % 8 != 0 || d->d != 1) return 0;
-    if (plan_skinny(a.g, d->groups) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, d->groups, ip)) return 0;
+    if (plan_skinny(a.g, d->groups) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, d->groups, ip, false)) return 0;
     return image_insum_ok(a.g, ip) ? 1 : 0;
 }
 
