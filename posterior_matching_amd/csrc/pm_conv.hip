@@ -2544,8 +2544,9 @@ struct SplitJob {
 // job.  A source tile is read along whichever of its axes is contiguous in the parameter buffer (columns n for HWIO forward
 // weights, channels c for the data-gradient direction) and written k-contiguous; a 32 x 33 LDS tile does the transpose.
 // All 4 x SPLIT_TPB loads of a thread are issued before the first is used, the job of the first tile is found with one
-// parallel pass over the job table (not a 9-deep chain of dependent loads per 1024 elements, which is what made this kernel
-// 1.1 ms at the 35 M-parameter PixelCNN: 0.5 TB/s), and a thread stores 4 bf16 = 8 bytes per plane and tile.
+// parallel pass over the job table (not a 9-deep chain of dependent loads per 1024 elements), and a thread stores 4 bf16 =
+// 8 bytes per plane and tile: ~99 -> 63 us per launch at the 35 M-parameter PixelCNN (steady state; rocprofv3 averages of
+// this kernel carry one ~15 ms first-touch call).
 // SPLIT_TPB = 8 for large stores, 2 for small ones (the PM-VAE's 4 k tiles are 2 k workgroups instead of 500).
 
 struct SplitTile {
