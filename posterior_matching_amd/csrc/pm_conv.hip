@@ -3228,6 +3228,168 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     }
 }
 
+// The 128 x 128-tile case for LARGE weight gradients (the PixelCNN's 256- / 512-channel masked convolutions over 12 544 rows,
+// grouped eight to sixteen layers to a launch: 2.9 ms of chip-filling launches at the end of a pm_vqvae_mnist step).  With
+// 64 x 64 tiles a workgroup moves 32 KB of operands from L2 per 64-row chunk for 64 x 64 x 64 MACs - every element of the
+// gathered operand is fetched N / 64 times and every element of the dense one K / 64 times (conv2 of a vertical block:
+// 8 and 48 times, 19 GB per launch through L2); a 128 x 128 tile halves both.  Four waves, each a 64 x 64 block (four 32 x 32
+// accumulators: one A / B fragment pair feeds 12 MFMAs instead of 3), 64-row chunks, 70 KB of LDS (two workgroups per CU).
+// Needs C % 128 == 0 (a 128-wide k-block inside one tap); flush with atomics like the 64 x 64 form.
+template <int DD, int BMC>
+__global__ __launch_bounds__(256, BMC == 32 ? 3 : 2) void gather_wgrad_bf16_big_kernel(WgradArgs p) {
+    constexpr int CB = 128, NB = 128;
+    constexpr int GS = CB + 8, DS = NB + 8;
+    extern __shared__ __attribute__((aligned(16))) short smem_big[];
+    short* Gh = smem_big;
+    short* Gl = Gh + BMC * GS;
+    short* Dh = Gl + BMC * GS;
+    short* Dl = Dh + BMC * DS;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1, wn = wave & 1;      // this wave's 64 x 64 block of the 128 x 128 tile
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int tile = blockIdx.x % p.ntiles;
+    const int split = blockIdx.x / p.ntiles;
+    const int nkb = g.K / CB;
+    const int kkb = tile % nkb;
+    const int nb = tile / nkb;
+    const int kk0 = kkb * CB;
+    const int n0 = nb * NB;
+    const int grp = blockIdx.z;
+    const float* gin = p.gathered + wg_off(p, grp, 0, p.in_gs);
+    const float* din = p.dense + wg_off(p, grp, 1, p.out_gs);
+    const bool do_bias = (p.db != nullptr) && (kkb == 0);          // workgroup-uniform: the first k-block of every column block
+    const int tap_u = kk0 / g.C;
+    const int c_u = kk0 - tap_u * g.C;
+    const int ky_u = tap_u / g.KW;
+    const int kx_u = tap_u - ky_u * g.KW;
+
+    const int total_chunks = (g.M + BMC - 1) / BMC;
+    const int c_begin = split * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    // one chunk of operands in flight per thread (two - a second loader and register set - was measured: 350 registers, one wave
+    // per SIMD, 22.5 k img/s against 25.8 k)
+    LoaderV4<BMC, CB, DD> lg0;
+    lg0.init(tid);
+    constexpr int DSLOTS = NB / 4;
+    constexpr int DRPP = 256 / DSLOTS;
+    constexpr int DNP = BMC / DRPP;
+    const int dslot = tid % DSLOTS;
+    const int dr0 = tid / DSLOTS;
+    const int dn = n0 + dslot * 4;
+    const bool dn_ok = dn < g.N;
+    f32x4 dreg0[DNP];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};              // bias gradient: this thread's 4 columns over the rows it stages
+    auto load_d = [&](int m0, f32x4 (&dreg)[DNP]) {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            const int m = m0 + dr0 + j * DRPP;
+            const bool ok = m < g.M && dn_ok;
+            dreg[j] = *reinterpret_cast<const f32x4*>(din + (ok ? (size_t)m * g.N + dn : 0));
+        }
+    };
+    auto store_d = [&](int m0, f32x4 (&dreg)[DNP]) {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            const bool ok = (m0 + dr0 + j * DRPP) < g.M && dn_ok;
+            f32x4 v = dreg[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            bsum += v;
+            u32x2 h2, l2;
+            split4(v, h2, l2);
+            *reinterpret_cast<u32x2*>(Dh + (dr0 + j * DRPP) * DS + dslot * 4) = h2;
+            *reinterpret_cast<u32x2*>(Dl + (dr0 + j * DRPP) * DS + dslot * 4) = l2;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int gq = lane >> 4;
+    const int q = (lane & 15) >> 2;
+    const int pq = lane & 3;
+    const int tr_row = 8 * (gq >> 1) + q;
+    const int tr_col = 16 * (gq & 1) + 4 * pq;
+
+    if (c_begin < c_end) {
+        lg0.set_rows(g, c_begin * BMC);
+        lg0.load_tap(g, gin, ky_u, kx_u, c_u, true);
+        load_d(c_begin * BMC, dreg0);
+    }
+    auto mma_chunk = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < BMC / 16; ++ks) {
+            const int row = 16 * ks + tr_row;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = tr_frag(Gh + row * GS + 64 * wc + 32 * a + tr_col, GS);
+                al[a] = tr_frag(Gl + row * GS + 64 * wc + 32 * a + tr_col, GS);
+                bh[a] = tr_frag(Dh + row * DS + 64 * wn + 32 * a + tr_col, DS);
+                bl[a] = tr_frag(Dl + row * DS + 64 * wn + 32 * a + tr_col, DS);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        lg0.store_split(g, Gh, Gl, GS);
+        store_d(ch * BMC, dreg0);
+        __syncthreads();
+        if (ch + 1 < c_end) {
+            lg0.advance_rows(g, (ch + 1) * BMC, p.step_b, p.step_p, p.step_q);
+            lg0.load_tap(g, gin, ky_u, kx_u, c_u, true);
+            load_d((ch + 1) * BMC, dreg0);
+        }
+        mma_chunk();
+        __syncthreads();
+    }
+
+    // flush straight from the C/D layout: col = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * h (k index)
+    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
+    const int wtap = (tap_u / g.KW) * g.kws + tap_u % g.KW;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + 64 * wn + 32 * b + i;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = c_u + 64 * wc + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[a][b][e]);
+            }
+    }
+    if (do_bias) {               // the 8 threads of a column quad (dr0 = 0 .. 7) meet in LDS, one atomic per column
+        float* red = reinterpret_cast<float*>(smem_big);                  // the tiles are dead (barrier at the end of the loop)
+        *reinterpret_cast<f32x4*>(red + (dr0 * DSLOTS + dslot) * 4) = bsum;
+        __syncthreads();
+        if (tid < NB && n0 + tid < g.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < DRPP; ++r) t += red[(r * DSLOTS + tid / 4) * 4 + (tid & 3)];
+            atomicAdd(p.db + wg_off(p, grp, 3, p.bias_gs) + n0 + tid, t);
+        }
+    }
+}
+
 // ----------------------- stride-1 weight gradients, patch-staged form (bf16x3) -----------------------
 // gather_wgrad_bf16_kernel gives every (tap x 32 channels) block its own workgroups: each of them re-gathers the
 // input rows and re-reads the dense operand (measured on the 28x28 5x5 layers: 212 MB of HBM-side traffic per
@@ -4139,6 +4301,44 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
         }
     }
     a.cpad = cpad ? 1 : 0;
+    {   // large problems with 128-channel-aligned taps: 128 x 128 tiles (PM_WG_NOBIG=1: the 64 x 64 form, for A/B runs)
+        const Geom& g = a.g;
+        const long long work = (long long)g.M * g.K * g.N * d->groups;
+        if (!getenv("PM_WG_NOBIG") && !cpad && g.C % 128 == 0 && g.K >= 512 && g.N >= 128 && g.M >= 2048 && work >= (1LL << 30)) {
+            const int nkb = g.K / 128, nnb = (g.N + 127) / 128;
+            static const int bmc = getenv("PM_WG_BIG_BMC") ? atoi(getenv("PM_WG_BIG_BMC")) : 32;   // rows per chunk (A/B knob)
+            const int total_chunks = (g.M + bmc - 1) / bmc;
+            long long tiles = (long long)nkb * nnb * d->groups;
+            static const int target = getenv("PM_WG_BIG_TARGET") ? atoi(getenv("PM_WG_BIG_TARGET")) : 1536;   // workgroups wanted (A/B knob)
+            int splits = (int)((target + tiles - 1) / tiles);
+            if (splits > total_chunks / 16) splits = total_chunks / 16;
+            if (splits < 1) splits = 1;
+            a.chunks_per_split = (total_chunks + splits - 1) / splits;
+            splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+            const int hw = g.OH * g.OW;
+            a.step_b = bmc / hw;
+            a.step_p = (bmc - a.step_b * hw) / g.OW;
+            a.step_q = bmc - a.step_b * hw - a.step_p * g.OW;
+            a.ntiles = nkb * nnb;
+            a.nsplits = splits;
+            a.xcd_map = 0;
+            const size_t lds = (size_t)2 * bmc * (136 + 136) * sizeof(short);
+            static bool attr_big = false;
+            if (!attr_big) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_wgrad_bf16_big_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_wgrad_bf16_big_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                attr_big = true;
+            }
+            dim3 gridb(a.ntiles * splits, 1, d->groups);
+            PM_KTAG("gather_wgrad_bf16_big_kernel<%d, %d>", d->d, bmc);
+            hipStream_t sb = (hipStream_t)stream;
+            if (d->d == 1 && bmc == 64) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<1, 64>), gridb, dim3(256), lds, sb, a);
+            else if (d->d == 1) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<1, 32>), gridb, dim3(256), lds, sb, a);
+            else if (bmc == 64) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<2, 64>), gridb, dim3(256), lds, sb, a);
+            else hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<2, 32>), gridb, dim3(256), lds, sb, a);
+            return pm_check_launch("pm_gather_wgrad_bf16(big)");
+        }
+    }
     Geom gplan = a.g;
     if (cpad) {                 // planned as the 64-channel problem it is executed as
         gplan.C = 64;
