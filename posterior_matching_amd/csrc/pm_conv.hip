@@ -1681,14 +1681,9 @@ bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
 //  * one barrier (after staging); waves run the k-loop and their epilogues independently.
 // TR: the MFMAs take the weights as A and the activations as B, so a lane's accumulators are ONE output position x 16
 // columns and the epilogue moves 16-byte vectors (pm_epilogue_tile_t); N % 4 == 0.  TR = false: rows in registers, dword epilogue.
-// Row bands (nb > 1): a 28 x 28 x 32 image is 125 KB of LDS - one workgroup per CU, and a kernel of the OTHER stream cannot
-// share the CU either.  Two workgroups per image, each staging only the input rows its half of the output rows reads
-// (16 of 28 rows for the 5x5 layers: 72 KB), fit two to a CU: the staging / epilogue phases of one overlap the MFMA phase of
-// the other, within a launch and across the two streams' launches.
 template <int NW, int T, bool TR>
 __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
-                                                                     long long plane, int nct, int nb, int ohb,
-                                                                     int npos_alloc) {
+                                                                     long long plane, int nct) {
     constexpr int NSET = 4;
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const Geom& g = p.g;
@@ -1697,28 +1692,19 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     const int wave = tid >> 6;
     const int i = lane & 31;
     const int h = lane >> 5;
-    const int b = (int)blockIdx.x / nb, band = (int)blockIdx.x - b * nb;
-    const int oy0 = band * ohb, oy1 = oy0 + ohb < g.OH ? oy0 + ohb : g.OH;        // this workgroup's output rows
-    int iy0 = 0, iy1 = g.IH;                                                      // the input rows they read (clipped to the image)
-    if (nb > 1) {
-        const int span = (g.KH - 1) * g.cs;
-        const int lo = oy0 * g.a + g.off + (span < 0 ? span : 0), hi = (oy1 - 1) * g.a + g.off + (span > 0 ? span : 0);
-        iy0 = lo > 0 ? lo : 0;
-        iy1 = hi + 1 < g.IH ? hi + 1 : g.IH;
-    }
+    const int b = blockIdx.x;
     const int PS = g.C + 8;                                             // bf16 per input position (16 B pad)
     const int cch = g.C / BK;
     const int nsteps = g.KH * g.KW * cch;
-    const int npos = (iy1 - iy0) * g.IW;                                // staged positions (npos_alloc: the largest band's)
+    const int npos = g.IH * g.IW;
     __bf16* Ph = reinterpret_cast<__bf16*>(dsm);
-    __bf16* Pl = Ph + (size_t)npos_alloc * PS + 64;                     // 64 zero elements (128 B) behind each plane
-    const int zoff = npos_alloc * PS;                                   // the zero slot of a plane
+    __bf16* Pl = Ph + (size_t)npos * PS + 64;                           // 64 zero elements (128 B) behind each plane
+    const int zoff = npos * PS;                                         // the zero slot of a plane
 
     // this wave: column tile ct, row tiles rt0 + j * wct
     const int wct = NW / nct;                                           // waves per column tile
     const int ct = wave / wct, rt0 = wave - ct * wct;
-    const int Mi = (oy1 - oy0) * g.OW;                                  // output positions of this workgroup
-    const int m0 = oy0 * g.OW, Mfull = g.OH * g.OW;
+    const int Mi = g.OH * g.OW;
     const int n = ct * 32 + i;
     const int ncl = (n < npad ? n : 0) * BK + 8 * h;
 
@@ -1743,13 +1729,13 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     }
 #if !(defined(PM_EXP) && PM_EXP == 31)
     {   // the image: f32 -> in_act -> hi / lo bf16; a linear read, up to 13 float4 per thread in flight
-        const float* img = p.in + ((size_t)b * g.IH + iy0) * g.IW * g.C;
+        const float* img = p.in + (size_t)b * npos * g.C;
         const int c4n = g.C >> 2;
         const int total = npos * c4n;
         const bool in_relu = g.in_act == PM_ACT_RELU;
         const float in_ns = g.in_act == PM_ACT_LEAKY ? g.slope : 1.f;
         constexpr int PB = NW == 8 ? 13 : 8;                             // 28 x 28 x 32 on 512 threads: 12.25 per thread
-        f32x4 csum = {0.f, 0.f, 0.f, 0.f};                               // in_colsum: this thread's channel quad never changes
+        [[maybe_unused]] f32x4 csum = {0.f, 0.f, 0.f, 0.f};              // in_colsum: this thread's channel quad never changes
         for (int e0 = tid; e0 < total; e0 += 64 * NW * PB) {             // (c4n divides 64: the launcher checks)
             f32x4 v[PB];
 #pragma unroll
@@ -1762,7 +1748,9 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
                 const int e = e0 + 64 * NW * j;
                 const int ee = e < total ? e : total - 1;               // the overhang rewrites the last piece: harmless
                 const int pos = ee / c4n, c4 = ee - pos * c4n;
+#ifdef PM_IMAGE_INSUM
                 if (e < total) csum += v[j];
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float x = v[j][q];
@@ -1775,13 +1763,15 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
                 *reinterpret_cast<u32x2*>(Pl + pos * PS + 4 * c4) = l2;
             }
         }
+#ifdef PM_IMAGE_INSUM
         if (p.in_colsum) {           // lanes l, l + c4n, ... of a wave hold the same channel quad: one row of sums per wave
             for (int o = c4n; o < 64; o <<= 1)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) csum[q] += __shfl_xor(csum[q], o, 64);
-            float* cs = reinterpret_cast<float*>(Pl + (size_t)npos_alloc * PS + 64);
+            float* cs = reinterpret_cast<float*>(Pl + (size_t)npos * PS + 64);
             if (lane < c4n) *reinterpret_cast<f32x4*>(cs + wave * g.C + 4 * lane) = csum;
         }
+#endif
     }
 
 #endif
@@ -1791,7 +1781,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     for (int j = 0; j < T; ++j) {
         const int m = 32 * (rt0 + j * wct) + i;
         const int oy = m / g.OW, ox = m - oy * g.OW;
-        py[j] = m < Mi ? (oy0 + oy) * g.a + g.off - iy0 : ROW_INVALID;    // relative to the first staged row
+        py[j] = m < Mi ? oy * g.a + g.off : ROW_INVALID;
         px[j] = ox * g.a + g.offx;
     }
 
@@ -1802,13 +1792,15 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
     __syncthreads();                 // image visible; the only barrier of the kernel
+#ifdef PM_IMAGE_INSUM
     if (p.in_colsum && tid < g.C) {  // the image's channel sums (the NW waves' rows) -> one atomic per channel and image
-        const float* cs = reinterpret_cast<const float*>(Pl + (size_t)npos_alloc * PS + 64);
+        const float* cs = reinterpret_cast<const float*>(Pl + (size_t)npos * PS + 64);
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += cs[w * g.C + tid];
         atomicAdd(p.in_colsum + tid, t);
     }
+#endif
 
     // A fragments run TWO (k-step, row tile) items ahead of the MFMAs in four static register sets (item index mod 4); the
     // tap walk (ky, kx, channel chunk) of the three k-steps in flight is kept in scalar registers - with the table lookup
@@ -1828,8 +1820,8 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         return t;
     };
     auto read_a = [&](const Tap& k, int j, bf16x8 (&aa)[4]) {
-        const int iy = py[j] + k.dy, ix = px[j] + k.dx;                 // iy: row within the staged rows
-        const bool ok = (unsigned)(iy + iy0) < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+        const int iy = py[j] + k.dy, ix = px[j] + k.dx;
+        const bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
         const int o = (ok ? (iy * g.IW + ix) * PS + k.c0 : zoff) + 8 * h;
         aa[0] = *reinterpret_cast<const bf16x8*>(Ph + o);
         aa[1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
@@ -1900,8 +1892,8 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         if (TR) {
 #pragma unroll
             for (int j = 0; j < T; ++j) {
-                const int m = 32 * (rt0 + j * wct) + i;                 // this lane's output position (within the band)
-                const long long ro = m < Mi ? ((long long)b * Mfull + m0 + m) * g.N : -1;
+                const int m = 32 * (rt0 + j * wct) + i;                 // this lane's output position
+                const long long ro = m < Mi ? ((long long)b * Mi + m) * g.N : -1;
                 pm_epilogue_tile_t(acc[j], ro, ct * 32, h, g.N, p.bias, p.aux, p.res, p.out, p.out2, p.act2, g.aux_act,
                                    g.out_act, g.slope);
             }
@@ -1912,7 +1904,7 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = 32 * (rt0 + j * wct) + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    ro[e] = m < Mi ? (b * Mfull + m0 + m) * g.N : -1;
+                    ro[e] = m < Mi ? (b * Mi + m) * g.N : -1;
                 }
                 pm_epilogue_tile(acc[j], ro, n, bv, p.aux, p.res, p.out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
             }
@@ -1920,9 +1912,9 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
     }
 }
 
-struct ImagePlan { int nw, t, nct; size_t lds; int nb, ohb, npos_alloc; };
+struct ImagePlan { int nw, t, nct; size_t lds; };
 // qualifies: plain d = 1 problems (any stride a) whose input image fits LDS as hi / lo planes, batches that fill the chip
-bool plan_image(const Geom& g, int groups, ImagePlan& ip, bool allow_bands = true) {
+bool plan_image(const Geom& g, int groups, ImagePlan& ip) {
     if (groups != 1 || g.d != 1 || g.C % BK != 0 || g.B < 128) return false;
     if (g.in_act != PM_ACT_NONE && g.in_act != PM_ACT_RELU && g.in_act != PM_ACT_LEAKY) return false;
     // 1x1: the dense form.  Masked sub-kernels (kws > KW: the PixelCNN's horizontal stack, 2 x 2 of a 3 x 3 kernel) qualify like
@@ -1936,30 +1928,9 @@ bool plan_image(const Geom& g, int groups, ImagePlan& ip, bool allow_bands = tru
     if (nsteps > 2048) return false;
     ip.lds = 2 * ((size_t)g.IH * g.IW * (g.C + 8) + 64) * 2;
     if (ip.lds > 158 * 1024) return false;
-    ip.nb = 1; ip.ohb = g.OH; ip.npos_alloc = g.IH * g.IW;
-    // two row bands per image when that brings a workgroup from one per CU (> 80 KB) to two per CU.  MEASURED SLOWER in the
-    // PM-VAE step (180.9 - 182.5 k img/s against 186.9 - 187.4 k, three same-box pairs): the halo rows are staged twice, a weight
-    // fragment serves two row tiles instead of four, and what two resident workgroups overlap does not make up for it.  Opt-in
-    // (PM_IMAGE_BANDS=1, read per call so that the parity cases can switch it on); parity-tested.
-    const bool bands_on = getenv("PM_IMAGE_BANDS") != nullptr;
-    if (allow_bands && bands_on && ip.lds > 80 * 1024 && g.OH >= 8) {
-        const int ohb = (g.OH + 1) / 2, span = (g.KH - 1) * g.cs;
-        int rows = 0;
-        for (int band = 0; band < 2; ++band) {
-            const int oy0 = band * ohb, oy1 = oy0 + ohb < g.OH ? oy0 + ohb : g.OH;
-            int lo = oy0 * g.a + g.off + (span < 0 ? span : 0), hi = (oy1 - 1) * g.a + g.off + (span > 0 ? span : 0);
-            lo = lo > 0 ? lo : 0;
-            hi = hi + 1 < g.IH ? hi + 1 : g.IH;
-            rows = hi - lo > rows ? hi - lo : rows;
-        }
-        const size_t lds2 = 2 * ((size_t)rows * g.IW * (g.C + 8) + 64) * 2;
-        if (rows > 0 && lds2 <= 80 * 1024) {
-            ip.nb = 2; ip.ohb = ohb; ip.npos_alloc = rows * g.IW; ip.lds = lds2;
-        }
-    }
     ip.nct = (g.N + 31) / 32;
     if (ip.nct > 8 || (8 % ip.nct) != 0) return false;
-    const int rt = (ip.ohb * g.OW + 31) / 32;
+    const int rt = (g.OH * g.OW + 31) / 32;
     ip.nw = rt * ip.nct <= 4 ? 4 : 8;
     if (ip.nw % ip.nct != 0) return false;
     const int wct = ip.nw / ip.nct;
@@ -1979,10 +1950,9 @@ void launch_image_tr(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, cons
     }
     PM_KTAG("image_conv_bf16_kernel<%d, %d, %s>", NW, T, TR ? "true" : "false");
     if (a.in_colsum) PM_KVAR("insum");
-    else if (ip.nb > 1) PM_KVAR("bands");
     const size_t lds = ip.lds + (a.in_colsum ? (size_t)NW * a.g.C * sizeof(float) : 0);
-    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T, TR>), dim3((unsigned)(a.g.B * ip.nb)), dim3(64 * NW), lds, s, a, ws, npad,
-                       plane, ip.nct, ip.nb, ip.ohb, ip.npos_alloc);
+    hipLaunchKernelGGL((image_conv_bf16_kernel<NW, T, TR>), dim3((unsigned)a.g.B), dim3(64 * NW), lds, s, a, ws, npad, plane,
+                       ip.nct);
 }
 template <int NW, int T>
 void launch_image(const ImagePlan& ip, hipStream_t s, const GemmArgs& a, const __bf16* ws, int npad, long long plane) {
@@ -3228,168 +3198,6 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     }
 }
 
-// The 128 x 128-tile case for LARGE weight gradients (the PixelCNN's 256- / 512-channel masked convolutions over 12 544 rows,
-// grouped eight to sixteen layers to a launch: 2.9 ms of chip-filling launches at the end of a pm_vqvae_mnist step).  With
-// 64 x 64 tiles a workgroup moves 32 KB of operands from L2 per 64-row chunk for 64 x 64 x 64 MACs - every element of the
-// gathered operand is fetched N / 64 times and every element of the dense one K / 64 times (conv2 of a vertical block:
-// 8 and 48 times, 19 GB per launch through L2); a 128 x 128 tile halves both.  Four waves, each a 64 x 64 block (four 32 x 32
-// accumulators: one A / B fragment pair feeds 12 MFMAs instead of 3), 64-row chunks, 70 KB of LDS (two workgroups per CU).
-// Needs C % 128 == 0 (a 128-wide k-block inside one tap); flush with atomics like the 64 x 64 form.
-template <int DD, int BMC>
-__global__ __launch_bounds__(256, BMC == 32 ? 3 : 2) void gather_wgrad_bf16_big_kernel(WgradArgs p) {
-    constexpr int CB = 128, NB = 128;
-    constexpr int GS = CB + 8, DS = NB + 8;
-    extern __shared__ __attribute__((aligned(16))) short smem_big[];
-    short* Gh = smem_big;
-    short* Gl = Gh + BMC * GS;
-    short* Dh = Gl + BMC * GS;
-    short* Dl = Dh + BMC * DS;
-
-    const Geom& g = p.g;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wc = wave >> 1, wn = wave & 1;      // this wave's 64 x 64 block of the 128 x 128 tile
-    const int i = lane & 31;
-    const int h = lane >> 5;
-    const int tile = blockIdx.x % p.ntiles;
-    const int split = blockIdx.x / p.ntiles;
-    const int nkb = g.K / CB;
-    const int kkb = tile % nkb;
-    const int nb = tile / nkb;
-    const int kk0 = kkb * CB;
-    const int n0 = nb * NB;
-    const int grp = blockIdx.z;
-    const float* gin = p.gathered + wg_off(p, grp, 0, p.in_gs);
-    const float* din = p.dense + wg_off(p, grp, 1, p.out_gs);
-    const bool do_bias = (p.db != nullptr) && (kkb == 0);          // workgroup-uniform: the first k-block of every column block
-    const int tap_u = kk0 / g.C;
-    const int c_u = kk0 - tap_u * g.C;
-    const int ky_u = tap_u / g.KW;
-    const int kx_u = tap_u - ky_u * g.KW;
-
-    const int total_chunks = (g.M + BMC - 1) / BMC;
-    const int c_begin = split * p.chunks_per_split;
-    int c_end = c_begin + p.chunks_per_split;
-    if (c_end > total_chunks) c_end = total_chunks;
-
-    // one chunk of operands in flight per thread (two - a second loader and register set - was measured: 350 registers, one wave
-    // per SIMD, 22.5 k img/s against 25.8 k)
-    LoaderV4<BMC, CB, DD> lg0;
-    lg0.init(tid);
-    constexpr int DSLOTS = NB / 4;
-    constexpr int DRPP = 256 / DSLOTS;
-    constexpr int DNP = BMC / DRPP;
-    const int dslot = tid % DSLOTS;
-    const int dr0 = tid / DSLOTS;
-    const int dn = n0 + dslot * 4;
-    const bool dn_ok = dn < g.N;
-    f32x4 dreg0[DNP];
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};              // bias gradient: this thread's 4 columns over the rows it stages
-    auto load_d = [&](int m0, f32x4 (&dreg)[DNP]) {
-#pragma unroll
-        for (int j = 0; j < DNP; ++j) {
-            const int m = m0 + dr0 + j * DRPP;
-            const bool ok = m < g.M && dn_ok;
-            dreg[j] = *reinterpret_cast<const f32x4*>(din + (ok ? (size_t)m * g.N + dn : 0));
-        }
-    };
-    auto store_d = [&](int m0, f32x4 (&dreg)[DNP]) {
-#pragma unroll
-        for (int j = 0; j < DNP; ++j) {
-            const bool ok = (m0 + dr0 + j * DRPP) < g.M && dn_ok;
-            f32x4 v = dreg[j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-            bsum += v;
-            u32x2 h2, l2;
-            split4(v, h2, l2);
-            *reinterpret_cast<u32x2*>(Dh + (dr0 + j * DRPP) * DS + dslot * 4) = h2;
-            *reinterpret_cast<u32x2*>(Dl + (dr0 + j * DRPP) * DS + dslot * 4) = l2;
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    const int gq = lane >> 4;
-    const int q = (lane & 15) >> 2;
-    const int pq = lane & 3;
-    const int tr_row = 8 * (gq >> 1) + q;
-    const int tr_col = 16 * (gq & 1) + 4 * pq;
-
-    if (c_begin < c_end) {
-        lg0.set_rows(g, c_begin * BMC);
-        lg0.load_tap(g, gin, ky_u, kx_u, c_u, true);
-        load_d(c_begin * BMC, dreg0);
-    }
-    auto mma_chunk = [&]() {
-#pragma unroll
-        for (int ks = 0; ks < BMC / 16; ++ks) {
-            const int row = 16 * ks + tr_row;
-            bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                ah[a] = tr_frag(Gh + row * GS + 64 * wc + 32 * a + tr_col, GS);
-                al[a] = tr_frag(Gl + row * GS + 64 * wc + 32 * a + tr_col, GS);
-                bh[a] = tr_frag(Dh + row * DS + 64 * wn + 32 * a + tr_col, DS);
-                bl[a] = tr_frag(Dl + row * DS + 64 * wn + 32 * a + tr_col, DS);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                }
-        }
-    };
-    for (int ch = c_begin; ch < c_end; ++ch) {
-        lg0.store_split(g, Gh, Gl, GS);
-        store_d(ch * BMC, dreg0);
-        __syncthreads();
-        if (ch + 1 < c_end) {
-            lg0.advance_rows(g, (ch + 1) * BMC, p.step_b, p.step_p, p.step_q);
-            lg0.load_tap(g, gin, ky_u, kx_u, c_u, true);
-            load_d((ch + 1) * BMC, dreg0);
-        }
-        mma_chunk();
-        __syncthreads();
-    }
-
-    // flush straight from the C/D layout: col = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * h (k index)
-    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
-    const int wtap = (tap_u / g.KW) * g.kws + tap_u % g.KW;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + 64 * wn + 32 * b + i;
-        if (n >= g.N) continue;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = c_u + 64 * wc + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
-                atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[a][b][e]);
-            }
-    }
-    if (do_bias) {               // the 8 threads of a column quad (dr0 = 0 .. 7) meet in LDS, one atomic per column
-        float* red = reinterpret_cast<float*>(smem_big);                  // the tiles are dead (barrier at the end of the loop)
-        *reinterpret_cast<f32x4*>(red + (dr0 * DSLOTS + dslot) * 4) = bsum;
-        __syncthreads();
-        if (tid < NB && n0 + tid < g.N) {
-            float t = 0.f;
-#pragma unroll
-            for (int r = 0; r < DRPP; ++r) t += red[(r * DSLOTS + tid / 4) * 4 + (tid & 3)];
-            atomicAdd(p.db + wg_off(p, grp, 3, p.bias_gs) + n0 + tid, t);
-        }
-    }
-}
-
 // ----------------------- stride-1 weight gradients, patch-staged form (bf16x3) -----------------------
 // gather_wgrad_bf16_kernel gives every (tap x 32 channels) block its own workgroups: each of them re-gathers the
 // input rows and re-reads the dense operand (measured on the 28x28 5x5 layers: 212 MB of HBM-side traffic per
@@ -3940,6 +3748,170 @@ const char* mode_name(int mode) {
     }
 }
 
+// (placed behind every other kernel of this file: inserting it in the middle moved the hot PM-VAE kernels in the code object and
+// cost that step 2 % - the step is sensitive to where its concurrently running kernels sit in the instruction cache)
+// The 128 x 128-tile case for LARGE weight gradients (the PixelCNN's 256- / 512-channel masked convolutions over 12 544 rows,
+// grouped eight to sixteen layers to a launch: 2.9 ms of chip-filling launches at the end of a pm_vqvae_mnist step).  With
+// 64 x 64 tiles a workgroup moves 32 KB of operands from L2 per 64-row chunk for 64 x 64 x 64 MACs - every element of the
+// gathered operand is fetched N / 64 times and every element of the dense one K / 64 times (conv2 of a vertical block:
+// 8 and 48 times, 19 GB per launch through L2); a 128 x 128 tile halves both.  Four waves, each a 64 x 64 block (four 32 x 32
+// accumulators: one A / B fragment pair feeds 12 MFMAs instead of 3), 64-row chunks, 70 KB of LDS (two workgroups per CU).
+// Needs C % 128 == 0 (a 128-wide k-block inside one tap); flush with atomics like the 64 x 64 form.
+template <int DD, int BMC>
+__global__ __launch_bounds__(256, BMC == 32 ? 3 : 2) void gather_wgrad_bf16_big_kernel(WgradArgs p) {
+    constexpr int CB = 128, NB = 128;
+    constexpr int GS = CB + 8, DS = NB + 8;
+    extern __shared__ __attribute__((aligned(16))) short smem_big[];
+    short* Gh = smem_big;
+    short* Gl = Gh + BMC * GS;
+    short* Dh = Gl + BMC * GS;
+    short* Dl = Dh + BMC * DS;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1, wn = wave & 1;      // this wave's 64 x 64 block of the 128 x 128 tile
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int tile = blockIdx.x % p.ntiles;
+    const int split = blockIdx.x / p.ntiles;
+    const int nkb = g.K / CB;
+    const int kkb = tile % nkb;
+    const int nb = tile / nkb;
+    const int kk0 = kkb * CB;
+    const int n0 = nb * NB;
+    const int grp = blockIdx.z;
+    const float* gin = p.gathered + wg_off(p, grp, 0, p.in_gs);
+    const float* din = p.dense + wg_off(p, grp, 1, p.out_gs);
+    const bool do_bias = (p.db != nullptr) && (kkb == 0);          // workgroup-uniform: the first k-block of every column block
+    const int tap_u = kk0 / g.C;
+    const int c_u = kk0 - tap_u * g.C;
+    const int ky_u = tap_u / g.KW;
+    const int kx_u = tap_u - ky_u * g.KW;
+
+    const int total_chunks = (g.M + BMC - 1) / BMC;
+    const int c_begin = split * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    // one chunk of operands in flight per thread (two - a second loader and register set - was measured: 350 registers, one wave
+    // per SIMD, 22.5 k img/s against 25.8 k)
+    LoaderV4<BMC, CB, DD> lg0;
+    lg0.init(tid);
+    constexpr int DSLOTS = NB / 4;
+    constexpr int DRPP = 256 / DSLOTS;
+    constexpr int DNP = BMC / DRPP;
+    const int dslot = tid % DSLOTS;
+    const int dr0 = tid / DSLOTS;
+    const int dn = n0 + dslot * 4;
+    const bool dn_ok = dn < g.N;
+    f32x4 dreg0[DNP];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};              // bias gradient: this thread's 4 columns over the rows it stages
+    auto load_d = [&](int m0, f32x4 (&dreg)[DNP]) {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            const int m = m0 + dr0 + j * DRPP;
+            const bool ok = m < g.M && dn_ok;
+            dreg[j] = *reinterpret_cast<const f32x4*>(din + (ok ? (size_t)m * g.N + dn : 0));
+        }
+    };
+    auto store_d = [&](int m0, f32x4 (&dreg)[DNP]) {
+#pragma unroll
+        for (int j = 0; j < DNP; ++j) {
+            const bool ok = (m0 + dr0 + j * DRPP) < g.M && dn_ok;
+            f32x4 v = dreg[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            bsum += v;
+            u32x2 h2, l2;
+            split4(v, h2, l2);
+            *reinterpret_cast<u32x2*>(Dh + (dr0 + j * DRPP) * DS + dslot * 4) = h2;
+            *reinterpret_cast<u32x2*>(Dl + (dr0 + j * DRPP) * DS + dslot * 4) = l2;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int gq = lane >> 4;
+    const int q = (lane & 15) >> 2;
+    const int pq = lane & 3;
+    const int tr_row = 8 * (gq >> 1) + q;
+    const int tr_col = 16 * (gq & 1) + 4 * pq;
+
+    if (c_begin < c_end) {
+        lg0.set_rows(g, c_begin * BMC);
+        lg0.load_tap(g, gin, ky_u, kx_u, c_u, true);
+        load_d(c_begin * BMC, dreg0);
+    }
+    auto mma_chunk = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < BMC / 16; ++ks) {
+            const int row = 16 * ks + tr_row;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = tr_frag(Gh + row * GS + 64 * wc + 32 * a + tr_col, GS);
+                al[a] = tr_frag(Gl + row * GS + 64 * wc + 32 * a + tr_col, GS);
+                bh[a] = tr_frag(Dh + row * DS + 64 * wn + 32 * a + tr_col, DS);
+                bl[a] = tr_frag(Dl + row * DS + 64 * wn + 32 * a + tr_col, DS);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        lg0.store_split(g, Gh, Gl, GS);
+        store_d(ch * BMC, dreg0);
+        __syncthreads();
+        if (ch + 1 < c_end) {
+            lg0.advance_rows(g, (ch + 1) * BMC, p.step_b, p.step_p, p.step_q);
+            lg0.load_tap(g, gin, ky_u, kx_u, c_u, true);
+            load_d((ch + 1) * BMC, dreg0);
+        }
+        mma_chunk();
+        __syncthreads();
+    }
+
+    // flush straight from the C/D layout: col = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * h (k index)
+    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
+    const int wtap = (tap_u / g.KW) * g.kws + tap_u % g.KW;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + 64 * wn + 32 * b + i;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = c_u + 64 * wc + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[a][b][e]);
+            }
+    }
+    if (do_bias) {               // the 8 threads of a column quad (dr0 = 0 .. 7) meet in LDS, one atomic per column
+        float* red = reinterpret_cast<float*>(smem_big);                  // the tiles are dead (barrier at the end of the loop)
+        *reinterpret_cast<f32x4*>(red + (dr0 * DSLOTS + dslot) * 4) = bsum;
+        __syncthreads();
+        if (tid < NB && n0 + tid < g.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < DRPP; ++r) t += red[(r * DSLOTS + tid / 4) * 4 + (tid & 3)];
+            atomicAdd(p.db + wg_off(p, grp, 3, p.bias_gs) + n0 + tid, t);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w,
@@ -4063,9 +4035,12 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
         if (rn == 2 && wgs64 < rn2_min) rn = 1;
     }
     const __bf16* ws = reinterpret_cast<const __bf16*>(wsplit);
+#ifndef PM_IMAGE_INSUM
+    if (in_colsum) return PM_EINVAL;                   // compiled out of the default build (see pm_image_conv_insum_applies)
+#endif
     if (in_colsum) {
         ImagePlan ipc;
-        if (plan_skinny(a.g, G) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, G, ipc, false) || !image_insum_ok(a.g, ipc))
+        if (plan_skinny(a.g, G) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, G, ipc) || !image_insum_ok(a.g, ipc))
             return PM_EINVAL;
     }
     if (plan_skinny(a.g, G)) {                         // one output position, few rows, long K: one launch, K over the waves
@@ -4077,7 +4052,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     }
     ImagePlan ip;
     static const bool image_off = getenv("PM_NO_IMAGE_CONV") != nullptr;   // A/B switch for measurements
-    if (!image_off && plan_image(a.g, G, ip, in_colsum == nullptr)) {       // whole input image of a workgroup resident in LDS
+    if (!image_off && plan_image(a.g, G, ip)) {       // whole input image of a workgroup resident in LDS
         a.ksplit = 1;
         if (ip.nw == 8 && ip.t == 4) launch_image<8, 4>(ip, s, a, ws, npad, plane);
         else if (ip.nw == 8 && ip.t == 2) launch_image<8, 2>(ip, s, a, ws, npad, plane);
@@ -4175,11 +4150,20 @@ extern "C" int pm_gather_gemm_bf16_insum(pm_stream_t stream, const pm_gather_des
 }
 
 extern "C" int pm_image_conv_insum_applies(const pm_gather_desc* d) {
+#ifndef PM_IMAGE_INSUM
+    // The column-sum code inside image_conv_bf16_kernel is compiled out of the default build.  Present but UNUSED it split the
+    // PM-VAE step into two regimes picked at random per process (8 runs of 300 steps on one box: 1.307 - 1.337 ms without the code,
+    // 3 x ~1.30 and 5 x ~1.36 ms with it) - a few more registers / instructions in the staging phase of the step's most frequent
+    // kernel are enough to move how the two streams' launches interleave.  -DPM_IMAGE_INSUM (tools/build_variant.sh) restores it.
+    (void)d;
+    return 0;
+#else
     GemmArgs a;
     ImagePlan ip;
     if (!d || !fill_geom(d, a.g, true) || d->C % 8 != 0 || d->d != 1) return 0;
-    if (plan_skinny(a.g, d->groups) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, d->groups, ip, false)) return 0;
+    if (plan_skinny(a.g, d->groups) || getenv("PM_NO_IMAGE_CONV") || !plan_image(a.g, d->groups, ip)) return 0;
     return image_insum_ok(a.g, ip) ? 1 : 0;
+#endif
 }
 
 extern "C" int pm_gather_gemm_bf16_dual(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
@@ -4202,6 +4186,8 @@ extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* o
                            reinterpret_cast<__bf16*>(out_bf16), reinterpret_cast<const SplitJob*>(jobs_dev), njobs, total_blocks);
     return pm_check_launch("pm_split_weights");
 }
+
+static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_desc* d, bool cpad);
 
 static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
                                   float* dw, float* db, const long long* gtab, bool tab_aligned) {
@@ -4301,43 +4287,9 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
         }
     }
     a.cpad = cpad ? 1 : 0;
-    {   // large problems with 128-channel-aligned taps: 128 x 128 tiles (PM_WG_NOBIG=1: the 64 x 64 form, for A/B runs)
-        const Geom& g = a.g;
-        const long long work = (long long)g.M * g.K * g.N * d->groups;
-        if (!getenv("PM_WG_NOBIG") && !cpad && g.C % 128 == 0 && g.K >= 512 && g.N >= 128 && g.M >= 2048 && work >= (1LL << 30)) {
-            const int nkb = g.K / 128, nnb = (g.N + 127) / 128;
-            static const int bmc = getenv("PM_WG_BIG_BMC") ? atoi(getenv("PM_WG_BIG_BMC")) : 32;   // rows per chunk (A/B knob)
-            const int total_chunks = (g.M + bmc - 1) / bmc;
-            long long tiles = (long long)nkb * nnb * d->groups;
-            static const int target = getenv("PM_WG_BIG_TARGET") ? atoi(getenv("PM_WG_BIG_TARGET")) : 1536;   // workgroups wanted (A/B knob)
-            int splits = (int)((target + tiles - 1) / tiles);
-            if (splits > total_chunks / 16) splits = total_chunks / 16;
-            if (splits < 1) splits = 1;
-            a.chunks_per_split = (total_chunks + splits - 1) / splits;
-            splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-            const int hw = g.OH * g.OW;
-            a.step_b = bmc / hw;
-            a.step_p = (bmc - a.step_b * hw) / g.OW;
-            a.step_q = bmc - a.step_b * hw - a.step_p * g.OW;
-            a.ntiles = nkb * nnb;
-            a.nsplits = splits;
-            a.xcd_map = 0;
-            const size_t lds = (size_t)2 * bmc * (136 + 136) * sizeof(short);
-            static bool attr_big = false;
-            if (!attr_big) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_wgrad_bf16_big_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_wgrad_bf16_big_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                attr_big = true;
-            }
-            dim3 gridb(a.ntiles * splits, 1, d->groups);
-            PM_KTAG("gather_wgrad_bf16_big_kernel<%d, %d>", d->d, bmc);
-            hipStream_t sb = (hipStream_t)stream;
-            if (d->d == 1 && bmc == 64) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<1, 64>), gridb, dim3(256), lds, sb, a);
-            else if (d->d == 1) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<1, 32>), gridb, dim3(256), lds, sb, a);
-            else if (bmc == 64) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<2, 64>), gridb, dim3(256), lds, sb, a);
-            else hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<2, 32>), gridb, dim3(256), lds, sb, a);
-            return pm_check_launch("pm_gather_wgrad_bf16(big)");
-        }
+    {
+        const int rc_big = launch_big_wgrad(stream, a, d, cpad);
+        if (rc_big != 1) return rc_big;
     }
     Geom gplan = a.g;
     if (cpad) {                 // planned as the 64-channel problem it is executed as
@@ -4396,4 +4348,47 @@ extern "C" int pm_gather_wgrad_table(pm_stream_t stream, const pm_gather_desc* d
     if (!table || d->groups < 1) return PM_EINVAL;
     if (use_bf16) return gather_wgrad_bf16_impl(stream, d, gathered, dense, dw, db, table, all_aligned16 != 0);
     return gather_wgrad_impl(stream, d, gathered, dense, dw, db, table, all_aligned16 != 0);
+}
+
+// Large weight gradients with 128-channel-aligned taps: 128 x 128 tiles (PM_WG_NOBIG=1: the 64 x 64 form, for A/B runs).  Returns
+// 1 when it did not apply (the caller goes on), else the launch status.  Defined at the END of this file so that the kernel's
+// instantiations are emitted behind every other kernel of the code object (see gather_wgrad_bf16_big_kernel).
+static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_desc* d, bool cpad) {
+        const Geom& g = a.g;
+        const long long work = (long long)g.M * g.K * g.N * d->groups;
+        if (!getenv("PM_WG_NOBIG") && !cpad && g.C % 128 == 0 && g.K >= 512 && g.N >= 128 && g.M >= 2048 && work >= (1LL << 30)) {
+            const int nkb = g.K / 128, nnb = (g.N + 127) / 128;
+            static const int bmc = getenv("PM_WG_BIG_BMC") ? atoi(getenv("PM_WG_BIG_BMC")) : 32;   // rows per chunk (A/B knob)
+            const int total_chunks = (g.M + bmc - 1) / bmc;
+            long long tiles = (long long)nkb * nnb * d->groups;
+            static const int target = getenv("PM_WG_BIG_TARGET") ? atoi(getenv("PM_WG_BIG_TARGET")) : 1536;   // workgroups wanted (A/B knob)
+            int splits = (int)((target + tiles - 1) / tiles);
+            if (splits > total_chunks / 16) splits = total_chunks / 16;
+            if (splits < 1) splits = 1;
+            a.chunks_per_split = (total_chunks + splits - 1) / splits;
+            splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+            const int hw = g.OH * g.OW;
+            a.step_b = bmc / hw;
+            a.step_p = (bmc - a.step_b * hw) / g.OW;
+            a.step_q = bmc - a.step_b * hw - a.step_p * g.OW;
+            a.ntiles = nkb * nnb;
+            a.nsplits = splits;
+            a.xcd_map = 0;
+            const size_t lds = (size_t)2 * bmc * (136 + 136) * sizeof(short);
+            static bool attr_big = false;
+            if (!attr_big) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_wgrad_bf16_big_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_wgrad_bf16_big_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                attr_big = true;
+            }
+            dim3 gridb(a.ntiles * splits, 1, d->groups);
+            PM_KTAG("gather_wgrad_bf16_big_kernel<%d, %d>", d->d, bmc);
+            hipStream_t sb = (hipStream_t)stream;
+            if (d->d == 1 && bmc == 64) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<1, 64>), gridb, dim3(256), lds, sb, a);
+            else if (d->d == 1) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<1, 32>), gridb, dim3(256), lds, sb, a);
+            else if (bmc == 64) hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<2, 64>), gridb, dim3(256), lds, sb, a);
+            else hipLaunchKernelGGL((gather_wgrad_bf16_big_kernel<2, 32>), gridb, dim3(256), lds, sb, a);
+            return pm_check_launch("pm_gather_wgrad_bf16(big)");
+        }
+    return 1;
 }

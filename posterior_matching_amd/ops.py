@@ -561,7 +561,8 @@ def dgrad_insum_ok(g: LayerGeom, B: int, wsplit, force: bool = False) -> bool:
     transposed convolution) - its dy images are staged in LDS by the image-resident kernel anyway.  Measured on the PM-VAE step
     (same box, 300 steps each): 189.8 / 191.6 k img/s with it against 193.8 / 192.7 k with the separate pm_colsum launches - the
     column sums ride on the weight-gradient stream, the data gradient is the critical chain, and five launches fewer do not pay
-    for the atomics and the longer staging loop there.  So the models only use it when PM_DGRAD_INSUM=1 (`force`: tests)."""
+    for the atomics and the longer staging loop there.  So the models only use it when PM_DGRAD_INSUM=1 (`force`: tests) - and
+    the default libpmhip.so is built WITHOUT the code (pm_image_conv_insum_applies returns 0; see csrc/pm_conv.hip)."""
     if wsplit is None or not (force or os.environ.get("PM_DGRAD_INSUM")):
         return False
     d = g._desc(B, "dgrad")
