@@ -243,6 +243,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the engine's training loop (Trainer.fit) pauses the cyclic garbage collector in its steady state: the same here, from the
+    # warm-up on (utils.steady_state_gc; PM_NO_GC_FREEZE=1 for A/B runs)
+    from posterior_matching_amd.utils import steady_state_gc
+
+    gc_guard = steady_state_gc()
+    gc_guard.__enter__()
     run(ts, args.warmup)
     fence()
     marks = []
@@ -276,6 +282,7 @@ def main():
         spread["extra_steps"] = {"n": len(ps), "min": q(0.0), "q1": q(0.25), "median": q(0.5), "q3": q(0.75), "max": round(ps[-1], 4),
                                  "mean": round(sum(ps) / len(ps), 4)}
 
+    gc_guard.__exit__(None, None, None)
     # strict arithmetic (every GEMM on the f32 MFMA) on the same batches: a few steps OUTSIDE the timed region
     f32_ips = None
     if rank == 0 and world == 1 and not args.f32 and not args.no_f32_aux:

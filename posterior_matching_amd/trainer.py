@@ -369,8 +369,16 @@ class Trainer:
                                 rank=self.rank, use_graph=self.use_graph)
         callbacks = callbacks or []
         batch = first
+        from .utils import steady_state_gc
+
+        with steady_state_gc() as gcs:
+            self._fit_loop(ts, steps, batch, it, key, dev, is_vq or is_vade, val_dataset, validation_freq, callbacks, log_fn, gcs)
+        ts.synchronize()
+        return self._state(ts)
+
+    def _fit_loop(self, ts, steps, batch, it, key, dev, unmasked, val_dataset, validation_freq, callbacks, log_fn, gcs) -> None:
         for step in range(steps):
-            if is_vq or is_vade:
+            if unmasked:
                 ts.set_batch(batch[key].to(dev, non_blocking=True))
             else:
                 ts.set_batch(batch[key].to(dev, non_blocking=True), batch["mask"].to(dev, non_blocking=True))
@@ -390,9 +398,8 @@ class Trainer:
                     if log_fn:
                         log_fn(f"step {step + 1}: " + ", ".join(f"{k}={v:.5g}" for k, v in logs.items()
                                                                  if getattr(v, "ndim", 0) == 0))
+                gcs.collect()                       # the safe point for a cyclic collection
             batch = next(it)
-        ts.synchronize()
-        return self._state(ts)
 
     def _validate(self, ts, val_dataset, key: str, dev, callbacks=()) -> Dict[str, float]:
         """loss_fn with is_training=False averaged over the validation batches (bax semantics); every callback sees each

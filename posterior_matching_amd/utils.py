@@ -69,3 +69,36 @@ class JSONLCallback(Callback):
 
 
 TensorBoardCallback = JSONLCallback
+
+
+class steady_state_gc:
+    """Context manager for the steady-state part of a training loop: the cyclic garbage collector is paused (after one full
+    collection; everything alive then is moved out of its reach with gc.freeze) - a generation-2 pass in the middle of a step
+    stalls the host long enough for the launch queue to drain (a 1.33 ms PM-VAE step shows up as 1.5 - 1.7 ms once in a few
+    dozen steps).  Reference counting still frees everything acyclic; `collect()` runs a collection at a safe point
+    (Trainer.fit: at validation time).  PM_NO_GC_FREEZE=1: leave the collector alone (A/B)."""
+
+    def __enter__(self):
+        import gc
+        import os
+
+        self._on = not os.environ.get("PM_NO_GC_FREEZE") and gc.isenabled()
+        if self._on:
+            gc.collect()
+            gc.freeze()
+            gc.disable()
+        return self
+
+    def collect(self) -> None:
+        if self._on:
+            import gc
+
+            gc.collect()
+
+    def __exit__(self, *exc):
+        if self._on:
+            import gc
+
+            gc.enable()
+            gc.unfreeze()
+        return False
