@@ -31,6 +31,9 @@ class _PlannedStep:
     _warm = False
 
     def _planned(self, sequence) -> None:
+        if ops._timer is not None:      # per-kernel timing (ops.KernelTimer): always the eager path, also when a plan exists
+            sequence()
+            return
         if self._plan is not None:
             store = self._grad_store()
             if store is None or store.g_clean or not self.adam_cfg.zero_grad:
