@@ -16,8 +16,7 @@ def get_config():
     config.data.mask_generator_kwargs = ConfigDict()
     config.data.mask_generator_kwargs.bounds = (0.0, 0.20)
 
-    # Replace this with a path to your own VAE model directory.
-    # This should be a directory that was created by the `train_pm_vae.py` script.
+    # run directory of `train_pm_vae.py` holding the trained VAE (model_config.json + train_state.pkl)
     config.pm_vae_dir = "runs/pm-vae-mnist16-20220302-160842"
 
     config.model = ConfigDict()

@@ -13,8 +13,7 @@ def get_config():
     config.data.train_batch_size = 128
     config.data.val_batch_size = 128
 
-    # Replace this with a path to your own VADE model directory.
-    # This should be a directory that was created by the `train_vade.py` script.
+    # run directory of `train_vade.py` holding the trained VADE (model_config.json + train_state.pkl)
     config.vade_dir = "runs/vade-mnist-20220305-121540"
 
     config.model = ConfigDict()

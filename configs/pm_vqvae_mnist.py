@@ -14,8 +14,7 @@ def get_config():
     config.data.val_batch_size = 32
     config.data.mask_generator = "MNISTMaskGenerator"
 
-    # Replace this with a path to your own VQVAE model directory.
-    # This should be a directory that was created by the `train_vqvae.py` script.
+    # run directory of `train_vqvae.py` holding the trained VQVAE (model_config.json + train_state.pkl)
     config.vqvae_dir = "runs/vqvae-mnist-20220227-111235"
 
     config.pixel_cnn = ConfigDict()

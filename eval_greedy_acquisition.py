@@ -40,11 +40,11 @@ def load_data(dataset, num_instances, path=None, seed=91):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--run_dir", required=True, help="The run directory of the model to evaluate.")
-    ap.add_argument("--dataset", required=True, help="The dataset to evaluate on.")
-    ap.add_argument("--num_instances", type=int, default=1000, help="The number of instances to evaluate.")
-    ap.add_argument("--num_samples", type=int, default=50, help="The number of samples to use for expectations.")
-    ap.add_argument("--episode_length", type=int, default=31, help="The length of episodes to collect.")
+    ap.add_argument("--run_dir", required=True, help="run directory written by train_lookahead_posterior.py")
+    ap.add_argument("--dataset", required=True, help="dataset name (mnist16 for the reference configuration)")
+    ap.add_argument("--num_instances", type=int, default=1000, help="how many test instances to run episodes for")
+    ap.add_argument("--num_samples", type=int, default=50, help="samples per expectation (sampling-based gains, imputations)")
+    ap.add_argument("--episode_length", type=int, default=31, help="acquisitions per episode")
     ap.add_argument("--data", default=None, help="optional .npy with the evaluation examples")
     args = ap.parse_args()
 
