@@ -1,45 +1,31 @@
-"""VaDE on MNIST: the configuration of the reference's configs/vade_mnist.py (values are data), expressed with this repo's
-ConfigDict."""
+"""VaDE on MNIST (GMM-prior VAE): the values of the reference's configs/vade_mnist.py as one nested literal."""
 from posterior_matching_amd.config_dict import ConfigDict
 
 
 def get_config():
-    config = ConfigDict()
-
-    config.data = ConfigDict()
-    config.data.dataset = "mnist"
-    config.data.train_split = "train"
-    config.data.validation_split = "test"
-    config.data.train_batch_size = 128
-    config.data.val_batch_size = 128
-
-    config.model = ConfigDict()
-    config.model.encoder_net = "ConvEncoder"
-    config.model.decoder_net = "ConvDecoder"
-    config.model.decoder_dist = "Bernoulli"
-    config.model.latent_dim = 10
-    config.model.num_components = 10
-
-    config.model.encoder_net_config = ConfigDict()
-    config.model.encoder_net_config.conv_layers = [(32, 5, 1), (32, 5, 2), (64, 5, 1), (64, 5, 2), (128, 7, 1)]
-
-    config.model.decoder_net_config = ConfigDict()
-    config.model.decoder_net_config.conv_layers = [(64, 7, 1), (64, 5, 2), (32, 5, 1), (32, 5, 2), (32, 5, 1), (1, 5, 1)]
-
-    config.pretrain_steps = int(60000 / config.data.train_batch_size * 150)
-    config.steps = int(60000 / config.data.train_batch_size * 300)
-    config.validation_freq = 1000
-    config.cluster_pred_num_samples = 50
-
-    config.pretrain_lr = 0.002
-
-    config.lr_schedule = ConfigDict()
-    config.lr_schedule.init_value = 0.002
-    config.lr_schedule.decay_rate = 0.9
-    config.lr_schedule.staircase = False
-    config.lr_schedule.transition_steps = int(60000 / config.data.train_batch_size * 10)
-
-    config.adam = ConfigDict()
-    config.adam.eps = 1e-4
-
-    return config
+    return ConfigDict(
+    {'data': {'dataset': 'mnist',
+              'train_split': 'train',
+              'validation_split': 'test',
+              'train_batch_size': 128,
+              'val_batch_size': 128},
+     'model': {'encoder_net': 'ConvEncoder',
+               'decoder_net': 'ConvDecoder',
+               'decoder_dist': 'Bernoulli',
+               'latent_dim': 10,
+               'num_components': 10,
+               'encoder_net_config': {'conv_layers': [(32, 5, 1), (32, 5, 2), (64, 5, 1), (64, 5, 2), (128, 7, 1)]},
+               'decoder_net_config': {'conv_layers': [(64, 7, 1),
+                                                      (64, 5, 2),
+                                                      (32, 5, 1),
+                                                      (32, 5, 2),
+                                                      (32, 5, 1),
+                                                      (1, 5, 1)]}},
+     'pretrain_steps': 70312,
+     'steps': 140625,
+     'validation_freq': 1000,
+     'cluster_pred_num_samples': 50,
+     'pretrain_lr': 0.002,
+     'lr_schedule': {'init_value': 0.002, 'decay_rate': 0.9, 'staircase': False, 'transition_steps': 4687},
+     'adam': {'eps': 0.0001}}
+    )
