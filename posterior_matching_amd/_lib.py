@@ -91,6 +91,25 @@ class SplitJob(C.Structure):
     ]
 
 
+class WgradPart(C.Structure):
+    """struct pm_wgrad_part (include/pmhip.h): arenas of a weight-gradient launch in partial-sum mode."""
+
+    _fields_ = [
+        ("w", C.c_void_p), ("b", C.c_void_p), ("bg", C.c_void_p),
+        ("w_stride", C.c_longlong), ("b_stride", C.c_longlong), ("bg_stride", C.c_longlong),
+        ("nslots", C.c_int),
+    ]
+
+
+class ReduceJob(C.Structure):
+    """struct pm_reduce_job (include/pmhip.h)."""
+
+    _fields_ = [
+        ("src", C.c_void_p), ("stride", C.c_longlong), ("g_off", C.c_longlong),
+        ("count", C.c_int), ("nslots", C.c_int),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _LL = C.c_longlong
@@ -107,6 +126,13 @@ SIGNATURES = {
     "pm_split_weights": [_P, _P, _P, _P, _I, _I],
     "pm_gather_wgrad_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
     "pm_gather_wgrad_table": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _I, _I],
+    "pm_wgrad_part_slots": [C.POINTER(GatherDesc), _P, _P, _I, _I, _I, C.POINTER(_I)],
+    "pm_gather_wgrad_part": [_P, C.POINTER(GatherDesc), _P, _P, _P, _I, _I, C.POINTER(WgradPart)],
+    "pm_thin_wgrad_part_slots": [C.POINTER(GatherDesc), _P, _P, C.POINTER(_I)],
+    "pm_thin_wgrad_part": [_P, C.POINTER(GatherDesc), _P, _P, C.POINTER(WgradPart)],
+    "pm_colsum_part_slots": [_LL, _I, C.POINTER(_I)],
+    "pm_colsum_part": [_P, _P, _LL, _I, _P, _LL, _I],
+    "pm_reduce_partials": [_P, _P, _I, _P],
     "pm_thin_conv": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
     "pm_thin_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P],
     "pm_thin_to1_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],

@@ -66,11 +66,29 @@ struct WgradArgs {
     // optional per-group element offsets (gathered, dense, dw, db) relative to the four base pointers, in DEVICE memory:
     // groups whose operands are separately allocated buffers (the weight gradients of many same-shaped layers in one launch)
     const long long* gtab;
+    // partial-sum destination (pm_wgrad_part): part_w != NULL -> a workgroup STORES its sums into slot s of the arena
+    // (part_w + s * part_ws + the offsets it would add to dw) instead of adding them to dw with f32 atomics; every element of
+    // a slot has exactly one writer per launch, pm_reduce_partials sums the slots in a fixed order.
+    float* part_w;
+    float* part_b;
+    long long part_ws, part_bs;
 };
 
 // element offset of group `grp`'s operand `which` (0 gathered, 1 dense, 2 dw, 3 db)
 __device__ __forceinline__ long long wg_off(const WgradArgs& p, int grp, int which, long long stride) {
     return p.gtab ? p.gtab[4 * grp + which] : (long long)grp * stride;
+}
+
+// where a workgroup of m-split / persistent slot `slot` sends its weight (bias) sums, and how
+__device__ __forceinline__ float* wg_dw(const WgradArgs& p, int slot) {
+    return p.part_w ? p.part_w + (size_t)slot * p.part_ws : p.dw;
+}
+__device__ __forceinline__ float* wg_db(const WgradArgs& p, int slot) {
+    return p.part_w ? p.part_b + (size_t)slot * p.part_bs : p.db;
+}
+__device__ __forceinline__ void wg_put(bool part, float* addr, float v) {
+    if (part) *addr = v;
+    else atomicAdd(addr, v);
 }
 
 constexpr int BK = 32;
@@ -2798,7 +2816,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
                 red[wave * CB * NB + cl * NB + nl] = acc[a][b][e];
             }
     __syncthreads();
-    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
+    const bool part = p.part_w != nullptr;
+    float* dw = wg_dw(p, (int)blockIdx.y) + wg_off(p, grp, 2, p.w_gs);
     for (int e = tid; e < CB * NB; e += 256) {
         int cl = e / NB;
         int nl = e - cl * NB;
@@ -2809,16 +2828,26 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(WgradArgs p) {
             int tap = kk / g.C;
             int c = kk - tap * g.C;
             const int wtap = (tap / g.KW) * g.kws + tap % g.KW;   // compact tap -> tap of the weight layout
-            atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
+            wg_put(part, dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
         }
     }
-    if (do_bias && h == 0) {
+    if (do_bias && !part && h == 0) {
         float* db = p.db + wg_off(p, grp, 3, p.bias_gs);
 #pragma unroll
         for (int b = 0; b < RN; ++b) {
             int n = n0 + b * 32 + i;
             if (n < g.N) atomicAdd(db + n, accb[b][0]);
         }
+    }
+    if (do_bias && part) {       // one writer per slot element: the four waves' row shares meet in LDS (workgroup-uniform branch)
+        __syncthreads();
+        if (h == 0) {
+#pragma unroll
+            for (int b = 0; b < RN; ++b) red[wave * NB + b * 32 + i] = accb[b][0];
+        }
+        __syncthreads();
+        float* db = wg_db(p, (int)blockIdx.y) + wg_off(p, grp, 3, p.bias_gs);
+        if (tid < NB && n0 + tid < g.N) db[n0 + tid] = (red[tid] + red[NB + tid]) + (red[2 * NB + tid] + red[3 * NB + tid]);
     }
 }
 
@@ -3028,7 +3057,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
                 red[wave * CB * NB + cl * NB + nl] = acc[a][b][e];
             }
     __syncthreads();
-    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
+    const bool part = p.part_w != nullptr;
+    float* dw = wg_dw(p, split) + wg_off(p, grp, 2, p.w_gs);
     for (int e = tid; e < CB * NB; e += 256) {
         int cl = e / NB;
         int nl = e - cl * NB;
@@ -3039,16 +3069,26 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_kernel(WgradArgs p) {
             int tap = kk / g.C;
             int c = kk - tap * g.C;
             const int wtap = (tap / g.KW) * g.kws + tap % g.KW;   // compact tap -> tap of the weight layout
-            atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
+            wg_put(part, dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, s);
         }
     }
-    if (do_bias && h == 0) {
+    if (do_bias && !part && h == 0) {
         float* db = p.db + wg_off(p, grp, 3, p.bias_gs);
 #pragma unroll
         for (int b = 0; b < RN; ++b) {
             int n = n0 + b * 32 + i;
             if (n < g.N) atomicAdd(db + n, accb[b][0]);
         }
+    }
+    if (do_bias && part) {       // one writer per slot element: the four waves' row shares meet in LDS (workgroup-uniform branch)
+        __syncthreads();
+        if (h == 0) {
+#pragma unroll
+            for (int b = 0; b < RN; ++b) red[wave * NB + b * 32 + i] = accb[b][0];
+        }
+        __syncthreads();
+        float* db = wg_db(p, split) + wg_off(p, grp, 3, p.bias_gs);
+        if (tid < NB && n0 + tid < g.N) db[n0 + tid] = (red[tid] + red[NB + tid]) + (red[2 * NB + tid] + red[3 * NB + tid]);
     }
 }
 
@@ -3181,7 +3221,8 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     }
 
     // flush straight from the C/D layout: col = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * h (k index)
-    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
+    const bool part = p.part_w != nullptr;
+    float* dw = wg_dw(p, split) + wg_off(p, grp, 2, p.w_gs);
     const int n = n0 + 32 * wn + i;
     if (n < g.N) {
 #pragma unroll
@@ -3192,9 +3233,9 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
             const int tap = cpad ? kkb : kk / g.C;
             const int c = cpad ? cl : kk - tap * g.C;
             const int wtap = (tap / g.KW) * g.kws + tap % g.KW;
-            atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[e]);
+            wg_put(part, dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[e]);
         }
-        if (do_bias && h == 0) atomicAdd(p.db + wg_off(p, grp, 3, p.bias_gs) + n, accb[0]);
+        if (do_bias && h == 0) wg_put(part, wg_db(p, split) + wg_off(p, grp, 3, p.bias_gs) + n, accb[0]);
     }
 }
 
@@ -3365,6 +3406,9 @@ __global__ __launch_bounds__(256) void patch_wgrad_bf16_kernel(WgradArgs p, int 
     }
 
     // flush: C/D layout row (= channel) = (e&3) + 8*(e>>2) + 4*h, column (= n) = lane & 31
+    // (partial-sum mode: slot = this workgroup; its four waves own disjoint taps, so every slot element has one writer)
+    const bool part = p.part_w != nullptr;
+    float* dwp = wg_dw(p, blockIdx.x);
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int tap = wave + 4 * j;
@@ -3377,7 +3421,7 @@ __global__ __launch_bounds__(256) void patch_wgrad_bf16_kernel(WgradArgs p, int 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
-                atomicAdd(p.dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[j][b][e]);
+                wg_put(part, dwp + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[j][b][e]);
             }
         }
     }
@@ -3385,7 +3429,7 @@ __global__ __launch_bounds__(256) void patch_wgrad_bf16_kernel(WgradArgs p, int 
 #pragma unroll
         for (int b = 0; b < RN; ++b) {
             const int n = 32 * b + i;
-            if (n < g.N) atomicAdd(p.db + n, accb[b][0]);
+            if (n < g.N) wg_put(part, wg_db(p, blockIdx.x) + n, accb[b][0]);
         }
     }
 }
@@ -3569,6 +3613,9 @@ __global__ __launch_bounds__(256) void image_wgrad_bf16_kernel(WgradArgs p, int 
     }
 
     // flush: C/D layout row (= channel) = (e&3) + 8*(e>>2) + 4*h, column (= n) = lane & 31
+    // (partial-sum mode: slot = b_first, shared by the nsub workgroups whose tap classes tile the kernel)
+    const bool part = p.part_w != nullptr;
+    float* dwp = wg_dw(p, b_first);
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int tap = sub + nsub * (wave + 4 * j);
@@ -3581,7 +3628,7 @@ __global__ __launch_bounds__(256) void image_wgrad_bf16_kernel(WgradArgs p, int 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
-                atomicAdd(p.dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[j][b2][e]);
+                wg_put(part, dwp + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[j][b2][e]);
             }
         }
     }
@@ -3589,7 +3636,7 @@ __global__ __launch_bounds__(256) void image_wgrad_bf16_kernel(WgradArgs p, int 
 #pragma unroll
         for (int b2 = 0; b2 < RN; ++b2) {
             const int n = 32 * b2 + i;
-            if (n < g.N) atomicAdd(p.db + n, accb[b2][0]);
+            if (n < g.N) wg_put(part, wg_db(p, b_first) + n, accb[b2][0]);
         }
     }
 }
@@ -3885,7 +3932,8 @@ __global__ __launch_bounds__(256, BMC == 32 ? 3 : 2) void gather_wgrad_bf16_big_
     }
 
     // flush straight from the C/D layout: col = lane & 31 (n), row = (e & 3) + 8 * (e >> 2) + 4 * h (k index)
-    float* dw = p.dw + wg_off(p, grp, 2, p.w_gs);
+    const bool part = p.part_w != nullptr;
+    float* dw = wg_dw(p, split) + wg_off(p, grp, 2, p.w_gs);
     const int wtap = (tap_u / g.KW) * g.kws + tap_u % g.KW;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -3896,7 +3944,7 @@ __global__ __launch_bounds__(256, BMC == 32 ? 3 : 2) void gather_wgrad_bf16_big_
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = c_u + 64 * wc + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
-                atomicAdd(dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[a][b][e]);
+                wg_put(part, dw + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[a][b][e]);
             }
     }
     if (do_bias) {               // the 8 threads of a column quad (dr0 = 0 .. 7) meet in LDS, one atomic per column
@@ -3907,7 +3955,7 @@ __global__ __launch_bounds__(256, BMC == 32 ? 3 : 2) void gather_wgrad_bf16_big_
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < DRPP; ++r) t += red[(r * DSLOTS + tid / 4) * 4 + (tid & 3)];
-            atomicAdd(p.db + wg_off(p, grp, 3, p.bias_gs) + n0 + tid, t);
+            wg_put(part, wg_db(p, split) + wg_off(p, grp, 3, p.bias_gs) + n0 + tid, t);
         }
     }
 }
@@ -3951,15 +3999,41 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
     return pm_check_launch("pm_gather_gemm");
 }
 
+// Partial-sum mode of the weight-gradient entry points.  `part` != NULL: dw / db are ignored, the launch STORES into the arenas
+// of `part` (which must hold exactly the number of slots the launch plan writes: pm_wgrad_part_slots).  `slots_out` != NULL: nothing
+// is launched, the slot count of the plan is returned (one planning code path for the query and the launch).
+static bool set_part(WgradArgs& a, const pm_wgrad_part* part, bool want_bias) {
+    a.part_w = a.part_b = nullptr;
+    a.part_ws = a.part_bs = 0;
+    if (!part) return true;
+    if (!part->w || part->nslots < 1 || part->w_stride < 0 || (want_bias && (!part->b || part->b_stride < 0))) return false;
+    a.part_w = part->w; a.part_ws = part->w_stride;
+    a.part_b = part->b; a.part_bs = part->b_stride;
+    a.dw = part->w;                               // non-NULL for the argument checks; never written in this mode
+    return true;
+}
+#define PM_PART_SLOTS(n)                                              \
+    do {                                                              \
+        if (slots_out) { *slots_out = (n); return PM_OK; }            \
+        if (part && part->nslots != (n)) {                            \
+            snprintf(pm_err_text, sizeof(pm_err_text), "pm_wgrad_part: the launch writes %d slots, the arena holds %d", (int)(n), part->nslots); \
+            return PM_EINVAL;                                         \
+        }                                                             \
+    } while (0)
+
 static int gather_wgrad_impl(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
-                             float* dw, float* db, const long long* gtab, bool tab_aligned) {
+                             float* dw, float* db, const long long* gtab, bool tab_aligned,
+                             const pm_wgrad_part* part = nullptr, int* slots_out = nullptr) {
     WgradArgs a;
-    if (!fill_geom(d, a.g, false) || !gathered || !dense || !dw) return PM_EINVAL;
+    if (part) { dw = part->w; db = part->b; }
+    if (!fill_geom(d, a.g, false) || !gathered || !dense || (!dw && !slots_out)) return PM_EINVAL;
     a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db; a.gtab = gtab;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    if (!set_part(a, part, db != nullptr)) return PM_EINVAL;
     const bool vec4 = (d->C % 4 == 0) && aligned16(gathered) && (gtab ? tab_aligned : d->in_gs % 4 == 0);
     const bool dvec4 = (d->N % 4 == 0) && aligned16(dense) && (gtab ? tab_aligned : d->out_gs % 4 == 0);
     const WgradPlan p = plan_wgrad(a.g, d->groups, vec4, dvec4);
+    PM_PART_SLOTS(p.splits);
     a.chunks_per_split = p.chunks_per_split;
     const int hw = a.g.OH * a.g.OW;
     a.step_b = 128 / hw;
@@ -4187,18 +4261,22 @@ extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* o
     return pm_check_launch("pm_split_weights");
 }
 
-static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_desc* d, bool cpad);
+static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_desc* d, bool cpad, const pm_wgrad_part* part,
+                            int* slots_out);
 
 static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
-                                  float* dw, float* db, const long long* gtab, bool tab_aligned) {
+                                  float* dw, float* db, const long long* gtab, bool tab_aligned,
+                                  const pm_wgrad_part* part = nullptr, int* slots_out = nullptr) {
     WgradArgs a;
-    if (!fill_geom(d, a.g, false) || !gathered || !dense || !dw) return PM_EINVAL;
+    if (part) { dw = part->w; db = part->b; }
+    if (!fill_geom(d, a.g, false) || !gathered || !dense || (!dw && !slots_out)) return PM_EINVAL;
     const bool cpad = d->C % 32 != 0 && d->C > 32 && d->C < 64 && d->C % 4 == 0;      // one zero-padded tap per k-block
     if ((d->C % 32 != 0 && !cpad) || d->N % 4 != 0 || (d->d != 1 && d->d != 2)) return PM_EINVAL;
     if (!aligned16(gathered) || !aligned16(dense)) return PM_EINVAL;
     if (gtab ? !tab_aligned : (d->in_gs % 4 != 0 || d->out_gs % 4 != 0)) return PM_EINVAL;
     a.gathered = gathered; a.dense = dense; a.dw = dw; a.db = db; a.gtab = gtab;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
+    if (!set_part(a, part, db != nullptr)) return PM_EINVAL;
     {   // 32 gathered channels, both images of a sample fit LDS: image-resident persistent form (any stride)
         static const bool image_off = getenv("PM_NO_IMAGE_WGRAD") != nullptr;      // A/B switch for measurements
         const Geom& g = a.g;
@@ -4218,6 +4296,7 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
             int grid = grid_env > 0 ? grid_env : (nsub == 1 ? 128 : 192);
             if (grid > g.B * nsub) grid = g.B * nsub;
             grid -= grid % nsub;
+            PM_PART_SLOTS(grid / nsub);
             const int npi = (g.IH * g.IW * 8 + 255) / 256;
             hipStream_t s = (hipStream_t)stream;
 #define PM_IW(RNv, NPIv, NPDv, TPWv)                                                                                  \
@@ -4268,6 +4347,7 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
                 int grid = (ntiles + tpw - 1) / tpw;
                 if (grid > 256) grid = 256;
                 if (grid < 1) grid = 1;
+                PM_PART_SLOTS(grid);
                 hipStream_t s = (hipStream_t)stream;
                 static bool attr_set = false;
                 if (!attr_set) {
@@ -4288,7 +4368,7 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
     }
     a.cpad = cpad ? 1 : 0;
     {
-        const int rc_big = launch_big_wgrad(stream, a, d, cpad);
+        const int rc_big = launch_big_wgrad(stream, a, d, cpad, part, slots_out);
         if (rc_big != 1) return rc_big;
     }
     Geom gplan = a.g;
@@ -4298,6 +4378,7 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
     }
     WgradPlan p = plan_wgrad(gplan, d->groups, true, true);
     if (cpad) p.rc = p.rn = 2;  // the sub kernel (64 x 64 tiles) is the only form with the padded-tap mode
+    PM_PART_SLOTS(p.splits);
     a.chunks_per_split = p.chunks_per_split;
     const int hw = a.g.OH * a.g.OW;
     a.step_b = 128 / hw;
@@ -4350,10 +4431,28 @@ extern "C" int pm_gather_wgrad_table(pm_stream_t stream, const pm_gather_desc* d
     return gather_wgrad_impl(stream, d, gathered, dense, dw, db, table, all_aligned16 != 0);
 }
 
+// Partial-sum forms (see pm_wgrad_part in pmhip.h).  table may be NULL (plain / uniformly strided groups).
+extern "C" int pm_gather_wgrad_part(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
+                                    const long long* table, int all_aligned16, int use_bf16, const pm_wgrad_part* part) {
+    if (!d || !part || d->groups < 1) return PM_EINVAL;
+    if (use_bf16) return gather_wgrad_bf16_impl(stream, d, gathered, dense, nullptr, nullptr, table, all_aligned16 != 0, part);
+    return gather_wgrad_impl(stream, d, gathered, dense, nullptr, nullptr, table, all_aligned16 != 0, part);
+}
+
+extern "C" int pm_wgrad_part_slots(const pm_gather_desc* d, const float* gathered, const float* dense, int has_table,
+                                   int all_aligned16, int use_bf16, int* nslots) {
+    if (!d || !nslots || d->groups < 1) return PM_EINVAL;
+    static const long long dummy_tab[4] = {0, 0, 0, 0};
+    const long long* tab = has_table ? dummy_tab : nullptr;       // only its presence enters the plan
+    if (use_bf16) return gather_wgrad_bf16_impl(nullptr, d, gathered, dense, nullptr, nullptr, tab, all_aligned16 != 0, nullptr, nslots);
+    return gather_wgrad_impl(nullptr, d, gathered, dense, nullptr, nullptr, tab, all_aligned16 != 0, nullptr, nslots);
+}
+
 // Large weight gradients with 128-channel-aligned taps: 128 x 128 tiles (PM_WG_NOBIG=1: the 64 x 64 form, for A/B runs).  Returns
 // 1 when it did not apply (the caller goes on), else the launch status.  Defined at the END of this file so that the kernel's
 // instantiations are emitted behind every other kernel of the code object (see gather_wgrad_bf16_big_kernel).
-static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_desc* d, bool cpad) {
+static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_desc* d, bool cpad, const pm_wgrad_part* part,
+                            int* slots_out) {
         const Geom& g = a.g;
         const long long work = (long long)g.M * g.K * g.N * d->groups;
         if (!getenv("PM_WG_NOBIG") && !cpad && g.C % 128 == 0 && g.K >= 512 && g.N >= 128 && g.M >= 2048 && work >= (1LL << 30)) {
@@ -4367,6 +4466,7 @@ static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_de
             if (splits < 1) splits = 1;
             a.chunks_per_split = (total_chunks + splits - 1) / splits;
             splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+            PM_PART_SLOTS(splits);
             const int hw = g.OH * g.OW;
             a.step_b = bmc / hw;
             a.step_p = (bmc - a.step_b * hw) / g.OW;

@@ -250,6 +250,114 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     for (int n = threadIdx.x; n < N; n += 256) atomicAdd(out + n, sums[n]);
 }
 
+// The same column sums without atomics (pm_colsum_part): every workgroup STORES its sums into slot blockIdx.x of an arena
+// (pm_reduce_partials adds the slots in a fixed order), and inside the workgroup the per-thread sums meet in LDS in thread
+// order - run-to-run identical results.  N % 4 == 0, 1024 % N == 0 (a thread's four columns never change).
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                            long long part_stride, long long M, int N, int rows_per_block) {
+    __shared__ f32x4 accs[256];
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const long long e0 = r0 * N, e1 = r1 * N;                 // rows_per_block * N % 1024 == 0: e0 % 4 == 0
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    long long q = (e0 >> 2) + threadIdx.x;
+    const long long q1 = e1 >> 2;
+    for (; q + 1792 < q1; q += 2048) {                        // 8 independent loads in flight
+        const f32x4 a = x4[q], b = x4[q + 256], c = x4[q + 512], d = x4[q + 768];
+        const f32x4 e = x4[q + 1024], f = x4[q + 1280], g = x4[q + 1536], h = x4[q + 1792];
+        acc += ((a + b) + (c + d)) + ((e + f) + (g + h));
+    }
+    for (; q + 768 < q1; q += 1024) {
+        const f32x4 a = x4[q], b = x4[q + 256], c = x4[q + 512], d = x4[q + 768];
+        acc += (a + b) + (c + d);
+    }
+    for (; q < q1; q += 256) acc += x4[q];
+    accs[threadIdx.x] = acc;
+    __syncthreads();
+    // thread t holds columns 4 * ((e0 / 4 + t) % (N / 4)) ..: column quad qd is held by threads t0, t0 + N/4, t0 + 2N/4, ...
+    const int nq = N >> 2;
+    if ((int)threadIdx.x < N) {
+        const int n = threadIdx.x, qd = n >> 2, j = n & 3;
+        int t0 = (int)((qd - (e0 >> 2)) % nq);
+        if (t0 < 0) t0 += nq;
+        float sacc = 0.f;
+        for (int t = t0; t < 256; t += nq) sacc += accs[t][j];
+        part[(size_t)blockIdx.x * part_stride + n] = sacc;
+    }
+}
+
+// ---- sum of partial-sum slots (pm_reduce_partials) -------------------------------------------------------------------
+// Weight-gradient kernels in partial-sum mode store one slot per m-split / persistent workgroup; here g[off + i] +=
+// sum_s src[s * stride + i] in a FIXED order, so gradients are run-to-run identical and no f32 atomic reaches memory (atomics
+// execute at the memory side at ~1.3 TB/s chip-wide and count twice in HBM traffic; plain stores and these reads stream).
+// A job is a run of consecutive elements of one parameter.  nslots >= 8: at most 256 elements, the four waves deal the slots
+// (wave w: w, w + 4, ...; a lane = one 16-byte vector, 8 loads in flight) and their four partial vectors meet in LDS;
+// nslots < 8: at most 1024 elements, every thread walks all slots of its own vector.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const pm_reduce_job* __restrict__ jobs, float* __restrict__ g) {
+    __shared__ f32x4 red[3][256];
+    const pm_reduce_job j = jobs[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ src = j.src;
+    const bool vec = ((reinterpret_cast<size_t>(src) | (size_t)(j.stride * 4) | (size_t)(j.g_off * 4)) & 15) == 0;
+    if (j.nslots < 8) {
+        // thread t: elements 4 t .. 4 t + 3 of the job, all slots in order
+        const int e = 4 * threadIdx.x;
+        if (e >= j.count) return;
+        const int rem = j.count - e;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (vec && rem >= 4) {
+            for (int s = 0; s < j.nslots; ++s) acc += *reinterpret_cast<const f32x4*>(src + (size_t)s * j.stride + e);
+            f32x4* gp = reinterpret_cast<f32x4*>(g + j.g_off + e);
+            *gp = *gp + acc;
+        } else {
+            for (int k = 0; k < 4 && k < rem; ++k) {
+                float a = 0.f;
+                for (int s = 0; s < j.nslots; ++s) a += src[(size_t)s * j.stride + e + k];
+                g[j.g_off + e + k] += a;
+            }
+        }
+        return;
+    }
+    // count <= 256: lane l of every wave covers elements 4 l .. 4 l + 3; wave w sums slots w, w + 4, ... (8 loads in flight)
+    const int e = 4 * lane;
+    const int rem = j.count - e;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (rem > 0) {
+        if (vec && rem >= 4) {
+            const float* sp = src + e;
+            int s = wave;
+            for (; s + 28 < j.nslots; s += 32) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * j.stride);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 4) * j.stride);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 8) * j.stride);
+                const f32x4 a3 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 12) * j.stride);
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 16) * j.stride);
+                const f32x4 a5 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 20) * j.stride);
+                const f32x4 a6 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 24) * j.stride);
+                const f32x4 a7 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 28) * j.stride);
+                acc += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+            }
+            for (; s < j.nslots; s += 4) acc += *reinterpret_cast<const f32x4*>(sp + (size_t)s * j.stride);
+        } else {
+            for (int s = wave; s < j.nslots; s += 4)
+                for (int k = 0; k < 4 && k < rem; ++k) acc[k] += src[(size_t)s * j.stride + e + k];
+        }
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && rem > 0) {
+        acc = (acc + red[0][lane]) + (red[1][lane] + red[2][lane]);
+        if (vec && rem >= 4) {
+            f32x4* gp = reinterpret_cast<f32x4*>(g + j.g_off + e);
+            *gp = *gp + acc;
+        } else {
+            for (int k = 0; k < 4 && k < rem; ++k) g[j.g_off + e + k] += acc[k];
+        }
+    }
+}
+
 // Philox4x32-10 counter-based generator + Box-Muller: eps ~ N(0,1) for posterior.sample
 // (vae.py:124).  Bit parity with JAX's threefry streams is not a goal; parity tests
 // pass eps explicitly.  key = (seed, stream_id), counter = (element/4, step).
@@ -467,6 +575,38 @@ extern "C" int pm_colsum(pm_stream_t stream, const float* x, float* out, long lo
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream,
                        x, out, M, N, rows);
     return pm_check_launch("pm_colsum");
+}
+
+static int colsum_rows(long long M, int N) {         // rows per workgroup: ~256 - 512 workgroups of >= 64 KB (see pm_colsum)
+    int rows = 256;
+    while (rows < 8192 && ((M + rows - 1) / rows > 512 || (long long)rows * N * 4 < 65536)) rows *= 2;
+    return rows;
+}
+
+extern "C" int pm_colsum_part_slots(long long M, int N, int* nslots) {
+    if (!nslots || M <= 0 || N <= 0) return PM_EINVAL;
+    if (N % 4 != 0 || 1024 % N != 0) return PM_EINVAL;          // other widths keep pm_colsum (atomics)
+    const int rows = colsum_rows(M, N);
+    *nslots = (int)((M + rows - 1) / rows);
+    return PM_OK;
+}
+
+extern "C" int pm_colsum_part(pm_stream_t stream, const float* x, long long M, int N, float* part, long long part_stride,
+                              int nslots) {
+    int need = 0;
+    if (!x || !part || part_stride < N || pm_colsum_part_slots(M, N, &need) != PM_OK || need != nslots) return PM_EINVAL;
+    if (reinterpret_cast<size_t>(x) & 15) return PM_EINVAL;
+    PM_KTAG("colsum_part_kernel");
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)need), dim3(256), 0, (hipStream_t)stream, x, part, part_stride, M, N,
+                       colsum_rows(M, N));
+    return pm_check_launch("pm_colsum_part");
+}
+
+extern "C" int pm_reduce_partials(pm_stream_t stream, const pm_reduce_job* jobs_dev, int njobs, float* g) {
+    if (!jobs_dev || !g || njobs <= 0) return PM_EINVAL;
+    PM_KTAG("reduce_partials_kernel");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, g);
+    return pm_check_launch("pm_reduce_partials");
 }
 
 extern "C" int pm_axpy1(pm_stream_t stream, const float* x, float* y, long long n) {

@@ -224,7 +224,15 @@ template <int CC, int KS, int NS>
 __global__ __launch_bounds__(32 * NS) void thin_wgrad_lane_kernel(ThinArgs t, const float* __restrict__ gathered,
                                                                     const float* __restrict__ dense,
                                                                     float* __restrict__ dw, float* __restrict__ db,
-                                                                    float* __restrict__ dbg) {
+                                                                    float* __restrict__ dbg, pm_wgrad_part part) {
+    // part.w != NULL (partial-sum mode): this workgroup STORES its sums into slot blockIdx.x of the arenas instead of adding
+    // them to dw / db / dbg with atomics (one writer per slot element; pm_reduce_partials sums the slots in a fixed order)
+    const bool pmode = part.w != nullptr;
+    if (pmode) {
+        dw = part.w + (size_t)blockIdx.x * part.w_stride;
+        db = part.b ? part.b + (size_t)blockIdx.x * part.b_stride : nullptr;
+        dbg = part.bg ? part.bg + (size_t)blockIdx.x * part.bg_stride : nullptr;
+    }
     extern __shared__ __attribute__((aligned(16))) float thin_lds[];
     constexpr int NT = 32 * NS;
     constexpr int KK = CC * KS * KS;
@@ -337,7 +345,8 @@ __global__ __launch_bounds__(32 * NS) void thin_wgrad_lane_kernel(ThinArgs t, co
     if (dbg && tid < CC) {
         float s = 0.f;
         for (int wv = 0; wv < NS / 2; ++wv) s += redg[wv * CC + tid];
-        atomicAdd(dbg + tid, s);
+        if (pmode) dbg[tid] = s;
+        else atomicAdd(dbg + tid, s);
     }
     for (int e = tid; e < (KK + 1) * 32; e += NT) {
         const int idx = e >> 5, nn = e & 31;
@@ -346,7 +355,10 @@ __global__ __launch_bounds__(32 * NS) void thin_wgrad_lane_kernel(ThinArgs t, co
 #pragma unroll
         for (int wv = 0; wv < NS / 2; ++wv) s += red[(wv * (KK + 1) + idx) * 32 + nn];
         if (idx == KK) {
-            if (db) atomicAdd(db + nn, s);
+            if (db) {
+                if (pmode) db[nn] = s;
+                else atomicAdd(db + nn, s);
+            }
             continue;
         }
         const int c = idx / (KS * KS);
@@ -354,7 +366,9 @@ __global__ __launch_bounds__(32 * NS) void thin_wgrad_lane_kernel(ThinArgs t, co
         const int jy = jj / KS, jx = jj - jy * KS;
         const int ky = t.cs > 0 ? jy : KS - 1 - jy;
         const int kx = t.cs > 0 ? jx : KS - 1 - jx;
-        atomicAdd(dw + (size_t)(ky * KS + kx) * t.wts + (size_t)c * t.wcs + (size_t)nn * t.wns, s);
+        float* wd = dw + (size_t)(ky * KS + kx) * t.wts + (size_t)c * t.wcs + (size_t)nn * t.wns;
+        if (pmode) *wd = s;
+        else atomicAdd(wd, s);
     }
 }
 
@@ -615,11 +629,21 @@ extern "C" int pm_thin_to1_bf16(pm_stream_t stream, const pm_gather_desc* d, con
     return pm_check_launch("pm_thin_to1_bf16");
 }
 
-extern "C" int pm_thin_wgrad(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
-                             float* dw, float* db, float* db_gathered) {
+static int thin_wgrad_impl(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
+                           float* dw, float* db, float* db_gathered, const pm_wgrad_part* partp, int* slots_out) {
     ThinArgs t;
-    if (!fill_thin(d, t) || !gathered || !dense || !dw) return PM_EINVAL;
+    pm_wgrad_part part = {};
+    if (partp) {
+        part = *partp;
+        dw = part.w; db = part.b; db_gathered = part.bg;
+    }
+    if (!fill_thin(d, t) || !gathered || !dense || (!dw && !slots_out)) return PM_EINVAL;
     if (!lane_form_ok(t)) return PM_EINVAL;
+    {
+        const int nslots = t.B < 256 ? t.B : 256;            // = the grid below: one slot per persistent workgroup
+        if (slots_out) { *slots_out = nslots; return PM_OK; }
+        if (partp && part.nslots != nslots) return PM_EINVAL;
+    }
     constexpr int NS = 32;
     const int KK = t.C * t.KH * t.KW;
     const size_t patch = (size_t)t.C * (t.OH + t.KH - 1) * (4 * ((t.OW + 3) / 4) + 4);
@@ -636,7 +660,7 @@ extern "C" int pm_thin_wgrad(pm_stream_t stream, const pm_gather_desc* d, const 
     }
     const dim3 grid(t.B < 256 ? t.B : 256);
     hipStream_t s = (hipStream_t)stream;
-#define PM_TW(CCv, KSv) hipLaunchKernelGGL((thin_wgrad_lane_kernel<CCv, KSv, NS>), grid, dim3(32 * NS), lds, s, t, gathered, dense, dw, db, db_gathered)
+#define PM_TW(CCv, KSv) hipLaunchKernelGGL((thin_wgrad_lane_kernel<CCv, KSv, NS>), grid, dim3(32 * NS), lds, s, t, gathered, dense, dw, db, db_gathered, part)
     PM_KTAG("thin_wgrad_lane_kernel<%d, %d, 32>", t.C == 1 ? 1 : 2, t.KH == 5 ? 5 : 3);
     if (t.C == 1 && t.KH == 5) PM_TW(1, 5);
     else if (t.C == 2 && t.KH == 5) PM_TW(2, 5);
@@ -644,6 +668,20 @@ extern "C" int pm_thin_wgrad(pm_stream_t stream, const pm_gather_desc* d, const 
     else PM_TW(2, 3);
 #undef PM_TW
     return pm_check_launch("pm_thin_wgrad");
+}
+
+extern "C" int pm_thin_wgrad(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
+                             float* dw, float* db, float* db_gathered) {
+    return thin_wgrad_impl(stream, d, gathered, dense, dw, db, db_gathered, nullptr, nullptr);
+}
+extern "C" int pm_thin_wgrad_part(pm_stream_t stream, const pm_gather_desc* d, const float* gathered, const float* dense,
+                                  const pm_wgrad_part* part) {
+    if (!part || !part->w) return PM_EINVAL;
+    return thin_wgrad_impl(stream, d, gathered, dense, nullptr, nullptr, nullptr, part, nullptr);
+}
+extern "C" int pm_thin_wgrad_part_slots(const pm_gather_desc* d, const float* gathered, const float* dense, int* nslots) {
+    if (!nslots) return PM_EINVAL;
+    return thin_wgrad_impl(nullptr, d, gathered, dense, nullptr, nullptr, nullptr, nullptr, nslots);
 }
 
 extern "C" int pm_tap_shift_add(pm_stream_t stream, const pm_gather_desc* d, const float* T, int ldt,

@@ -64,8 +64,18 @@ class _PlannedStep:
     # gradient buffer after step()).
     def _zero_grad(self, store) -> None:
         if not store.g_clean:
-            ops.fill_zero(store.flat_g)
+            store.zero_grad()           # also drops partial sums a host-side backward pass left pending
         store.g_clean = False
+
+    @staticmethod
+    def _reduce_partials(store) -> None:
+        """The weight-gradient launches of the backward pass left per-split partial sums (partials.PartialSums): add them
+        into the flat gradient buffer on the current stream - the stream the optimizer runs on, already ordered behind every
+        weight-gradient launch.  With an overlapping data-parallel reducer each bucket's runs are added on the communication
+        stream right in front of its all-reduce instead (GradReducer._flush)."""
+        r = store.reducer
+        if r is None or not r.overlap:
+            store.reduce_partials()
 
     def _grads_consumed(self, store) -> None:
         store.g_clean = bool(self.adam_cfg.zero_grad)
@@ -186,6 +196,7 @@ class PMVAETrainStep(_PlannedStep):
         ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], self.loss_cfg, self.step_dev,
                        self.metrics, self.g_rec, self.g_kl, None if early else self.g_mll)
         m.backward(self.g_rec, self.g_kl, self.g_mll)
+        self._reduce_partials(m.store)
 
     def _update(self) -> None:
         s = self.model.store
@@ -294,6 +305,7 @@ class VQVAETrainStep(_PlannedStep):
         m(self.x, is_training=True)
         self._zero_grad(s)
         m.backward()
+        self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
@@ -449,6 +461,7 @@ class PMVQVAETrainStep(_PlannedStep):
         s = self.store
         if self.adam_cfg is None:
             raise RuntimeError("this PMVQVAETrainStep was built without an optimizer (evaluation only)")
+        self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
@@ -542,6 +555,7 @@ class VDVAETrainStep(_PlannedStep):
         m(self.x, self.b, self.eps)
         self._zero_grad(s)
         m.backward()
+        self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()       # the clip / non-finite decision below sees the REDUCED gradient on every rank
         ops.sumsq(s.flat_g, self.gnorm_sq)
@@ -646,6 +660,7 @@ class VADETrainStep(_PlannedStep):
             m.backward_elbo(self.g)
         else:
             m.backward_reconstruction_at_mean(self.g)
+        self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
@@ -721,6 +736,7 @@ class PMVADETrainStep(_PlannedStep):
         ops.neg_mean_loss(ll, 1.0 / self.B, self.metrics, self.g)
         self._zero_grad(s)
         m.backward_posterior_matching_ll(self.g)
+        self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
@@ -800,6 +816,7 @@ class LookaheadTrainStep(_PlannedStep):
         ops.neg_mean_loss(ll, 1.0 / self.B, self.metrics, self.g)
         self._zero_grad(s)
         m.backward(self.g)
+        self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)

@@ -68,13 +68,39 @@ class ParamStore:
         self.p: Dict[str, torch.Tensor] = {}
         self.g: Dict[str, torch.Tensor] = _GradViews(self)
         self.g_clean = False           # True: flat_g is known to be all zeros (see _GradViews)
-        self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self.flat_p = self._flat_g = self.flat_m = self.flat_v = None
+        self.partials = None           # partials.PartialSums: weight-gradient launches leave per-split partial sums
         self.n_decay = 0
         self.device = None
         self._split_requests = []      # (param name, LayerGeom, mode, groups, group kw)
         self._split_views = []
         self.use_bf16 = True           # bf16x3 matrix-core path for layers that qualify
         self.reducer = None            # parallel.GradReducer when the step runs data-parallel (set by the train step)
+
+    # The flat gradient buffer.  Weight-gradient launches store per-split partial sums into arenas (self.partials) and the
+    # train steps add them with reduce_partials() in front of the optimizer; host code that reads the buffer any other way
+    # (tests, tools) gets the same contract through this property: whatever is pending is added first (device-synchronous).
+    @property
+    def flat_g(self):
+        if self.partials is not None and self.partials.pending:
+            self.partials.flush_sync()
+        return self._flat_g
+
+    @flat_g.setter
+    def flat_g(self, value):
+        self._flat_g = value
+
+    def reduce_partials(self, lo: int = 0, hi=None) -> None:
+        """adds the pending partial sums of gradient elements [lo, hi) into the flat buffer on the CURRENT stream (which the
+        caller has ordered behind the weight-gradient launches)"""
+        if self.partials is not None and self.partials.pending:
+            self.partials.reduce(lo, hi)
+
+    def zero_grad(self) -> None:
+        """zero gradients: pending partial sums are dropped, the flat buffer is zero-filled"""
+        if self.partials is not None:
+            self.partials.pending.clear()
+        ops.fill_zero(self._flat_g)
 
     def grads_ready(self, prefixes, streams=None) -> None:
         """A model's backward reports that every parameter under `prefixes` has its final gradient (once the work
@@ -120,7 +146,11 @@ class ParamStore:
         pad4 = (lambda n: n) if os.environ.get("PM_NO_PARAM_PAD") else (lambda n: (n + 3) // 4 * 4)   # (A/B switch)
         total = sum(pad4(int(np.prod(self.specs[n][0]))) for n in decayed + plain)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=device)
-        self.flat_g = torch.zeros_like(self.flat_p)
+        self._flat_g = torch.zeros_like(self.flat_p)
+        if torch.device(device).type == "cuda":
+            from ..partials import PartialSums
+
+            self.partials = PartialSums(self._flat_g)
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         off = 0
@@ -132,7 +162,7 @@ class ParamStore:
             n = int(np.prod(shape))
             self.offsets[name] = (off, n)
             self.p[name] = self.flat_p[off:off + n].view(shape)
-            self.g[name] = self.flat_g[off:off + n].view(shape)
+            self.g[name] = self._flat_g[off:off + n].view(shape)
             self.p[name].copy_(torch.from_numpy(host[name]))
             off += pad4(n)
             if name in decayed_set:

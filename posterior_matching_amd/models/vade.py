@@ -169,7 +169,7 @@ class VADE(Module):
         return probs
 
     def zero_grad(self) -> None:
-        ops.fill_zero(self.store.flat_g)
+        self.store.zero_grad()
 
     def params_dict(self) -> Dict[str, torch.Tensor]:
         return self.store.to_dict("p")

@@ -332,7 +332,7 @@ class PosteriorMatchingVAE(Module):
         ops.wait_stream(main, side)
 
     def zero_grad(self) -> None:
-        ops.fill_zero(self.store.flat_g)
+        self.store.zero_grad()
 
     # checkpoint-style access (reference: TrainState.params pytree)
     def params_dict(self) -> Dict[str, torch.Tensor]:

@@ -1018,7 +1018,7 @@ class PosteriorMatchingVDVAE(Module):
         self.ws.join_all_aux()
 
     def zero_grad(self) -> None:
-        ops.fill_zero(self.store.flat_g)
+        self.store.zero_grad()
 
     def params_dict(self):
         return self.store.to_dict("p")

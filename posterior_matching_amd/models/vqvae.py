@@ -463,7 +463,7 @@ class VQVAE(Module):
         self.ws.join_aux()
 
     def zero_grad(self) -> None:
-        ops.fill_zero(self.store.flat_g)
+        self.store.zero_grad()
 
     def params_dict(self) -> Dict[str, torch.Tensor]:
         return self.store.to_dict("p")

@@ -452,17 +452,64 @@ def _bf16_wgrad_channels(C: int) -> bool:
     return C % 32 == 0 or (32 < C < 64 and C % 4 == 0)
 
 
+def _weight_extent(d: GatherDesc) -> int:
+    """floats from a weight gradient's first element to one past the last the launch can write (all groups)"""
+    one = ((d.KH - 1) * d.kws + d.KW - 1) * d.wts + (d.C - 1) * d.wcs + (d.N - 1) * d.wns + 1
+    return (d.groups - 1) * d.w_gs + one
+
+
+def _part_arenas(desc: GatherDesc, dw, db, nslots: int, dbg=None):
+    """pm_wgrad_part of a launch whose weight (bias) gradients are ONE run of the flat gradient buffer starting at dw (db):
+    plain launches and uniformly strided groups (the groups of every such launch in this package tile one contiguous run).
+    None: dw is not a view of a parameter store's gradient buffer (free-standing tensors keep the atomics)."""
+    from . import partials
+
+    own = partials.owner_of(dw)
+    if own is None or (db is not None and partials.owner_of(db) is not own) or (
+            dbg is not None and partials.owner_of(dbg) is not own):
+        return None
+    wn = max(_weight_extent(desc), dw.numel())            # whole parameters (groups: the run their weights tile)
+    wbuf, woff = own.arena(own.offset(dw), wn, nslots)
+    wstride = own.entries[(own.offset(dw), wn)][2]
+    bbuf = bgbuf = None
+    boff = bgoff = bstride = bgstride = 0
+    if db is not None:
+        bn = max((desc.groups - 1) * desc.bias_gs + desc.N, db.numel())
+        bbuf, boff = own.arena(own.offset(db), bn, nslots)
+        bstride = own.entries[(own.offset(db), bn)][2]
+    if dbg is not None:
+        bgbuf, bgoff = own.arena(own.offset(dbg), dbg.numel(), nslots)
+        bgstride = own.entries[(own.offset(dbg), dbg.numel())][2]
+    return partials.make_part(wbuf, woff, wstride, nslots, bbuf, boff, bstride, bgbuf, bgoff, bgstride)
+
+
+def reduce_partials(table, njobs: int, flat_g, nbytes: float = 0.0) -> None:
+    _call("pm_reduce_partials", table.data_ptr(), njobs, _ptr(flat_g), tag="reduce_partials_kernel", work={"bytes": nbytes})
+
+
 def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, db_gathered=None) -> None:
     """db_gathered: bias gradient taken over the GATHERED operand (transposed convs); only the thin lane form
-    fuses it - callers must check the return value (True = db_gathered was accumulated)."""
+    fuses it - callers must check the return value (True = db_gathered was accumulated).
+    Gradients that are views of a ParamStore's flat buffer leave the kernels as PARTIAL SUMS (partials.PartialSums:
+    plain stores into per-split slots, summed in a fixed order by pm_reduce_partials); free-standing dw / db keep the
+    accumulate-with-atomics contract of the C entry points."""
+    lib = _lib.load()
     if _lane_form(desc) and not os.environ.get("PM_NO_LANE_WGRAD"):
         tag = work = None
         if _timer is not None:
             tag = f"thin_wgrad_lane_kernel<{desc.C}, {desc.KH}, 32>"
             work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
+        ns = C.c_int()
+        part = None
+        if lib.pm_thin_wgrad_part_slots(C.byref(desc), _ptr(gathered), _ptr(dense), C.byref(ns)) == 0:
+            part = _part_arenas(desc, dw, db, ns.value, db_gathered)
+        if part is not None:
+            _call("pm_thin_wgrad_part", C.byref(desc), _ptr(gathered), _ptr(dense), C.byref(part), tag=tag, work=work)
+            return True
         _call("pm_thin_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), _ptr(db_gathered),
               tag=tag, work=work)
         return True
+    al = int(gathered.data_ptr() % 16 == 0 and dense.data_ptr() % 16 == 0)
     if (bf16 and USE_BF16_WGRAD and _bf16_wgrad_channels(desc.C) and desc.N % 4 == 0 and desc.d in (1, 2)
             and gathered.data_ptr() % 16 == 0 and dense.data_ptr() % 16 == 0):
         tag = work = None
@@ -473,15 +520,30 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, 
             if (_patch_form(desc) and desc.C == 32 and desc.N <= 64 and desc.KH * desc.KW in (9, 25)):
                 tag = f"patch_wgrad_bf16_kernel<{2 if desc.N > 32 else 1}, {7 if desc.KH * desc.KW == 25 else 3}>"
             work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
+        ns = C.c_int()
+        part = None
+        if lib.pm_wgrad_part_slots(C.byref(desc), _ptr(gathered), _ptr(dense), 0, al, 1, C.byref(ns)) == 0:
+            part = _part_arenas(desc, dw, db, ns.value)
+        if part is not None:
+            _call("pm_gather_wgrad_part", C.byref(desc), _ptr(gathered), _ptr(dense), None, al, 1, C.byref(part), tag=tag,
+                  work=work)
+            return
         _call("pm_gather_wgrad_bf16", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
         return
     tag = work = None
     if _timer is not None:
         v = [C.c_int() for _ in range(5)]
-        _lib.load().pm_query_wgrad_plan(C.byref(desc), int(gathered.data_ptr() % 16 == 0),
-                                        int(dense.data_ptr() % 16 == 0), *[C.byref(x) for x in v])
+        lib.pm_query_wgrad_plan(C.byref(desc), int(gathered.data_ptr() % 16 == 0),
+                                int(dense.data_ptr() % 16 == 0), *[C.byref(x) for x in v])
         tag = f"gather_wgrad_kernel<{v[0].value},{v[1].value},{_MODES[v[2].value]},{v[3].value}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(gathered, dense, dw), "detail": _detail(desc)}
+    ns = C.c_int()
+    part = None
+    if lib.pm_wgrad_part_slots(C.byref(desc), _ptr(gathered), _ptr(dense), 0, al, 0, C.byref(ns)) == 0:
+        part = _part_arenas(desc, dw, db, ns.value)
+    if part is not None:
+        _call("pm_gather_wgrad_part", C.byref(desc), _ptr(gathered), _ptr(dense), None, al, 0, C.byref(part), tag=tag, work=work)
+        return
     _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
 
@@ -621,6 +683,7 @@ class WgradBatch:
     def __init__(self):
         self.items = {}          # key -> [(geom, x, dy, dw, db)]
         self._tables = {}        # (key, pointer tuple) -> (device table, aligned flag)
+        self._ptables = {}       # (key, pointer tuple) -> partial-sum form of the same launch (_part_table)
         self.reducer = None      # parallel.GradReducer under data parallelism: every grouped launch reports its weight ranges
 
     def add(self, g: LayerGeom, x, dy, dw, db, bf16: bool, in_act: int = ACT_NONE) -> None:
@@ -659,8 +722,14 @@ class WgradBatch:
             if _timer is not None:
                 tag = "gather_wgrad_table"
                 work = {"flops": _algorithmic_flops(d), "bytes": len(lst) * _nbytes(x0, dy0, dw0), "detail": _detail(d)}
-            _call("pm_gather_wgrad_table", C.byref(d), _ptr(x0), _ptr(dy0), _ptr(dw0), _ptr(db0), table.data_ptr(), aligned,
-                  int(key[-2]), tag=tag, work=work)
+            pt = self._part_table(key, ptrs, lst, d, aligned)
+            if pt is not None:          # partial sums: one slot-major arena for the launch, [slot][group][weight]
+                ptable, part = pt
+                _call("pm_gather_wgrad_part", C.byref(d), _ptr(x0), _ptr(dy0), ptable.data_ptr(), aligned, int(key[-2]),
+                      C.byref(part), tag=tag, work=work)
+            else:
+                _call("pm_gather_wgrad_table", C.byref(d), _ptr(x0), _ptr(dy0), _ptr(dw0), _ptr(db0), table.data_ptr(), aligned,
+                      int(key[-2]), tag=tag, work=work)
             if self.reducer is not None:
                 # data-parallel: these weights have their final gradient once this launch has run (a parameter belongs to one
                 # layer, a layer to one group); bias gradients sit in the 1-D suffix, which finish() reduces
@@ -668,6 +737,41 @@ class WgradBatch:
                 offs = [((dw.data_ptr() - base) // 4, dw.numel()) for _, _, _, dw, _ in lst]
                 self.reducer.ready_ranges([(o, o + c) for o, c in offs if 0 <= o and o + c <= n])
         self.items = {}
+
+    def _part_table(self, key, ptrs, lst, d, aligned):
+        """(device table with arena-relative dw / db offsets, pm_wgrad_part) when every gradient of the launch is a view of
+        one ParamStore's flat buffer; None keeps the accumulate-with-atomics launch"""
+        from . import partials
+
+        g0, x0, dy0, dw0, db0 = lst[0]
+        own = partials.owner_of(dw0)
+        if own is None or any(partials.owner_of(it[3]) is not own or (it[4] is not None and partials.owner_of(it[4]) is not own)
+                              for it in lst):
+            return None
+        cached = self._ptables.get((key, ptrs))
+        if cached is None:
+            ns = C.c_int()
+            if _lib.load().pm_wgrad_part_slots(C.byref(d), _ptr(x0), _ptr(dy0), 1, aligned, int(key[-2]), C.byref(ns)) != 0:
+                return None
+            S, G = ns.value, len(lst)
+            wn = (dw0.numel() + 3) // 4 * 4
+            bn = ((db0.numel() + 3) // 4 * 4) if db0 is not None else 0
+            wbuf = own.new_shared(S * G * wn)
+            bbuf = own.new_shared(S * G * bn) if bn else None
+            rows = []
+            for gi, (_, x, dy, dw, db) in enumerate(lst):
+                rows += [(x.data_ptr() - x0.data_ptr()) // 4, (dy.data_ptr() - dy0.data_ptr()) // 4, gi * wn, gi * bn]
+            ptable = torch.tensor(rows, dtype=torch.int64, device=x0.device)
+            part = partials.make_part(wbuf, 0, G * wn, S, bbuf, 0, G * bn)
+            cached = (ptable, part, wbuf, bbuf, S, wn, bn)
+            self._ptables[(key, ptrs)] = cached
+        ptable, part, wbuf, bbuf, S, wn, bn = cached
+        G = len(lst)
+        for gi, (_, _, _, dw, db) in enumerate(lst):       # (re-)register the runs and mark them pending
+            own.arena(own.offset(dw), dw.numel(), S, stride=G * wn, shared=(wbuf, gi * wn))
+            if db is not None:
+                own.arena(own.offset(db), db.numel(), S, stride=G * bn, shared=(bbuf, gi * bn))
+        return ptable, part
 
     def discard(self) -> None:
         """drops queued items (a backward pass that raised must not leave stale operands behind)"""
@@ -1320,8 +1424,22 @@ def fill_zero(t) -> None:
 
 
 def colsum(x, out) -> None:
+    """out[n] += sum_m x[m, n].  `out` inside a ParamStore's gradient buffer: per-workgroup partial sums (no atomics,
+    deterministic; partials.PartialSums), added by the store's next reduce."""
+    from . import partials
+
     N = x.shape[-1]
-    _call("pm_colsum", _ptr(x), _ptr(out), x.numel() // N, N, tag="colsum_kernel", work={"bytes": _nbytes(x, out)})
+    M = x.numel() // N
+    own = partials.owner_of(out)
+    ns = C.c_int()
+    if (own is not None and x.data_ptr() % 16 == 0 and out.numel() == N
+            and _lib.load().pm_colsum_part_slots(M, N, C.byref(ns)) == 0):
+        buf, off = own.arena(own.offset(out), N, ns.value)
+        stride = own.entries[(own.offset(out), N)][2]
+        _call("pm_colsum_part", _ptr(x), M, N, buf.data_ptr() + 4 * off, stride, ns.value, tag="colsum_part_kernel",
+              work={"bytes": _nbytes(x) + 4.0 * ns.value * N})
+        return
+    _call("pm_colsum", _ptr(x), _ptr(out), M, N, tag="colsum_kernel", work={"bytes": _nbytes(x, out)})
 
 
 def axpy1(x, y) -> None:

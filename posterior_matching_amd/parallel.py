@@ -88,7 +88,7 @@ class GradReducer:
         if async_issue is None:
             async_issue = dist.is_initialized() and dist.get_backend() == "nccl"
         self.async_issue = async_issue
-        self.flat = store.flat_g
+        self.flat = store.flat_g           # (the tensor itself: ranges of it are all-reduced in place)
         self._cuda = torch.device(store.device).type == "cuda"     # host tensors (gloo, CPU tests): no streams to order
         self.comm = torch.cuda.Stream(device=store.device) if self._cuda else None
         self._done: List[Tuple[int, int]] = []          # element ranges already handed to a collective this step
@@ -159,6 +159,11 @@ class GradReducer:
             ops.wait_event(self.comm, ev)
         self._pending_events = []
         for a, b in go:
+            # the weight-gradient launches left per-split partial sums (partials.PartialSums): this range's are added into
+            # the flat buffer on the communication stream, behind its producers and in front of its collective
+            if self._cuda and getattr(self.store, "partials", None) is not None and self.store.partials.pending:
+                with torch.cuda.stream(self.comm):
+                    self.store.reduce_partials(a, b)
             ops.host_call(self._issue, a, b, not final)
             self._done.append((a, b))
         self._pending = [r for r in merged if r not in go]
