@@ -133,6 +133,7 @@ SIGNATURES = {
     "pm_colsum_part_slots": [_LL, _I, C.POINTER(_I)],
     "pm_colsum_part": [_P, _P, _LL, _I, _P, _LL, _I],
     "pm_reduce_partials": [_P, _P, _I, _P],
+    "pm_adam_step_jobs": [_P, _P, _I, _P, _P, _P, _P, _LL, _P, C.POINTER(AdamCfg)],
     "pm_thin_conv": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
     "pm_thin_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P],
     "pm_thin_to1_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],

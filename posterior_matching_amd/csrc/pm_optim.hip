@@ -191,6 +191,74 @@ int launch_adam(hipStream_t s, float* p, float* g, float* m, float* v, float* em
     return 0;
 }
 
+// pm_adam_step_jobs: the same update driven by a job table that covers the whole flat buffer (pm_reduce_job; nslots == 0: a
+// run without partial sums).  A job's gradient is g[i] + sum over its slots, added in the fixed order of
+// reduce_partials_kernel - the weight-gradient kernels' partial sums are read ONCE, by the optimizer, and the separate
+// reduction launch with its write and re-read of g is gone.  Runs start on 16-byte boundaries and their buffers are padded to
+// whole vectors (ParamStore pads every parameter to 4 floats, arenas to 4 floats per slot), so every access is a 16-byte one.
+__global__ __launch_bounds__(256) void adam_jobs_kernel(const pm_reduce_job* __restrict__ jobs, float* __restrict__ p,
+                                                          float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          long long n_decay, const int* __restrict__ count_dev, pm_adam_cfg c) {
+    __shared__ f32x4 red[3][64];
+    const pm_reduce_job j = jobs[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ src = j.src;
+    const int count = j.count;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int e;                                  // this thread's first element of the job (a vector of 4), valid when `mine`
+    bool mine;
+    if (j.nslots >= 8) {                    // <= 256 elements: the waves deal the slots, wave 0 finishes
+        e = 4 * lane;
+        const bool in = e < count;
+        if (in) {
+            const float* sp = src + e;
+            int s = wave;
+            for (; s + 28 < j.nslots; s += 32) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp + (size_t)s * j.stride);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 4) * j.stride);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 8) * j.stride);
+                const f32x4 a3 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 12) * j.stride);
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 16) * j.stride);
+                const f32x4 a5 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 20) * j.stride);
+                const f32x4 a6 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 24) * j.stride);
+                const f32x4 a7 = *reinterpret_cast<const f32x4*>(sp + (size_t)(s + 28) * j.stride);
+                acc += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+            }
+            for (; s < j.nslots; s += 4) acc += *reinterpret_cast<const f32x4*>(sp + (size_t)s * j.stride);
+        }
+        if (wave > 0) red[wave - 1][lane] = acc;
+        __syncthreads();
+        mine = in && wave == 0;
+        if (mine) acc = (acc + red[0][lane]) + (red[1][lane] + red[2][lane]);
+    } else {                                // <= 1024 elements: every thread walks the slots of its own vector
+        e = 4 * threadIdx.x;
+        mine = e < count;
+        if (mine)
+            for (int s = 0; s < j.nslots; ++s) acc += *reinterpret_cast<const f32x4*>(src + (size_t)s * j.stride + e);
+    }
+    if (!mine) return;
+    const int cnt = count_dev[0];
+    const float t = (float)(cnt + 1);
+    const float bc1 = 1.f - powf(c.b1, t);
+    const float bc2 = 1.f - powf(c.b2, t);
+    const float lr = pm_lr(c, cnt);
+    const long long i0 = j.g_off + e;
+    f32x4* g4 = reinterpret_cast<f32x4*>(g + i0);
+    f32x4* p4 = reinterpret_cast<f32x4*>(p + i0);
+    f32x4* m4 = reinterpret_cast<f32x4*>(m + i0);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v + i0);
+    f32x4 gv = *g4, pv = *p4, mv = *m4, vv = *v4;
+    gv += acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float p0 = pv[k], m0 = mv[k], v0 = vv[k];
+        adam_one(p0, gv[k] * c.grad_scale, m0, v0, i0 + k < n_decay, c, bc1, bc2, lr);
+        pv[k] = p0; mv[k] = m0; vv[k] = v0;
+    }
+    *m4 = mv; *v4 = vv; *p4 = pv;
+    if (c.zero_grad) *g4 = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 __global__ void counter_increment_kernel(int* c) { c[0] += 1; }
 
 // sum of squares with a non-finite guard: out[0] += sum x^2 (NaN / inf propagate into the sum)
@@ -478,6 +546,17 @@ extern "C" int pm_adam_step(pm_stream_t stream, float* p, float* g, float* m, fl
     if (!p || !g || !m || !v || !count_dev || !cfg || n <= 0) return PM_EINVAL;
     launch_adam<false>((hipStream_t)stream, p, g, m, v, nullptr, n, n_decay, count_dev, nullptr, *cfg, 0.f, 0.f, 0);
     return pm_check_launch("pm_adam_step");
+}
+
+extern "C" int pm_adam_step_jobs(pm_stream_t stream, const pm_reduce_job* jobs_dev, int njobs, float* p, float* g, float* m,
+                                 float* v, long long n_decay, const int* count_dev, const pm_adam_cfg* cfg) {
+    if (!jobs_dev || njobs <= 0 || !p || !g || !m || !v || !count_dev || !cfg) return PM_EINVAL;
+    if ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) | reinterpret_cast<size_t>(v)) & 15)
+        return PM_EINVAL;
+    PM_KTAG("adam_jobs_kernel");
+    hipLaunchKernelGGL(adam_jobs_kernel, dim3((unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, p, g, m, v, n_decay,
+                       count_dev, *cfg);
+    return pm_check_launch("pm_adam_step_jobs");
 }
 
 extern "C" int pm_sumsq(pm_stream_t stream, const float* x, long long n, float* out) {

@@ -67,15 +67,38 @@ class _PlannedStep:
             store.zero_grad()           # also drops partial sums a host-side backward pass left pending
         store.g_clean = False
 
-    @staticmethod
-    def _reduce_partials(store) -> None:
+    plain_adam = True       # False: the step's optimizer reads the REDUCED buffer (global-norm clip: VDVAETrainStep)
+
+    def _reduce_partials(self, store) -> None:
         """The weight-gradient launches of the backward pass left per-split partial sums (partials.PartialSums): add them
         into the flat gradient buffer on the current stream - the stream the optimizer runs on, already ordered behind every
         weight-gradient launch.  With an overlapping data-parallel reducer each bucket's runs are added on the communication
         stream right in front of its all-reduce instead (GradReducer._flush)."""
         r = store.reducer
+        if r is None and self._fuse_adam() and store.partials is not None:
+            return                      # one GPU, plain Adam: _adam_step reads the partial sums itself (pm_adam_step_jobs)
         if r is None or not r.overlap:
             store.reduce_partials()
+
+    fused_adam = not os.environ.get("PM_NO_FUSED_ADAM")       # A/B switch
+
+    def _fuse_adam(self) -> bool:
+        # zero_grad = 0 (tests that read the gradient buffer after step()): the buffer must hold the gradient -> reduce first
+        return bool(self.fused_adam and self.plain_adam and self.adam_cfg is not None and self.adam_cfg.zero_grad)
+
+    def _adam_step(self, s, step_dev) -> None:
+        """optax.scale_by_adam -> add_decayed_weights -> schedule -> apply_updates on the flat buffers.  With partial sums
+        pending (one GPU) the optimizer kernel adds them as it reads g; otherwise g already holds the gradient."""
+        ps = s.partials
+        if ps is not None and ps.pending and s.reducer is None and self._fuse_adam():
+            tab = ps.adam_table()
+            if tab is not None:
+                table, njobs, nbytes = tab
+                ops.adam_step_jobs(table, njobs, s.flat_p, s._flat_g, s.flat_m, s.flat_v, s.n_decay, step_dev, self.adam_cfg,
+                                   nbytes)
+                return
+            s.reduce_partials()
+        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, step_dev, self.adam_cfg)
 
     def _grads_consumed(self, store) -> None:
         store.g_clean = bool(self.adam_cfg.zero_grad)
@@ -200,7 +223,7 @@ class PMVAETrainStep(_PlannedStep):
 
     def _update(self) -> None:
         s = self.model.store
-        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._adam_step(s, self.step_dev)
         self._grads_consumed(s)
         s.split_all()                      # refresh the pre-split bf16 weight copies (one launch)
         ops.counter_increment(self.step_dev)
@@ -308,7 +331,7 @@ class VQVAETrainStep(_PlannedStep):
         self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
-        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._adam_step(s, self.step_dev)
         self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)
@@ -464,7 +487,7 @@ class PMVQVAETrainStep(_PlannedStep):
         self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
-        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._adam_step(s, self.step_dev)
         self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)
@@ -497,6 +520,9 @@ class VDVAETrainStep(_PlannedStep):
     """train_pm_vdvae.py:109-154 as one launch sequence: eps -> PosteriorMatchingVDVAE forward ->
     loss = -mean(rec_ll - kl) + mean(pm_kl) -> backward -> [gradient all-reduce] -> global-norm clip +
     Adam (+ parameter EMA, non-finite steps skipped) -> step += 1."""
+
+    plain_adam = False      # sumsq / clip / non-finite skip read the reduced gradient: the partial sums are added first
+
 
     def __init__(self, model, lr, batch_size: int, gradient_clip: float = 200.0, ema_rate: Optional[float] = 0.999,
                  weight_decay: float = 0.0, adam: Optional[Mapping[str, float]] = None, seed: int = 0, world_size: int = 1,
@@ -663,7 +689,7 @@ class VADETrainStep(_PlannedStep):
         self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
-        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._adam_step(s, self.step_dev)
         self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)
@@ -739,7 +765,7 @@ class PMVADETrainStep(_PlannedStep):
         self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
-        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._adam_step(s, self.step_dev)
         self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)
@@ -819,7 +845,7 @@ class LookaheadTrainStep(_PlannedStep):
         self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()
-        ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, self.step_dev, self.adam_cfg)
+        self._adam_step(s, self.step_dev)
         self._grads_consumed(s)
         s.split_all()
         ops.counter_increment(self.step_dev)

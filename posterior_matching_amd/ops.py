@@ -480,7 +480,22 @@ def _part_arenas(desc: GatherDesc, dw, db, nslots: int, dbg=None):
     if dbg is not None:
         bgbuf, bgoff = own.arena(own.offset(dbg), dbg.numel(), nslots)
         bgstride = own.entries[(own.offset(dbg), dbg.numel())][2]
-    return partials.make_part(wbuf, woff, wstride, nslots, bbuf, boff, bstride, bgbuf, bgoff, bgstride)
+    part = partials.make_part(wbuf, woff, wstride, nslots, bbuf, boff, bstride, bgbuf, bgoff, bgstride)
+    part._eager = (own, (own.offset(dw), wn), nslots * wstride * 4)     # see _part_done
+    return part
+
+
+def _part_done(part) -> None:
+    """Behind a partial-sum launch: a LARGE arena (persistent-workgroup kernels: one slot per workgroup, 10 - 25 MB) is added
+    into the flat buffer right away, on the launching stream, beside whatever the step's other stream runs - left to the
+    reduction in front of the optimizer, its bytes would be read on the step's serial tail (measured: 181 MB = 52 us there
+    for configs/pm_vae_mnist.py).  Small arenas (and every bias) stay for that one launch.  PM_PART_EAGER_MB: threshold."""
+    own, key, nbytes = part._eager
+    if nbytes >= _PART_EAGER_BYTES and key in own.pending:
+        own.reduce(key[0], key[0] + key[1], only=(key,))
+
+
+_PART_EAGER_BYTES = float(os.environ.get("PM_PART_EAGER_MB", "4")) * (1 << 20)
 
 
 def reduce_partials(table, njobs: int, flat_g, nbytes: float = 0.0) -> None:
@@ -505,6 +520,7 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, 
             part = _part_arenas(desc, dw, db, ns.value, db_gathered)
         if part is not None:
             _call("pm_thin_wgrad_part", C.byref(desc), _ptr(gathered), _ptr(dense), C.byref(part), tag=tag, work=work)
+            _part_done(part)
             return True
         _call("pm_thin_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), _ptr(db_gathered),
               tag=tag, work=work)
@@ -527,6 +543,7 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, 
         if part is not None:
             _call("pm_gather_wgrad_part", C.byref(desc), _ptr(gathered), _ptr(dense), None, al, 1, C.byref(part), tag=tag,
                   work=work)
+            _part_done(part)
             return
         _call("pm_gather_wgrad_bf16", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
         return
@@ -543,6 +560,7 @@ def gather_wgrad(desc: GatherDesc, gathered, dense, dw, db, bf16: bool = False, 
         part = _part_arenas(desc, dw, db, ns.value)
     if part is not None:
         _call("pm_gather_wgrad_part", C.byref(desc), _ptr(gathered), _ptr(dense), None, al, 0, C.byref(part), tag=tag, work=work)
+        _part_done(part)
         return
     _call("pm_gather_wgrad", C.byref(desc), _ptr(gathered), _ptr(dense), _ptr(dw), _ptr(db), tag=tag, work=work)
 
@@ -1404,6 +1422,13 @@ def adam_step(p, g, m, v, n_decay, count_dev, cfg: _lib.AdamCfg) -> None:
     passes = 8.0 if cfg.zero_grad else 7.0                      # reads p, g, m, v; writes p, m, v (and zeroes g)
     _call("pm_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), n_decay, _iptr(count_dev), C.byref(cfg),
           tag="adam_kernel<false, true>", work={"bytes": passes * 4.0 * p.numel()})
+
+
+def adam_step_jobs(table, njobs: int, p, g, m, v, n_decay, count_dev, cfg: _lib.AdamCfg, part_bytes: float = 0.0) -> None:
+    """pm_adam_step reading the weight-gradient kernels' partial sums itself (partials.PartialSums.adam_table)"""
+    passes = 8.0 if cfg.zero_grad else 7.0
+    _call("pm_adam_step_jobs", table.data_ptr(), njobs, _ptr(p), _ptr(g), _ptr(m), _ptr(v), n_decay, _iptr(count_dev),
+          C.byref(cfg), tag="adam_jobs_kernel", work={"bytes": passes * 4.0 * p.numel() + part_bytes})
 
 
 def counter_increment(count_dev) -> None:

@@ -119,13 +119,14 @@ class PartialSums:
         self._tables[keys] = (dev, len(jobs))
         return self._tables[keys]
 
-    def reduce(self, lo: int = 0, hi: Optional[int] = None) -> None:
-        """flat_g[i] += sum over slots, for every pending run that touches [lo, hi) (default: all), on the current stream.
-        The caller orders the stream behind the launches that wrote the arenas."""
+    def reduce(self, lo: int = 0, hi: Optional[int] = None, only: Optional[tuple] = None) -> None:
+        """flat_g[i] += sum over slots, for every pending run that touches [lo, hi) (default: all; only: these runs), on the
+        current stream.  The caller orders the stream behind the launches that wrote the arenas."""
         from . import ops
 
         hi = self.flat.numel() if hi is None else hi
-        keys = tuple(sorted(k for k in self.pending if k[0] < hi and lo < k[0] + k[1]))
+        keys = tuple(sorted(k for k in (only if only is not None else self.pending)
+                            if k in self.pending and k[0] < hi and lo < k[0] + k[1]))
         if not keys:
             return
         for k in keys:
@@ -133,6 +134,47 @@ class PartialSums:
         table, njobs = self._table(keys)
         nbytes = sum((self.entries[k][1] + 2) * k[1] * 4.0 for k in keys)
         ops.reduce_partials(table, njobs, self.flat, nbytes)
+
+    def adam_table(self):
+        """Job table of pm_adam_step_jobs: every pending run, plus runs without partial sums for the rest of the flat buffer.
+        Returns (device table, njobs, arena bytes read) and takes the runs off the pending set; None when a run or the buffer
+        is not made of whole 16-byte vectors (PM_NO_PARAM_PAD builds): the caller reduces and runs the plain optimizer."""
+        keys = tuple(sorted(self.pending))
+        n = self.flat.numel()
+        if n % 4 or any(k[0] % 4 or self.entries[k][2] % 4 or self.entries[k][3] % 4 for k in keys):
+            return None
+        cached = self._tables.get(("adam",) + keys)
+        if cached is None:
+            jobs: List[ReduceJob] = []
+
+            def plain(lo, hi):
+                for o in range(lo, hi, 1024):
+                    j = ReduceJob()
+                    j.src, j.stride, j.g_off, j.count, j.nslots = None, 0, o, min(1024, hi - o), 0
+                    jobs.append(j)
+
+            pos, nbytes = 0, 0.0
+            for key in keys:
+                g_off, count = key
+                buf, nslots, stride, src_off = self.entries[key]
+                plain(pos, g_off)
+                per = 256 if nslots >= 8 else 1024
+                base = buf.data_ptr() + 4 * src_off
+                cnt4 = (count + 3) // 4 * 4              # whole vectors: the pad elements are zero in every buffer
+                for o in range(0, cnt4, per):
+                    j = ReduceJob()
+                    j.src, j.stride, j.g_off = base + 4 * o, stride, g_off + o
+                    j.count, j.nslots = min(per, cnt4 - o), nslots
+                    jobs.append(j)
+                pos = g_off + cnt4
+                nbytes += nslots * count * 4.0
+            plain(pos, n)
+            raw = b"".join(bytes(j) for j in jobs)
+            dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat.device)
+            cached = (dev, len(jobs), nbytes)
+            self._tables[("adam",) + keys] = cached
+        self.pending.clear()
+        return cached
 
     def flush_sync(self) -> None:
         """host code is about to read or overwrite the flat gradient buffer (tests, checkpoints): everything in flight ends,
