@@ -114,6 +114,91 @@ def cpu_baseline(cfg, xs, B, budget_s=12.0):
                       "reference itself cannot run here (jax/haiku/tfp absent)"}
 
 
+# BASELINE.json's global batches (configs 2, 4, 5; the rest: the config's per-device batch on one GPU) and per-GPU weak batches
+GLOBAL_BATCH = {"pm_vae_mnist": 256, "pm_vae_gas": 128, "vqvae_mnist": 256, "pm_vqvae_mnist": 256, "pm_vdvae_mnist": 64,
+                "pm_vqvae_celeb_a": 128}
+WEAK_BATCH = {"pm_vae_mnist": 256, "pm_vae_gas": 128, "vqvae_mnist": 256, "pm_vqvae_mnist": 256, "pm_vdvae_mnist": 8,
+              "pm_vqvae_celeb_a": 16}
+
+
+def dist_info(world, dev):
+    """what a reader needs to see that the collective library really ran on `world` ranks: communicator size, backend string and
+    the device every rank sits on (all-gathered through the communicator itself)"""
+    import torch
+    import torch.distributed as dist
+
+    if world <= 1 or not dist.is_initialized():
+        return {"rccl_ranks": 1, "backend": None, "rank_devices": [str(dev)]}
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, f"{dev}:{torch.cuda.get_device_properties(dev).name}")
+    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": ids}
+
+
+def run_workload(args, world, rank, dev, json_fd):
+    """--workload / --scaling other than the headline's defaults: the same contract (W warm-up steps, K timed steps between
+    barrier + synchronize on both sides, MAX over ranks, one JSON line from rank 0) on tools/workloads.build, the step the train
+    script of that config runs.  Data parallel exactly as the headline: per-rank batch, bucketed all-reduce (parallel.GradReducer)."""
+    import torch
+    import torch.distributed as dist
+
+    from tools.workloads import WORKLOADS, build
+
+    name = args.workload
+    if args.scaling == "strong":
+        if GLOBAL_BATCH[name] % world:
+            raise SystemExit(f"global batch {GLOBAL_BATCH[name]} of {name} is not divisible by {world} ranks")
+        B = GLOBAL_BATCH[name] // world
+    else:
+        B = args.batch if args.batch != 256 or name == "pm_vae_mnist" else WEAK_BATCH[name]
+    kw = {"overlap_allreduce": not args.no_overlap} if (world > 1 or os.environ.get("PM_FORCE_DP") == "1") else {}
+    w = build(name, B, device=str(dev), f32=args.f32, world_size=world, rank=rank, **kw)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from posterior_matching_amd.utils import steady_state_gc
+
+    with steady_state_gc():
+        w.feed()
+        for _ in range(args.warmup):
+            w.step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            w.step()
+        fence()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    met = w.ts.read_metrics()
+    info = dist_info(world, dev)
+    red = getattr(w.ts, "reducer", None)
+    if rank == 0:
+        value = world * B * args.steps / dt
+        line = {"metric": f"training images/sec, {name} (configs/{WORKLOADS[name][0]}), full train step",
+                "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+                "vs_baseline": None, "dtype": "f32" if args.f32 else "bf16x3", "data": "synthetic",
+                "config": {"workload": f"configs/{WORKLOADS[name][0]}", "per_gpu_batch": B, "global_batch": B * world,
+                           "parallelism": f"dp{world}", "params": w.params,
+                           "allreduce": None if red is None else ("single" if args.no_overlap else "bucketed_overlapped"),
+                           "bucket_bytes": getattr(red, "bucket_bytes", None),
+                           "gradient_bytes": 4 * w.params, **info},
+                "aux": {"loss": round(float(met["loss"]), 4),
+                        "collectives_per_step": getattr(red, "calls_last_step", None),
+                        "collectives_before_backward_end": getattr(red, "calls_before_finish_last_step", None),
+                        "whole_step_tflops_per_gpu": round(WORKLOADS[name][2] * B / (dt / args.steps) / 1e12, 2)},
+                "roofline": None, "cpu_baseline": None}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +223,11 @@ def main():
                                                                 "other configs, outside the headline's timed region)")
     ap.add_argument("--spread-steps", type=int, default=200, help="extra untimed-for-the-headline steps whose per-step HIP-event "
                                                                   "times give aux.step_ms quartiles (0 = off)")
+    ap.add_argument("--workload", default="pm_vae_mnist", choices=sorted(GLOBAL_BATCH),
+                    help="which BASELINE.json config to time (default: the headline, configs/pm_vae_mnist.py)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: the config's per-GPU batch on every rank; strong: BASELINE.json's fixed GLOBAL batch split over "
+                         "the ranks (pm_vdvae_mnist 64, pm_vqvae_celeb_a 128: per-GPU 8 / 16 at N = 8)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -170,7 +260,8 @@ def main():
     # HBM-side traffic per kernel: two PMC passes over a short run of this same workload, each in a child process
     # BEFORE this process initialises the GPU (counters cannot be read from inside the measured process)
     traffic, traffic_src = None, None
-    if world == 1 and not args.no_pmc and args.profile_steps > 0:
+    headline = args.workload == "pm_vae_mnist" and args.scaling == "weak"
+    if world == 1 and not args.no_pmc and args.profile_steps > 0 and headline:
         traffic = measured_traffic()
         traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes, 2*FETCH_SIZE + WRITE_SIZE per launch"
     if traffic is None and world == 1 and args.profile_steps > 0:
@@ -207,6 +298,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
+
+    if args.workload != "pm_vae_mnist" or args.scaling == "strong":
+        run_workload(args, world, rank, dev, json_fd)
+        return
 
     cfg = load_config_file(os.path.join(ROOT, "configs", "pm_vae_mnist.py")).to_dict()   # the CLI's own config file
     xs, B = data_shape(cfg["data"]["dataset"]), args.batch
@@ -376,6 +471,7 @@ def main():
                 secondary.append({"workload": name, "per_gpu_batch": bsz, "error": repr(exc)[:200]})
             torch.cuda.empty_cache()
 
+    info = dist_info(world, dev)               # a collective: every rank
     if rank == 0:
         value = world * B * args.steps / dt
         per_gpu = value / world
@@ -393,7 +489,7 @@ def main():
                                            "2-channel layers on the VALU in f32") if model.store.use_bf16 else "f32 MFMA",
                        "launch": "hip_graph_1stream" if args.graph else ("eager_1stream" if args.serial else "launch_plan_2streams"),
                        "allreduce": (None if world == 1 else ("single" if args.no_overlap else "bucketed_overlapped")),
-                       "params": model.num_params},
+                       "params": model.num_params, **info},
             "aux": {"elbo": round(metrics["reconstruction_ll"] - metrics["beta"] * metrics["kl"], 4),
                     "matching_ll": round(metrics["matching_ll"], 4), "kl": round(metrics["kl"], 4),
                     "loss": round(metrics["loss"], 4), "step_ms": spread, "f32_images_per_sec": f32_ips,

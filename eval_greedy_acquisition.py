@@ -61,7 +61,7 @@ def main():
     device = torch.device("cuda", 0)
     eval_fn = make_acquisition_eval_fn(lookahead_config, pm_vae_config, args.num_samples, device=device, seed=91)
     eval_fn.model.init(tuple(data.shape[1:]), device)
-    eval_fn.model.load_params(model_state.params)
+    eval_fn.model.load_params(model_state.params, require_trainable=True)     # evaluation: the lookahead networks too
     collect_trajectory = make_collect_trajectory_fn(eval_fn, args.episode_length)
 
     sampling_trajectories, lookahead_trajectories = [], []

@@ -100,6 +100,13 @@ class _PlannedStep:
             s.reduce_partials()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, step_dev, self.adam_cfg)
 
+    def _fresh_grads_before_graph(self, store) -> None:
+        """A captured step was recorded while the gradient buffer was known to be zero (no zero-fill inside the graph): if host
+        code has written gradients since (a direct model.backward(), a test poking store.g), zero it before the replay."""
+        if self.adam_cfg.zero_grad and not store.g_clean:
+            store.zero_grad()
+            store.g_clean = True
+
     def _grads_consumed(self, store) -> None:
         store.g_clean = bool(self.adam_cfg.zero_grad)
 
@@ -124,7 +131,10 @@ def _make_reducer(store, world_size: int, overlap: bool):
 
     total = store.flat_g.numel() * 4
     mb = os.environ.get("PM_BUCKET_MB")                       # A/B knob for measurements
-    bucket = int(float(mb) * (1 << 20)) if mb else max(1 << 20, min(16 << 20, total // 4))
+    # a quarter of the buffer, 1 - 32 MB: PM-VAE (8.4 MB) one bucket behind the encoder backward; PM-VQVAE 140 MB / CelebA 273 MB
+    # 5 - 9 collectives of 32 MB - each far above the size at which a ring over xGMI (7 links x ~153 GB/s per GPU, per-link
+    # bound) stops being latency-bound, few enough that their fixed cost (tens of us each) stays under 1 % of the 8 - 10 ms step
+    bucket = int(float(mb) * (1 << 20)) if mb else max(1 << 20, min(32 << 20, total // 4))
     store.reducer = GradReducer(store, bucket_bytes=bucket, overlap=overlap)
     return store.reducer
 
@@ -264,6 +274,7 @@ class PMVAETrainStep(_PlannedStep):
                     self._forward_backward()
                     self._update()
             return
+        self._fresh_grads_before_graph(self.model.store)
         self._graph_fb.launch()
         if self.world_size > 1:
             self._allreduce()
@@ -347,6 +358,7 @@ class VQVAETrainStep(_PlannedStep):
                 with self._graph:
                     self._sequence()
             else:
+                self._fresh_grads_before_graph(self.model.store)
                 self._graph.launch()
 
     def set_batch(self, x: torch.Tensor) -> None:

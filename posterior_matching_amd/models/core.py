@@ -238,6 +238,18 @@ class ParamStore:
             self.p[name].copy_(t.reshape(self.p[name].shape))
         self.split_all()
 
+    def load_matching(self, values, require_all: bool, what: str = "parameters") -> set:
+        """load_dict of the entries of `values` that name parameters of this store; returns the names it used.
+        require_all: a checkpoint that does not cover the whole store (another prefix, a missing leaf) raises KeyError with
+        the missing names instead of leaving those parameters at their random initial values."""
+        used = {k for k in values if k in self.specs}
+        missing = [n for n in self.specs if n not in used]
+        if require_all and missing:
+            raise KeyError(f"checkpoint lacks {len(missing)} of the {len(self.specs)} {what}: {missing[:8]}"
+                           f"{' ...' if len(missing) > 8 else ''}")
+        self.load_dict({k: values[k] for k in used})
+        return used
+
     def to_dict(self, which: str = "p") -> Dict[str, torch.Tensor]:
         flat = {"p": self.flat_p, "g": self.flat_g, "m": self.flat_m, "v": self.flat_v}[which]
         return OrderedDict((n, flat[o:o + c].view(self.specs[n][0]).detach().clone()) for n, (o, c) in

@@ -222,7 +222,15 @@ class LookaheadPosterior:
         out.update(self.store.to_dict("p"))
         return out
 
-    def load_params(self, values) -> None:
-        self.pm_vae.store.load_dict({k: v for k, v in values.items() if k in self.pm_vae.store.specs})
+    def load_params(self, values, require_trainable: bool = False) -> None:
+        """The frozen PM-VAE must be covered completely (KeyError otherwise: a checkpoint with another prefix would leave it at
+        random values and every number downstream would still look plausible); the lookahead networks may be absent (training
+        starts them from scratch) unless `require_trainable` (evaluation).  Unused checkpoint keys are reported."""
+        import warnings
+
+        used = self.pm_vae.store.load_matching(values, True, "frozen PM-VAE parameters")
         if self.store is not None:
-            self.store.load_dict({k: v for k, v in values.items() if k in self.store.specs})
+            used |= self.store.load_matching(values, require_trainable, "lookahead parameters")
+        extra = [k for k in values if k not in used]
+        if extra:
+            warnings.warn(f"LookaheadPosterior.load_params: {len(extra)} checkpoint entries were not used: {extra[:6]}")

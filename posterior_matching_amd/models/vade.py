@@ -177,8 +177,14 @@ class VADE(Module):
     def grads_dict(self) -> Dict[str, torch.Tensor]:
         return self.store.to_dict("g")
 
-    def load_params(self, values) -> None:
-        self.store.load_dict({k: v for k, v in values.items() if k in self.store.specs})
+    def load_params(self, values, require_all: bool = False) -> None:
+        """require_all: every parameter of the VaDE must be in `values` (KeyError otherwise)"""
+        import warnings
+
+        used = self.store.load_matching(values, require_all, "VaDE parameters")
+        extra = [k for k in values if k not in used]
+        if extra:
+            warnings.warn(f"VADE.load_params: {len(extra)} checkpoint entries were not used: {extra[:6]}")
 
 
 class PosteriorMatchingVADE(VADE):
@@ -276,7 +282,14 @@ class PosteriorMatchingVADE(VADE):
     def partial_params_dict(self) -> Dict[str, torch.Tensor]:
         return self.partial_store.to_dict("p")
 
-    def load_params(self, values) -> None:
-        self.store.load_dict({k: v for k, v in values.items() if k in self.store.specs})
+    def load_params(self, values, require_trainable: bool = False) -> None:
+        """The frozen VaDE must be covered completely (KeyError otherwise); the partial encoder may be absent unless
+        `require_trainable` (evaluation of a trained PM-VaDE).  Unused checkpoint keys are reported."""
+        import warnings
+
+        used = self.store.load_matching(values, True, "frozen VaDE parameters")
         if self.partial_store is not None:
-            self.partial_store.load_dict({k: v for k, v in values.items() if k in self.partial_store.specs})
+            used |= self.partial_store.load_matching(values, require_trainable, "partial-encoder parameters")
+        extra = [k for k in values if k not in used]
+        if extra:
+            warnings.warn(f"PosteriorMatchingVADE.load_params: {len(extra)} checkpoint entries were not used: {extra[:6]}")

@@ -338,6 +338,7 @@ class Trainer:
         if initial_state is not None and isinstance(model, VQVAE):
             model.load_state(strip(initial_state))
         dev = model.store.device
+        self._broadcast_initial_state(model, lf)
         is_vq = isinstance(lf, VQVAELoss)
         is_pmvq = isinstance(lf, PMVQVAELoss)
         if is_vade:
@@ -376,6 +377,30 @@ class Trainer:
         ts.synchronize()
         return self._state(ts)
 
+    def _broadcast_initial_state(self, model, lf) -> None:
+        """Replicas must START identical: only gradients are all-reduced afterwards.  The seeded init is the same on every rank,
+        but `initial_params` may be rank-local (train_vade.py fits its GMM on each rank's own data shard; the reference runs that
+        phase on one device, train_vade.py:88-121), so rank 0's parameters (and haiku state) go to everyone before the first
+        step (bax replicates the train state onto its devices the same way)."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+
+        stores = [model.store] + [getattr(m, "store", None) for m in
+                                  (getattr(lf, "partial_encoder", None), getattr(lf, "pixel_cnn", None))]
+        stores += [getattr(model, n, None) for n in ("partial_store",)]
+        seen = set()
+        for st in stores:
+            if st is None or id(st) in seen or getattr(st, "flat_p", None) is None:
+                continue
+            seen.add(id(st))
+            dist.broadcast(st.flat_p, src=0)
+            st.split_all()
+        vq = getattr(model, "vq", None)
+        if vq is not None and getattr(vq, "state", None):
+            for k in sorted(vq.state):
+                dist.broadcast(vq.state[k], src=0)
+
     def _fit_loop(self, ts, steps, batch, it, key, dev, unmasked, val_dataset, validation_freq, callbacks, log_fn, gcs) -> None:
         for step in range(steps):
             if unmasked:
@@ -399,6 +424,8 @@ class Trainer:
                         log_fn(f"step {step + 1}: " + ", ".join(f"{k}={v:.5g}" for k, v in logs.items()
                                                                  if getattr(v, "ndim", 0) == 0))
                 gcs.collect()                       # the safe point for a cyclic collection
+            elif (step + 1) % 1000 == 0:
+                gcs.collect()                       # runs without validation points (train_vade.py's 70 k pretraining steps)
             batch = next(it)
 
     def _validate(self, ts, val_dataset, key: str, dev, callbacks=()) -> Dict[str, float]:
@@ -408,8 +435,9 @@ class Trainer:
         n = 0
         batches = getattr(val_dataset, "batches", None) or list(val_dataset)
         for i, vb in enumerate(batches):
-            for cb in callbacks or ():
-                cb.on_validation_step(None, None, vb)
+            if self.rank == 0:                      # on_validation_end only runs there (other ranks would collect forever)
+                for cb in callbacks or ():
+                    cb.on_validation_step(None, None, vb)
             if isinstance(ts, (VQVAETrainStep, VADETrainStep)):
                 out = ts.evaluate(vb[key].to(dev))
             elif isinstance(ts, (PMVQVAETrainStep, VDVAETrainStep, PMVADETrainStep, LookaheadTrainStep)):
