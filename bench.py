@@ -88,7 +88,7 @@ def measured_traffic():
     return out
 
 
-def cpu_baseline(cfg, xs, B, budget_s=12.0):
+def cpu_baseline(cfg, xs, B, budget_s=25.0):
     """The oracle's train step (torch CPU, float32) on the host cores: a reported baseline."""
     import torch
 
@@ -101,7 +101,8 @@ def cpu_baseline(cfg, xs, B, budget_s=12.0):
     x = torch.rand((B,) + xs, generator=gen) * (torch.rand((B,) + xs, generator=gen) < 0.19)
     b = (torch.rand((B,) + xs, generator=gen) < 0.5).float()
     eps = torch.randn((B, cfg["model"]["latent_dim"]), generator=gen)
-    O.train_step(p, m, v, cfg, x, b, eps, 0)                       # warm-up
+    O.train_step(p, m, v, cfg, x, b, eps, 0)                       # warm-up (two steps: thread pools, allocator)
+    O.train_step(p, m, v, cfg, x, b, eps, 0)
     n, t0 = 0, time.perf_counter()
     while True:
         O.train_step(p, m, v, cfg, x, b, eps, n + 1)

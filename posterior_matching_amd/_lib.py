@@ -149,6 +149,8 @@ SIGNATURES = {
     "pm_diag_gaussian_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I],
     "pm_bernoulli_ll_fwd": [_P, _P, _P, _P, _I, _I],
     "pm_bernoulli_ll_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "pm_bernoulli_ll_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "pm_tril_sample_kl_bwd2": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "pm_normal_ll_fwd": [_P, _P, _P, _P, _P, _I, _I, _F],
     "pm_normal_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F],
     "pm_vq_select": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
@@ -226,6 +228,7 @@ SIGNATURES = {
     "pm_pmvae_loss": [_P, _P, _P, _P, _I, C.POINTER(LossCfg), _P, _P, _P, _P, _P],
     "pm_adam_step": [_P, _P, _P, _P, _P, _LL, _LL, _P, C.POINTER(AdamCfg)],
     "pm_counter_increment": [_P, _P],
+    "pm_stamp": [_P, _P],
     "pm_normal_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
     "pm_fill_zero": [_P, _P, _LL],
     "pm_axpy1": [_P, _P, _P, _LL],

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void tril_sample_kl_fwd_kernel(const float* __
 __global__ __launch_bounds__(256) void tril_sample_kl_bwd_kernel(const float* __restrict__ params,
                                                                    const float* __restrict__ eps,
                                                                    const float* __restrict__ dz,
+                                                                   const float* __restrict__ dz2,
                                                                    const float* __restrict__ g_kl,
                                                                    float* __restrict__ dparams, int B, int k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(256) void tril_sample_kl_bwd_kernel(const float* __
     float* drow = dparams + (size_t)b * P;
     if (lane < k) {
         es[lane] = eps[(size_t)b * k + lane];
-        dzs[lane] = dz[(size_t)b * k + lane];
+        // dz2 (may be NULL): a second gradient w.r.t. z that the caller would otherwise add with its own launch (the
+        // posterior-matching branch's d matching_ll / dz beside the decoder's, vae.py:136-140)
+        dzs[lane] = dz[(size_t)b * k + lane] + (dz2 ? dz2[(size_t)b * k + lane] : 0.f);
     }
     __syncthreads();
     const float gk = g_kl[b];
@@ -229,6 +232,27 @@ __global__ __launch_bounds__(256) void bernoulli_ll_bwd_kernel(const float* __re
     if (idx >= total) return;
     float l = logits[idx];
     dpre[idx] = g[idx / D] * (x[idx] - pm_sigmoid(l)) * pm_dact(l, act, slope);
+}
+
+// Forward AND backward of the Bernoulli log-likelihood in one pass over the logits: d loss / d ll_b = g[b] is known before the
+// forward pass runs (train_pm_vae.py:62-70: the loss is linear in reconstruction_ll with coefficient -1 / B), so the
+// gradient w.r.t. the decoder's last pre-activation leaves the same kernel that sums ll - the loss kernel and a second
+// pass over logits / x are off the step's dependent chain.
+__global__ __launch_bounds__(256) void bernoulli_ll_fwd_bwd_kernel(const float* __restrict__ logits,
+                                                                     const float* __restrict__ x, const float* __restrict__ g,
+                                                                     float* __restrict__ ll, float* __restrict__ dpre, int D,
+                                                                     int act, float slope) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * D;
+    const float gb = g[blockIdx.x];
+    float s = 0.f;
+    for (int j = threadIdx.x; j < D; j += 256) {
+        const float l = logits[base + j], t = x[base + j];
+        s += t * (-pm_softplus(-l)) + (1.f - t) * (-pm_softplus(l));
+        dpre[base + j] = gb * (t - pm_sigmoid(l)) * pm_dact(l, act, slope);
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) ll[blockIdx.x] = s;
 }
 
 __global__ __launch_bounds__(256) void normal_ll_fwd_kernel(const float* __restrict__ loc, const float* __restrict__ x,
@@ -459,8 +483,17 @@ extern "C" int pm_tril_sample_kl_bwd(pm_stream_t stream, const float* params, co
     if (!params || !eps || !dz || !g_kl || !dparams || B <= 0 || k <= 0 || k > TRIL_MAXK) return PM_EINVAL;
     size_t sh = 4 * (size_t)(2 * k) * sizeof(float);
     hipLaunchKernelGGL(tril_sample_kl_bwd_kernel, dim3((B + 3) / 4), dim3(256), sh, (hipStream_t)stream, params, eps,
-                       dz, g_kl, dparams, B, k);
+                       dz, (const float*)nullptr, g_kl, dparams, B, k);
     return pm_check_launch("pm_tril_sample_kl_bwd");
+}
+
+extern "C" int pm_tril_sample_kl_bwd2(pm_stream_t stream, const float* params, const float* eps, const float* dz,
+                                      const float* dz2, const float* g_kl, float* dparams, int B, int k) {
+    if (!params || !eps || !dz || !g_kl || !dparams || B <= 0 || k <= 0 || k > TRIL_MAXK) return PM_EINVAL;
+    size_t sh = 4 * (size_t)(2 * k) * sizeof(float);
+    hipLaunchKernelGGL(tril_sample_kl_bwd_kernel, dim3((B + 3) / 4), dim3(256), sh, (hipStream_t)stream, params, eps,
+                       dz, dz2, g_kl, dparams, B, k);
+    return pm_check_launch("pm_tril_sample_kl_bwd2");
 }
 
 extern "C" int pm_tril_logprob_fwd(pm_stream_t stream, const float* params, const float* z, float* lp, int B, int k) {
@@ -493,6 +526,14 @@ extern "C" int pm_bernoulli_ll_bwd(pm_stream_t stream, const float* logits, cons
     hipLaunchKernelGGL(bernoulli_ll_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, logits, x, g, dpre, total, D, act, slope);
     return pm_check_launch("pm_bernoulli_ll_bwd");
+}
+
+extern "C" int pm_bernoulli_ll_fwd_bwd(pm_stream_t stream, const float* logits, const float* x, const float* g, float* ll,
+                                       float* dpre, int B, int D, int act, float slope) {
+    if (!logits || !x || !g || !ll || !dpre || B <= 0 || D <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(bernoulli_ll_fwd_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, x, g, ll, dpre, D, act,
+                       slope);
+    return pm_check_launch("pm_bernoulli_ll_fwd_bwd");
 }
 
 extern "C" int pm_normal_ll_fwd(pm_stream_t stream, const float* loc, const float* x, const float* log_scale,

@@ -580,6 +580,18 @@ extern "C" int pm_adam_step_clip_ema(pm_stream_t stream, float* p, float* g, flo
     return pm_check_launch("pm_adam_step_clip_ema");
 }
 
+// Device-side time stamp: dst[0] = the GPU's constant-rate real-time counter (100 MHz) when this one-thread kernel runs.
+// tools/stamp_timeline.py puts one behind every launch of a replayed step: the stream order makes it the end time of the
+// kernel in front of it - a timeline of the CONCURRENT step without a profiler attached (rocprofv3 slows the host's launches
+// enough to change how the two streams interleave).
+__global__ void stamp_kernel(unsigned long long* dst) { dst[0] = wall_clock64(); }
+
+extern "C" int pm_stamp(pm_stream_t stream, unsigned long long* dst) {
+    if (!dst) return PM_EINVAL;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+    return pm_check_launch("pm_stamp");
+}
+
 extern "C" int pm_counter_increment(pm_stream_t stream, int* count_dev) {
     if (!count_dev) return PM_EINVAL;
     hipLaunchKernelGGL(counter_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, count_dev);

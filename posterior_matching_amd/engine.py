@@ -223,19 +223,53 @@ class PMVAETrainStep(_PlannedStep):
         # posterior-matching branch runs its backward pass right behind its forward pass on the side stream (beside the
         # decoder) instead of waiting for the loss (PM_NO_EARLY_PM=1: the round-2 order, for A/B runs)
         early = m.concurrent and not self.use_graph and not os.environ.get("PM_NO_EARLY_PM")
-        if early:
+        # round 4: ALL three upstream gradients are constants of the step (-1 / B, beta(step) / B, -matching_coef / B): with
+        # them on the device up front the Bernoulli head writes d loss / d logits from its forward launch and the loss
+        # kernel (metrics only then) leaves the dependent chain - it runs on the side stream (PM_NO_EARLY_LOSS=1: A/B)
+        early_all = early and not os.environ.get("PM_NO_EARLY_LOSS")
+        if early_all:
+            ops.pmvae_loss_grads(self.B, self.loss_cfg, self.step_dev, self.g_rec, self.g_kl, self.g_mll)
+        elif early:
             ops.pmvae_loss_grads(self.B, self.loss_cfg, self.step_dev, None, None, self.g_mll)
-        out = m(self.x, self.b, is_training=True, eps=self.eps, early_g_mll=self.g_mll if early else None)
-        ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], self.loss_cfg, self.step_dev,
-                       self.metrics, self.g_rec, self.g_kl, None if early else self.g_mll)
+        self._wait_split()              # the bf16 weight copies of the previous update (side stream, see _update)
+        out = m(self.x, self.b, is_training=True, eps=self.eps, early_g_mll=self.g_mll if early else None,
+                early_g_rec=self.g_rec if early_all else None)
+        if early_all:
+            main, side = torch.cuda.current_stream(self.x.device), m._side_stream(self.x.device)
+            ops.wait_stream(side, main)                 # reconstruction_ll and kl are ready behind the main stream's last launch
+            with torch.cuda.stream(side):
+                ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], self.loss_cfg, self.step_dev,
+                               self.metrics, None, None, None)
+        else:
+            ops.pmvae_loss(out["reconstruction_ll"], out["kl"], out["matching_ll"], self.loss_cfg, self.step_dev,
+                           self.metrics, self.g_rec, self.g_kl, None if early else self.g_mll)
         m.backward(self.g_rec, self.g_kl, self.g_mll)
         self._reduce_partials(m.store)
+
+    def _wait_split(self) -> None:
+        ev = getattr(self, "_split_done", None)
+        if ev is not None and self._split_on_side:
+            ops.wait_event(torch.cuda.current_stream(self.x.device), ev)
 
     def _update(self) -> None:
         s = self.model.store
         self._adam_step(s, self.step_dev)
         self._grads_consumed(s)
-        s.split_all()                      # refresh the pre-split bf16 weight copies (one launch)
+        # refresh the pre-split bf16 weight copies (one launch).  Two-stream steps: on the SIDE stream, beside the counter
+        # increment, the next batch's copies and the next step's head kernels - its first consumers (the second layer of each
+        # encoder) wait for `_split_done` (PM_SPLIT_MAIN=1: on the main stream as before, A/B)
+        m = self.model
+        self._split_on_side = bool(m.concurrent and not self.use_graph and not os.environ.get("PM_SPLIT_MAIN"))
+        if self._split_on_side:
+            main, side = torch.cuda.current_stream(self.x.device), m._side_stream(self.x.device)
+            if getattr(self, "_split_done", None) is None:
+                self._split_done = torch.cuda.Event()
+            ops.wait_stream(side, main)
+            with torch.cuda.stream(side):
+                s.split_all()
+                ops.record_event(self._split_done, side)
+        else:
+            s.split_all()
         ops.counter_increment(self.step_dev)
 
     def _allreduce(self) -> None:
@@ -290,9 +324,12 @@ class PMVAETrainStep(_PlannedStep):
 
     def synchronize(self) -> None:
         self.stream.synchronize()
+        side = getattr(self.model, "_side", None)       # the weight copies / the loss metrics may still be on the side stream
+        if side is not None:
+            side.synchronize()
 
     def read_metrics(self) -> Dict[str, float]:
-        self.stream.synchronize()
+        self.synchronize()
         v = self.metrics.cpu().tolist()
         return {"loss": v[0], "reconstruction_ll": v[1], "kl": v[2], "matching_ll": v[3], "beta": v[4]}
 
@@ -301,6 +338,7 @@ class PMVAETrainStep(_PlannedStep):
         m = self.model
         self.stream.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(self.stream):
+            self._wait_split()
             out = m(x, b, is_training=False, eps=eps)
             cfg = LossCfg.from_buffer_copy(self.loss_cfg)
             cfg.grad_scale = 1.0 / x.shape[0]

@@ -25,17 +25,28 @@ class Bernoulli(Module):
     def build(self, store, prefix, feat_shape):
         self.attach(store, prefix)
 
-    def log_prob_sum(self, feat: Feat, x: torch.Tensor) -> torch.Tensor:
+    def log_prob_sum(self, feat: Feat, x: torch.Tensor, early_g: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """early_g [B]: d loss / d ll, already on the device (a train step knows it before the forward pass: -1 / B) - the
+        gradient w.r.t. the decoder's last pre-activation then leaves the same launch and backward() only hands it out."""
         if feat.in_act != ACT_NONE:
             raise NotImplementedError("Bernoulli head expects materialised logits (conv decoder)")
         self._feat, self._x = feat, x
         ll = self.buf("ll", (x.shape[0],))
-        ops.bernoulli_ll_fwd(feat.t, x, ll)
+        self._dpre_done = False
+        if early_g is not None:
+            dpre = self.buf("dpre", feat.t.shape)
+            ops.bernoulli_ll_fwd_bwd(feat.t, x, early_g, ll, dpre, feat.grad_act)
+            self._dpre_done = True
+        else:
+            ops.bernoulli_ll_fwd(feat.t, x, ll)
         return ll
 
     def backward(self, g: torch.Tensor) -> torch.Tensor:
         """returns the gradient w.r.t. the decoder network's last pre-activation."""
         dpre = self.buf("dpre", self._feat.t.shape)
+        if getattr(self, "_dpre_done", False):          # written by log_prob_sum(early_g=...) of this forward pass
+            self._dpre_done = False
+            return dpre
         ops.bernoulli_ll_bwd(self._feat.t, self._x, g, dpre, self._feat.grad_act)
         return dpre
 
@@ -141,9 +152,10 @@ class TriLGaussian(_LinearHead):
         ops.tril_sample_kl_fwd(prm, eps, z, kl)
         return z, kl
 
-    def backward_sample_kl(self, dz: torch.Tensor, g_kl: torch.Tensor) -> torch.Tensor:
+    def backward_sample_kl(self, dz: torch.Tensor, g_kl: torch.Tensor, dz2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dz2: a second gradient w.r.t. z (the posterior-matching branch's), summed inside the kernel"""
         dprm = self.buf("dparams", self._prm.shape)
-        ops.tril_sample_kl_bwd(self._prm, self._eps, dz, g_kl, dprm)
+        ops.tril_sample_kl_bwd(self._prm, self._eps, dz, g_kl, dprm, dz2=dz2)
         return self._linear_bwd(dprm)
 
     # -- partial-posterior use: log_prob(z) (vae.py:134-138)

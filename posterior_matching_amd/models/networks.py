@@ -60,7 +60,11 @@ class ConvEncoder(Module):
         for i in reversed(range(len(self.geoms))):
             g = self.geoms[i]
             inp = self._outs[i - 1] if i > 0 else self._x.t
+            lent = self.ws.wgrad_stream
+            if i in getattr(self, "own_stream_wgrad", ()):     # this layer's weight gradient stays on the data-gradient stream
+                self.ws.wgrad_stream = None
             self.wgrad(g, inp, dpre, self.G(f"conv_{i}/w"), self.G(f"conv_{i}/b"))
+            self.ws.wgrad_stream = lent
             if i > 0:
                 dprev = self.buf(f"dpre_{i - 1}", (B, g.IH, g.IW, g.CI))
                 ops.layer_dgrad(g, dpre, self.P(f"conv_{i}/w"), dprev, aux=inp, aux_act=ACT_LEAKY,

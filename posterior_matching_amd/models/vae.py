@@ -14,7 +14,7 @@ import torch
 from .. import ops
 from ..ops import ACT_NONE
 from .core import Feat, Module, ParamStore, Workspace
-from .distributions import AutoregressiveGMM, DiagonalGaussian, TriLGaussian, get_distribution
+from .distributions import AutoregressiveGMM, Bernoulli, DiagonalGaussian, TriLGaussian, get_distribution
 from .networks import get_network
 
 
@@ -34,6 +34,10 @@ class PosteriorMatchingVAE(Module):
         self._seed = seed
         self.concurrent = True   # run the ELBO and the posterior-matching chains on two HIP streams
         self.lend_wgrad = "enc"  # which weight gradients of the ELBO chain run on the side stream (see backward)
+        # encoder layers whose weight gradient stays on the main stream although "enc" is lent: the first layer's (the LAST of
+        # the backward pass, a thin lane kernel) - with it lent the side queue ends ~45 us behind the main one
+        # (profiles/r04_stamp_timeline_pm_vae.txt); same-box pairs 1.376 / 1.360 vs 1.381 / 1.389 ms
+        self.enc_keep_wgrad = "0"
         self.store: Optional[ParamStore] = None
         if not isinstance(posterior_dist, (TriLGaussian, DiagonalGaussian)):
             raise NotImplementedError("posterior_dist must be TriLGaussian or DiagonalGaussian")
@@ -98,7 +102,8 @@ class PosteriorMatchingVAE(Module):
         return self.store.num_params
 
     def __call__(self, x: torch.Tensor, b: torch.Tensor, is_training: bool = False,
-                 eps: Optional[torch.Tensor] = None, early_g_mll: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                 eps: Optional[torch.Tensor] = None, early_g_mll: Optional[torch.Tensor] = None,
+                 early_g_rec: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """reference vae.py:120-144.  `eps` is the N(0,1) draw behind posterior.sample (required:
         the caller owns the RNG, see trainer.py).  Returns per-example `reconstruction_ll`, `kl`,
         `matching_ll` (device tensors owned by the model, overwritten by the next call).
@@ -107,7 +112,9 @@ class PosteriorMatchingVAE(Module):
         starts (it is -matching_coef / B whatever the forward computes).  The posterior-matching branch then runs its
         BACKWARD pass on the side stream straight behind its forward pass, beside the decoder, instead of waiting for the
         loss; backward() skips that branch.  The gradient buffer must be zero (or hold gradients to accumulate onto) before
-        the call."""
+        the call.
+        early_g_rec [B] (train steps): d loss / d reconstruction_ll, likewise known up front - a Bernoulli decoder head then
+        writes d loss / d logits from the launch that sums the log-likelihood (backward() finds it there)."""
         if self.store is None:
             self.init(x.shape[1:], x.device)
         if eps is None:
@@ -140,7 +147,10 @@ class PosteriorMatchingVAE(Module):
                 self._pm_backward(early_g_mll, side)
                 self._pm_backward_done = True
         dec = self.decoder_net(Feat(z), is_training=is_training)
-        rec = self.decoder_dist.log_prob_sum(dec, x)
+        if early_g_rec is not None and is_training and isinstance(self.decoder_dist, Bernoulli):
+            rec = self.decoder_dist.log_prob_sum(dec, x, early_g=early_g_rec)
+        else:
+            rec = self.decoder_dist.log_prob_sum(dec, x)
         if mll_ready is not None:
             ops.wait_event(main, mll_ready)
         else:
@@ -322,10 +332,18 @@ class PosteriorMatchingVAE(Module):
             self.store.grads_ready(["decoder_net", "decoder_dist"])
         if want_dz:
             ops.wait_event(main, dz_ready)
-            ops.axpy1(dz_pm, dz)
-        denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
+        if want_dz and isinstance(self.posterior_dist, TriLGaussian):
+            denc = self.posterior_dist.backward_sample_kl(dz, g_kl, dz2=dz_pm)       # dz + dz_pm inside the kernel
+        else:
+            if want_dz:
+                ops.axpy1(dz_pm, dz)
+            denc = self.posterior_dist.backward_sample_kl(dz, g_kl)
         if "enc" in parts:      # the encoder's weight gradients, issued when the posterior-matching chain has long finished
             self.ws.wgrad_stream = side
+            # ... except the layers named here (PM_ENC_KEEP, layer indices): tools/stamp_timeline.py shows both queues busy to
+            # the end of the step, the side queue ending ~45 us after the main one with all five lent
+            keep = os.environ.get("PM_ENC_KEEP", self.enc_keep_wgrad)
+            self.encoder_net.own_stream_wgrad = tuple(int(t) for t in str(keep).split(",") if t.strip() != "")
         self.encoder_net.backward(denc, need_input_grad=False)
         self.ws.wgrad_stream = None
         self.ws.join_aux()

@@ -164,20 +164,59 @@ def coverage_end() -> set:
     return out
 
 
+# ---- device-side time stamps behind every launch (tools/stamp_timeline.py) -----------------------------------------------
+_stamps: Optional[dict] = None
+
+
+def stamps_begin(capacity: int = 4096) -> None:
+    """from here on every C-ABI launch is followed, on its stream, by a one-thread kernel that stores the device's real-time
+    counter (pm_stamp) into the next slot of a buffer; a launch plan recorded meanwhile replays the stamps too"""
+    global _stamps
+    _stamps = {"buf": torch.zeros(capacity, dtype=torch.int64, device="cuda"), "names": [], "streams": []}
+    _lib.load().pm_kernel_names_enable(1)
+
+
+def stamps_end():
+    """[(kernel name, stream handle, counter value in 10 ns ticks)] in issue order"""
+    global _stamps
+    st, _stamps = _stamps, None
+    if _timer is None and _coverage is None:
+        _lib.load().pm_kernel_names_enable(0)
+    torch.cuda.synchronize()
+    vals = st["buf"].cpu().tolist()
+    return [(n, s, vals[i]) for i, (n, s) in enumerate(zip(st["names"], st["streams"]))]
+
+
+def _stamp(lib, stream: int, name: str) -> None:
+    i = len(_stamps["names"])
+    if i >= _stamps["buf"].numel():
+        return
+    _stamps["names"].append(name)
+    _stamps["streams"].append(stream)
+    args = (stream, _stamps["buf"].data_ptr() + 8 * i)
+    _lib.check(lib.pm_stamp(*args), "pm_stamp")
+    if _recording is not None:
+        _recording.append((lib.pm_stamp, args, "pm_stamp"))
+
+
 def _call(fname: str, *args, tag: Optional[str] = None, work: Optional[dict] = None) -> None:
     lib = _lib.load()
     fn = getattr(lib, fname)
     if _timer is None:
         full = (_stream(),) + args
-        if _coverage is not None:
+        if _coverage is not None or _stamps is not None:
             lib.pm_clear_kernel_name()
             _lib.check(fn(*full), fname)
             var = lib.pm_last_kernel_variant().decode()
-            _coverage.add((lib.pm_last_kernel_name().decode() or fname) + (f"[{var}]" if var else ""))
+            name = (lib.pm_last_kernel_name().decode() or fname) + (f"[{var}]" if var else "")
+            if _coverage is not None:
+                _coverage.add(name)
         else:
             _lib.check(fn(*full), fname)
         if _recording is not None:
             _recording.append((fn, full, fname))
+        if _stamps is not None:
+            _stamp(lib, full[0], name)
         return
     e0, e1 = Event(), Event()
     lib.pm_clear_kernel_name()
@@ -491,11 +530,13 @@ def _part_done(part) -> None:
     reduction in front of the optimizer, its bytes would be read on the step's serial tail (measured: 181 MB = 52 us there
     for configs/pm_vae_mnist.py).  Small arenas (and every bias) stay for that one launch.  PM_PART_EAGER_MB: threshold."""
     own, key, nbytes = part._eager
-    if nbytes >= _PART_EAGER_BYTES and key in own.pending:
+    if nbytes >= _PART_EAGER_BYTES and key in own.pending and not torch.cuda.is_current_stream_capturing():
         own.reduce(key[0], key[0] + key[1], only=(key,))
 
 
-_PART_EAGER_BYTES = float(os.environ.get("PM_PART_EAGER_MB", "4")) * (1 << 20)
+# measured on configs/pm_vae_mnist.py (profiles/r04_ab_partials_vs_atomics.txt): reducing the 10 - 25 MB arenas behind their
+# launches (12 extra launches) is SLOWER than one reduction in front of / inside the optimizer (1.385 vs 1.365 ms): off by default
+_PART_EAGER_BYTES = float(os.environ.get("PM_PART_EAGER_MB", "1e9")) * (1 << 20)
 
 
 def reduce_partials(table, njobs: int, flat_g, nbytes: float = 0.0) -> None:
@@ -810,8 +851,13 @@ def tril_sample_kl_fwd(params, eps, z, kl) -> None:
     _call("pm_tril_sample_kl_fwd", _ptr(params), _ptr(eps), _ptr(z), _ptr(kl), B, k)
 
 
-def tril_sample_kl_bwd(params, eps, dz, g_kl, dparams) -> None:
+def tril_sample_kl_bwd(params, eps, dz, g_kl, dparams, dz2=None) -> None:
+    """dz2: a second gradient w.r.t. z, added as the rows are loaded (no separate axpy launch)"""
     B, k = eps.shape
+    if dz2 is not None:
+        _call("pm_tril_sample_kl_bwd2", _ptr(params), _ptr(eps), _ptr(dz), _ptr(dz2), _ptr(g_kl), _ptr(dparams), B, k,
+              tag="pm_tril_sample_kl_bwd")
+        return
     _call("pm_tril_sample_kl_bwd", _ptr(params), _ptr(eps), _ptr(dz), _ptr(g_kl), _ptr(dparams), B, k)
 
 
@@ -848,6 +894,12 @@ def diag_gaussian_logprob_bwd(params, z, g, dparams, dz) -> None:
 def bernoulli_ll_fwd(logits, x, ll) -> None:
     B = x.shape[0]
     _call("pm_bernoulli_ll_fwd", _ptr(logits), _ptr(x), _ptr(ll), B, x.numel() // B)
+
+
+def bernoulli_ll_fwd_bwd(logits, x, g, ll, dpre, act, slope=LEAKY_SLOPE) -> None:
+    """ll [B] and d loss / d pre-activation in one pass (g [B] = d loss / d ll, known before the forward pass)"""
+    B = x.shape[0]
+    _call("pm_bernoulli_ll_fwd_bwd", _ptr(logits), _ptr(x), _ptr(g), _ptr(ll), _ptr(dpre), B, x.numel() // B, act, slope)
 
 
 def bernoulli_ll_bwd(logits, x, g, dpre, act, slope=LEAKY_SLOPE) -> None:

@@ -18,7 +18,7 @@ def test_two_ranks_equal_one_process_on_the_full_batch():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "dp_gpu_worker.py")],
                          capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-12000:]
     assert "DP-GPU-OK" in out.stdout
 
 

@@ -236,6 +236,11 @@ def test_tril_sample_kl(B, k):
     dprm = torch.full((B, P), float("nan"), device=d)
     ops.tril_sample_kl_bwd(prd, epd, dz.float().to(d), gk.float().to(d), dprm)
     assert rel_err(dprm, pr.grad) < 2e-6
+    # two gradients w.r.t. z summed on load (the decoder's and the posterior-matching branch's): dz = a + b
+    a = g32((B, k), gen)
+    dprm2 = torch.full((B, P), float("nan"), device=d)
+    ops.tril_sample_kl_bwd(prd, epd, a.float().to(d), gk.float().to(d), dprm2, dz2=(dz.float() - a.float()).to(d))
+    assert rel_err(dprm2, pr.grad) < 2e-6
 
 
 @pytest.mark.parametrize("B,k", [(5, 16), (130, 32)])
@@ -276,6 +281,11 @@ def test_bernoulli_and_normal_ll():
     dpre = torch.empty((B, D), device=d)
     ops.bernoulli_ll_bwd(lg, x.float().to(d), g.float().to(d), dpre, ACT_LEAKY)
     assert rel_err(dpre, pr.grad) < 2e-6
+    # the one-pass form the train step uses (d loss / d ll on the device before the forward pass): same numbers, bit for bit
+    ll2, dpre2 = torch.empty(B, device=d), torch.empty((B, D), device=d)
+    ops.bernoulli_ll_fwd_bwd(lg, x.float().to(d), g.float().to(d), ll2, dpre2, ACT_LEAKY)
+    assert rel_err(ll2, ll) < 2e-6 and rel_err(dpre2, pr.grad) < 2e-6
+    assert torch.equal(ll2, lld) and torch.equal(dpre2, dpre)
 
     loc, ls = g32((B, 8), gen), torch.tensor(0.3, dtype=F64)
     xs = g32((B, 8), gen)
