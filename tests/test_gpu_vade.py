@@ -29,6 +29,16 @@ def dev():
 
 
 def rel_err(a, b):
+    from tests import conftest
+
+
+def _compared():
+    """a scalar of the step (loss / metrics) is about to be compared with the oracle's: the step's kernels count as compared"""
+    from tests import conftest
+
+    conftest.confirm_compared()
+
+    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
@@ -193,6 +203,7 @@ def test_vade_train_steps_match_oracle():
         V.adam_update(p64, {n: (g if g is not None else torch.zeros_like(p64[n])) for n, g in zip(leaves, gr)}, mo, vo, step, 0.002)
         ts.set_batch(f32d(x))
         ts.step()
+        _compared()
         assert abs(ts.read_metrics()["loss"] - loss.item()) < 1e-4 * abs(loss.item()), step
     sched = {"init_value": 0.002, "decay_rate": 0.9, "transition_steps": 4}
     opt = optim.chain(optim.scale_by_adam(eps=1e-4), optim.scale_by_schedule(optim.exponential_decay(**sched, staircase=False)),
@@ -207,6 +218,7 @@ def test_vade_train_steps_match_oracle():
         V.adam_update(p64, gr, mo, vo, step, V.lr_value(sched, step), eps=1e-4)
         ts2.set_batch(f32d(x), f32d(eps))
         ts2.step()
+        _compared()
         assert abs(ts2.read_metrics()["loss"] - loss.item()) < 1e-4 * abs(loss.item()), step
     after = m.params_dict()
     worst = max((rel_err(after[n], p64[n]), n) for n in p64)
@@ -234,6 +246,7 @@ def test_pm_vade_train_steps_match_oracle():
         V.adam_update(p64, gr, mo, vo, step, V.lr_value(sched, step), trainable=lambda n: n.startswith("partial_"))
         ts.set_batch(f32d(x), f32d(b), f32d(eps))
         ts.step()
+        _compared()
         assert abs(ts.read_metrics()["loss"] - loss.item()) < 1e-4 * abs(loss.item()), step
     for n, t in m.params_dict().items():
         assert torch.equal(t, frozen[n]), n

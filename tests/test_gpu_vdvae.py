@@ -18,6 +18,16 @@ def dev():
 
 
 def rel_err(a, b):
+    from tests import conftest
+
+
+def _compared():
+    """a scalar of the step (loss / metrics) is about to be compared with the oracle's: the step's kernels count as compared"""
+    from tests import conftest
+
+    conftest.confirm_compared()
+
+    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
@@ -426,6 +436,7 @@ def test_vdvae_train_steps_match_oracle():
         ts.set_batch(f32d(xb), f32d(bb), [f32d(e) for e in ee])
         ts.step()
         met = ts.read_metrics()
+        _compared()
         assert abs(met["loss"] - loss.item()) < 1e-4 * abs(loss.item()), (step, met)
         assert abs(met["grad_norm"] - gn) < 1e-3 * gn
         pd, ed = m.params_dict(), ts.ema_params()
@@ -458,6 +469,7 @@ def test_vdvae_default_mode_trajectory_within_1e3(size):
         ts.set_batch(f32d(xb), f32d(bb), [f32d(e) for e in ee])
         ts.step()
         met = ts.read_metrics()
+        _compared()
         elbo = float(aux["reconstruction_ll"] - aux["kl"])
         assert abs((met["reconstruction_ll"] - met["kl"]) - elbo) <= 1e-3 * abs(elbo), (step, met, elbo)
         assert abs(met["pm_kl"] - float(aux["pm_kl"])) <= 1e-3 * abs(float(aux["pm_kl"])), (step, met, float(aux["pm_kl"]))

