@@ -242,11 +242,7 @@ struct LoaderV4 {  // C % 4 == 0: one 16-byte load per (row, 4 channels)
             // branch-free: always load (offset c of image 0 when the tap misses), then select.  A
             // conditional load would put an s_waitcnt behind every row and serialise the gather.
             const int o = ok ? rbase[j] + (sy * g.IW + sx) * g.C + c : c;
-#if defined(PM_EXP) && PM_EXP == 1
-            regs[j] = f32x4{1.f, 2.f, 3.f, float(o)};
-#else
             regs[j] = *reinterpret_cast<const f32x4*>(in + o);
-#endif
             okm |= (ok ? 1u : 0u) << j;
         }
         okmask = okm;
@@ -548,11 +544,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
                 f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + r * 32 * LDS_LD + 8 * u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-#if defined(PM_EXP) && PM_EXP == 2
-                    acc[r][e] += a4[e] * b4[e];
-#else
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[r], 0, 0, 0);
-#endif
             }
         }
         __syncthreads();
@@ -679,11 +671,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
     }
     __syncthreads();
     const int sb = (int)(((long long)nsteps_all * ks) / p.ksplit);
-#if defined(PM_EXP) && PM_EXP == 6
-    const int se = sb;
-#else
     const int se = (int)(((long long)nsteps_all * (ks + 1)) / p.ksplit);
-#endif
 
     // bounds-checked view of the gathered tensor: offsets past the end read as zero
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -700,11 +688,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
         const int voff = (int(oky) & int(okx)) ? off : OOB;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-#if defined(PM_EXP) && PM_EXP == 3
-            af[SET][u] = f32x4{1.f, 2.f, float(voff), 4.f};
-#else
             af[SET][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 32 * u, 0));
-#endif
     };
 
     // weight stage loader: Bs[stage][step][n][k] <- w[woff(step) + k*wcs + (n0+n)*wns].  Columns
@@ -733,11 +717,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
         for (int st = 0; st < DGS; ++st) {
             const float* wb = w + kd[s0 + st].woff;   // kd is padded: s0 + st < nsteps_all + DGS
 #pragma unroll
-#if defined(PM_EXP) && PM_EXP == 5
-            for (int j = 0; j < EPS; ++j) breg[st][j] = float(eo[j] + st);
-#else
             for (int j = 0; j < EPS; ++j) breg[st][j] = wb[eo[j]];
-#endif
         }
     };
     auto store_b = [&](float* dst) {
@@ -775,11 +755,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
                 f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + r * 32 * LDS_LD + 8 * u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-#if defined(PM_EXP) && PM_EXP == 4
-                    acc[r][e] += af[SET][u][e] * b4[e];
-#else
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[SET][u][e], b4[e], acc[r], 0, 0, 0);
-#endif
             }
         }
     };
@@ -825,9 +801,6 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
     const float* res = p.res ? p.res + (size_t)grp * p.out_gs : nullptr;
     float* out = p.out + (size_t)grp * p.out_gs;
     int ro[16];
-#if defined(PM_EXP) && PM_EXP == 7
-    if (acc[0][0] != 123.456f) return;
-#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) ro[e] = __shfl(rowoff, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
 #pragma unroll
@@ -987,14 +960,10 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
         const bool okx = coord_ok<DD>(rqx + k.dx, g.d, g.IW, sx);
         const int off = (rbase + (sy * g.IW + sx) * g.C + k.c0) * 4;
         const int voff = (int(oky) & int(okx)) ? off : OOB;
-#if defined(PM_EXP) && PM_EXP == 13
-        for (int u = 0; u < 4; ++u) af[SET][u] = f32x4{1.f, 2.f, float(voff), 4.f};
-#else
         af[SET][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
         af[SET][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16, 0));
         af[SET][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 64, 0));
         af[SET][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 80, 0));
-#endif
     };
 
     // weight stage: per k-step 2*NB rows (hi then lo) of 64 bytes; 16 bytes per thread per piece
@@ -1054,24 +1023,15 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 ah, al;
-#if defined(PM_EXP) && PM_EXP == 15
-            ah = __builtin_bit_cast(bf16x8, af[SET][2 * kk]);
-            al = __builtin_bit_cast(bf16x8, af[SET][2 * kk + 1]);
-#else
             split8(af[SET][2 * kk], af[SET][2 * kk + 1], ah, al);
-#endif
 #pragma unroll
             for (int r = 0; r < RN; ++r) {
                 const __bf16* brow = bstep + (r * 32 + i) * BROW + 16 * kk + 8 * h;
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(brow);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(brow + NB * BROW);
-#if defined(PM_EXP) && PM_EXP == 14
-                acc[r][0] += float(ah[0]) * float(bh[0]) + float(al[1]) * float(bl[1]);
-#else
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r], 0, 0, 0);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r], 0, 0, 0);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r], 0, 0, 0);
-#endif
             }
         }
     };
@@ -1355,7 +1315,6 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
     load_b(1, breg[1]);
     load_b(2, breg[2]);
     // (the first three weight stages are in flight while the patch is staged)
-#if !(defined(PM_EXP) && PM_EXP == 21)
     {   // the patch: f32 -> hi / lo bf16, zero outside the image.  Loads are issued in batches of 8 per thread so
         // that a workgroup pays ~2 global latencies for its patch instead of one per 16 bytes
         const float* img = p.in + (size_t)b * g.IH * g.IW * g.C;
@@ -1388,7 +1347,6 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
             }
         }
     }
-#endif
     __syncthreads();                 // kd table visible
     store_b(Bs, breg[0]);
     __syncthreads();                 // patch + first weight stage visible
@@ -1426,17 +1384,13 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
         constexpr int u = decltype(uc)::value;
         const int s0 = t * PDGS;
         const __bf16* bcur = Bs + (u & 1) * BTILE;
-#if !(defined(PM_EXP) && PM_EXP == 24)
         load_b(t + 3, breg[(u + 3) & 3]);                   // consumed three stages from now
-#endif
         read_a(s0 + 1, 1);
         mma(bcur, 0);
         read_a(s0 + 2, 0);                                  // first step of the next stage (a padding entry after the last)
         if (s0 + 1 < nsteps) mma(bcur + STEP_E, 1);
-#if !(defined(PM_EXP) && PM_EXP == 24)
         store_b(Bs + ((u + 1) & 1) * BTILE, breg[(u + 1) & 3]);       // stage t+1, loaded two stages ago
         __syncthreads();
-#endif
     };
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
@@ -1445,9 +1399,6 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
     // full groups of NSET stages without exits (an early exit inside the group lands in the loop latch, whose merged
     // wait-count state drains vmcnt at the top of every trip), then the 0 - 3 remaining stages as straight-line code
     int t0 = 0;
-#if defined(PM_EXP) && PM_EXP == 22
-    t0 = nstages;
-#endif
     for (; t0 + NSET <= nstages; t0 += NSET) {
         stage(t0, U0{});
         stage(t0 + 1, U1{});
@@ -1474,9 +1425,6 @@ __global__ __launch_bounds__(256) void patch_conv_bf16_kernel(GemmArgs p, const 
         int n = n0 + r * 32 + i;
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
-#if defined(PM_EXP) && PM_EXP == 23
-        if (acc[r][0] == 12345.f)
-#endif
         pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
     }
 }
@@ -1745,7 +1693,6 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         reinterpret_cast<unsigned*>(Ph + zoff)[tid] = 0u;
         reinterpret_cast<unsigned*>(Pl + zoff)[tid] = 0u;
     }
-#if !(defined(PM_EXP) && PM_EXP == 31)
     {   // the image: f32 -> in_act -> hi / lo bf16; a linear read, up to 13 float4 per thread in flight
         const float* img = p.in + (size_t)b * npos * g.C;
         const int c4n = g.C >> 2;
@@ -1792,7 +1739,6 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
 #endif
     }
 
-#endif
     // per row tile: this lane's A row = output position m -> top-left input coordinate of its receptive field
     int py[T], px[T];
 #pragma unroll
@@ -1888,9 +1834,6 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
         read_a(t0, 0, a[0]);                                            // items 0 and 1
         read_a(T == 1 ? t1 : t0, T == 1 ? 0 : 1, a[1]);
         int s0 = 0;
-#if defined(PM_EXP) && PM_EXP == 32
-        s0 = nsteps;
-#endif
         for (; s0 + NSET <= nsteps; s0 += NSET) {                       // exit-free groups, then 0 - 3 steps straight-line
             step(s0, U0{});
             step(s0 + 1, U1{});
@@ -1904,9 +1847,6 @@ __global__ __launch_bounds__(64 * NW, 2) void image_conv_bf16_kernel(GemmArgs p,
                 if (s0 + 2 < nsteps) step(s0 + 2, U2{});
             }
         }
-#if defined(PM_EXP) && PM_EXP == 33
-        if (acc[0][0] == 12345.f)
-#endif
         if (TR) {
 #pragma unroll
             for (int j = 0; j < T; ++j) {
