@@ -411,3 +411,54 @@ def test_ctypes_signatures_match_the_header():
         assert got == want, f"{name}: header {[t.__name__ for t in want]} vs _lib {[t.__name__ for t in got]}"
         checked += 1
     assert checked == len(protos)
+
+
+def test_planners_and_argument_checks_without_a_gpu():
+    """The host side of the C ABI that needs no device: launch planning (which kernel form, how many m-splits / partial-sum
+    slots) and the argument validation in front of every launch.  `make -C posterior_matching_amd/csrc asan` runs this file
+    against a host-only AddressSanitizer + UBSan build of the same sources (race / memory checking of the
+    native code happens on the CPU build; GPU sanitizers are not available on the pool)."""
+    import ctypes as C
+
+    from posterior_matching_amd import _lib
+    from posterior_matching_amd.ops import LayerGeom
+
+    lib = _lib.load()
+    aligned = C.c_void_p(1 << 20)                                  # never dereferenced: planning only looks at alignment
+    seen = set()
+    for geom, B, mode in [(LayerGeom.conv(28, 28, 32, 32, 5, 2, "SAME"), 256, "wgrad"),
+                          (LayerGeom.conv(14, 14, 32, 64, 5, 1, "SAME"), 256, "wgrad"),
+                          (LayerGeom.conv_t(28, 28, 32, 32, 5, 1, "SAME"), 256, "dgrad"),
+                          (LayerGeom.conv(14, 14, 64, 64, 5, 2, "SAME"), 256, "wgrad"),
+                          (LayerGeom.dense(256, 256), 8192, "wgrad"),
+                          (LayerGeom.masked_conv(7, 7, 256, 256, 3, 3, 2, 3), 256, "wgrad"),
+                          (LayerGeom.conv(28, 28, 48, 48, 3, 1, "SAME"), 16, "wgrad")]:
+        d = geom._desc(B, mode)
+        n = C.c_int(-1)
+        assert lib.pm_wgrad_part_slots(C.byref(d), aligned, aligned, 0, 1, 1, C.byref(n)) == 0, geom
+        assert 1 <= n.value <= 1024
+        seen.add(n.value)
+        v = [C.c_int() for _ in range(5)]
+        assert lib.pm_query_wgrad_plan(C.byref(d), 1, 1, *[C.byref(x) for x in v]) == 0
+        assert v[4].value >= 1
+        bm, bn, md = C.c_int(), C.c_int(), C.c_int()
+        assert lib.pm_query_gemm_plan(C.byref(geom._desc(B, "fwd")), 1, C.byref(bm), C.byref(bn), C.byref(md)) == 0
+        assert bm.value in (32, 64, 128) and bn.value in (32, 64, 128)
+    assert len(seen) > 1                                            # persistent forms (one slot per workgroup) and m-splits
+    n = C.c_int()
+    assert lib.pm_colsum_part_slots(256 * 784, 32, C.byref(n)) == 0 and n.value >= 1
+    assert lib.pm_colsum_part_slots(100, 30, C.byref(n)) != 0       # 1024 % N != 0: the atomics form keeps these
+    d = LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME")._desc(256, "wgrad")
+    assert lib.pm_thin_wgrad_part_slots(C.byref(d), aligned, aligned, C.byref(n)) == 0 and n.value == 256
+    # argument validation returns before anything is launched (no device needed): NULL operands, bad shapes, bad tables
+    d = LayerGeom.dense(256, 256)._desc(64, "wgrad")
+    part = _lib.WgradPart()
+    assert lib.pm_gather_wgrad_part(None, C.byref(d), None, aligned, None, 1, 1, C.byref(part)) != 0
+    assert lib.pm_gather_wgrad_part(None, C.byref(d), aligned, aligned, None, 1, 1, None) != 0
+    assert lib.pm_reduce_partials(None, None, 4, aligned) != 0
+    assert lib.pm_adam_step_jobs(None, aligned, 0, aligned, aligned, aligned, aligned, 0, aligned, None) != 0
+    assert lib.pm_colsum_part(None, aligned, 1024, 32, aligned, 8, 3) != 0          # stride < N
+    bad = LayerGeom.dense(256, 256)._desc(64, "wgrad")
+    bad.C = 0
+    assert lib.pm_wgrad_part_slots(C.byref(bad), aligned, aligned, 0, 1, 1, C.byref(n)) != 0
+    assert lib.pm_gather_gemm_bf16(None, C.byref(bad), aligned, aligned, None, None, None, aligned) != 0
