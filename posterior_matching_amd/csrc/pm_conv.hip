@@ -3055,8 +3055,17 @@ __global__ __launch_bounds__(256) void gather_wgrad_bf16_sub_kernel(WgradArgs p)
     const int wc = wave >> 1, wn = wave & 1;      // this wave's 32 x 32 block of the 64 x 64 tile
     const int i = lane & 31;
     const int h = lane >> 5;
-    const int tile = blockIdx.x % p.ntiles;
-    const int split = blockIdx.x / p.ntiles;
+    // all tiles of an m-split read the same rows of both operands: keep them on one XCD when the splits divide evenly over
+    // the eight (blocks b and b + 8 share an XCD's L2 under round-robin placement - speed only, see gather_wgrad_bf16_kernel)
+    int tile, split;
+    if (p.xcd_map) {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        tile = r % p.ntiles;
+        split = xcd + 8 * (r / p.ntiles);
+    } else {
+        tile = blockIdx.x % p.ntiles;
+        split = blockIdx.x / p.ntiles;
+    }
     // cpad (32 < C < 64, the 48-channel layers of the VDVAE): a k-block is one tap with its C channels zero-padded to 64 -
     // 56 % of the MFMA work is real, on a pipe 16x faster than the f32 form these shapes ran on before
     const bool cpad = p.cpad != 0;
@@ -3579,6 +3588,174 @@ __global__ __launch_bounds__(256) void image_wgrad_bf16_kernel(WgradArgs p, int 
             if (n < g.N) wg_put(part, wg_db(p, b_first) + n, accb[b2][0]);
         }
     }
+}
+
+// ----------------------- weight gradients of 64-channel layers on SMALL grids, one TAP ROW per workgroup class (bf16x3) ------
+// The 14x14x64 <-> 7x7x64 stride-2 5x5 layers of the PM-VAE (three launches per step) ran on gather_wgrad_bf16_sub_kernel: every
+// (tap, 64 channels) k-block is a workgroup column of its own that re-gathers its input rows and re-reads the dense rows - 25 taps
+// x 24 m-splits = 600 workgroups, 160 MB through L2 for 16 MB of operands, 35 us (58 algorithmic TFLOP/s).  image_wgrad_bf16 cannot
+// take them: the weights (25 x 64 x 64 floats = 410 KB) are 6 x the operands of a sample, so accumulating all taps per workgroup
+// makes the flush, not the MFMAs, the kernel.  Here a workgroup class owns ONE ROW of taps (ky: KW taps x 64 x 64 = 80 KB of
+// accumulators, 16 x KW registers per lane: wave w owns the 32 x 32 block (w >> 1, w & 1) of every tap) and walks whole samples:
+// the OH input rows that tap row meets (y = oy * a + off + ky * cs) and the dense image are staged once per sample as hi / lo bf16
+// planes (47 KB of LDS: two workgroups per CU), a k16 step is TWO output rows of up to 8 positions (dense pads are zero in LDS, a
+// gathered position outside the image reads the zero pixel), every operand a transposed LDS read.  Slots of the partial-sum arena =
+// sample groups.  Needs d = 1, C = N = 64, OW <= 8, OH <= 8, IW <= 16.
+template <int KW>
+__global__ __launch_bounds__(256, 2) void rowtap_wgrad_bf16_kernel(WgradArgs p, int ngroups) {
+    constexpr int PS = 72, DS = 72;                // bf16 per pixel / dense position: 64 + 16 B pad
+    constexpr int NPI = 8, NPD = 4;                // 16-byte pieces per thread: gathered rows (<= 8 x 16 x 16), dense image (<= 64 x 16)
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave >> 1, nb = wave & 1;       // this wave's 32 x 32 block of every tap's 64 x 64 tile
+    const int i = lane & 31, h = lane >> 5;
+    const int ky = blockIdx.x % g.KH, grp = blockIdx.x / g.KH;
+    const int npix = g.OH * g.IW;                  // staged gathered pixels: OH rows of IW
+    short* Ph = reinterpret_cast<short*>(dsm);
+    short* Pl = Ph + (npix + 1) * PS;
+    short* Dh = Pl + (npix + 1) * PS;
+    short* Dl = Dh + 64 * DS;
+
+    // zero pixel + dense pads: written once (the dense buffer is [8][8] positions; staging only touches real ones)
+    for (int e = tid; e < 64 * DS / 2; e += 256) {
+        reinterpret_cast<unsigned*>(Dh)[e] = 0u;
+        reinterpret_cast<unsigned*>(Dl)[e] = 0u;
+    }
+    if (tid < PS / 2) {
+        reinterpret_cast<unsigned*>(Ph + npix * PS)[tid] = 0u;
+        reinterpret_cast<unsigned*>(Pl + npix * PS)[tid] = 0u;
+    }
+
+    const int gq = lane >> 4;                      // transposed-read lane geometry (see gather_wgrad_bf16_kernel)
+    const int q = (lane & 15) >> 2;
+    const int pq = lane & 3;
+    const int half = gq >> 1;                      // which of the step's two output rows this lane's positions sit in
+    const int tr_col = 16 * (gq & 1) + 4 * pq;
+    const int oxa = q, oxb = q + 4;                // this lane's two positions of the row: columns q and q + 4
+    int xoa[KW], xob[KW];
+    bool oka[KW], okb[KW];
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+        const int xa = oxa * g.a + g.offx + kx * g.cs, xb = oxb * g.a + g.offx + kx * g.cs;
+        oka[kx] = kx < g.KW && oxa < g.OW && (unsigned)xa < (unsigned)g.IW;
+        okb[kx] = kx < g.KW && oxb < g.OW && (unsigned)xb < (unsigned)g.IW;
+        xoa[kx] = xa * PS + tr_col + 32 * cb;
+        xob[kx] = xb * PS + tr_col + 32 * cb;
+    }
+    const int zpix = npix * PS + tr_col + 32 * cb;
+    // which staged rows exist in the image: row r holds input row r * a + off + ky * cs
+    unsigned rowmask = 0u;
+    for (int r = 0; r < g.OH; ++r) rowmask |= ((unsigned)(r * g.a + g.off + ky * g.cs) < (unsigned)g.IH ? 1u : 0u) << r;
+
+    f32x16 acc[KW], accb;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[kx][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const bool do_bias = p.db != nullptr && ky == 0 && cb == 0;       // wave-uniform
+
+    const int np4 = npix * 16, nd4 = g.OH * g.OW * 16;
+    f32x4 pv[NPI], dv[NPD];
+    auto issue = [&](int b) {
+        const float* img = p.gathered + (size_t)b * g.IH * g.IW * 64;
+        const float* dimg = p.dense + (size_t)b * g.OH * g.OW * 64;
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) {
+            const int e = tid + 256 * j;
+            const int ee = e < np4 ? e : 0;
+            const int pos = ee >> 4, c4 = ee & 15;
+            const int r = pos / g.IW, col = pos - r * g.IW;
+            const int y = r * g.a + g.off + ky * g.cs;
+            const bool ok = e < np4 && (unsigned)y < (unsigned)g.IH;
+            pv[j] = *reinterpret_cast<const f32x4*>(img + (ok ? ((size_t)y * g.IW + col) * 64 + 4 * c4 : 0));
+            if (!ok) pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NPD; ++j) {
+            const int e = tid + 256 * j;
+            dv[j] = *reinterpret_cast<const f32x4*>(dimg + 4 * (size_t)(e < nd4 ? e : 0));
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) {
+            const int e = tid + 256 * j;
+            if (e < np4) {
+                u32x2 h2, l2;
+                split4(pv[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Ph + (e >> 4) * PS + 4 * (e & 15)) = h2;
+                *reinterpret_cast<u32x2*>(Pl + (e >> 4) * PS + 4 * (e & 15)) = l2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPD; ++j) {
+            const int e = tid + 256 * j;
+            if (e < nd4) {
+                const int pos = e >> 4, c4 = e & 15;
+                const int oy = pos / g.OW, ox = pos - oy * g.OW;
+                u32x2 h2, l2;
+                split4(dv[j], h2, l2);
+                *reinterpret_cast<u32x2*>(Dh + (oy * 8 + ox) * DS + 4 * c4) = h2;
+                *reinterpret_cast<u32x2*>(Dl + (oy * 8 + ox) * DS + 4 * c4) = l2;
+            }
+        }
+    };
+    const int nsteps = (g.OH + 1) >> 1;
+    const int dcol = tr_col + 32 * nb;
+    if (grp < g.B) issue(grp);
+    __syncthreads();                                                   // the zero fills above
+    for (int b = grp; b < g.B; b += ngroups) {
+        stage();
+        __syncthreads();
+        issue(b + ngroups < g.B ? b + ngroups : b);                    // next sample's loads fly during the MFMAs
+        for (int st = 0; st < nsteps; ++st) {
+            const int oy = 2 * st + half;                              // <= 7: inside the [8][8] dense buffer
+            const bool rv = (rowmask >> oy) & 1u;
+            const int da = (oy * 8 + oxa) * DS + dcol, db2 = (oy * 8 + oxb) * DS + dcol;
+            const bf16x8 bh = tr_frag2(Dh + da, Dh + db2);
+            const bf16x8 bl = tr_frag2(Dl + da, Dl + db2);
+            const int rbase = oy * g.IW * PS;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int o0 = (rv && oka[kx]) ? rbase + xoa[kx] : zpix;
+                const int o1 = (rv && okb[kx]) ? rbase + xob[kx] : zpix;
+                const bf16x8 ah = tr_frag2(Ph + o0, Ph + o1);
+                const bf16x8 al = tr_frag2(Pl + o0, Pl + o1);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[kx], 0, 0, 0);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[kx], 0, 0, 0);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[kx], 0, 0, 0);
+            }
+            if (do_bias) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bh, accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bl, accb, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // flush: C/D layout row (= channel) = (e&3) + 8*(e>>2) + 4*h, column (= n) = lane & 31; slot = sample group
+    const bool part = p.part_w != nullptr;
+    float* dwp = wg_dw(p, grp);
+    const int n = 32 * nb + i;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+        if (kx >= g.KW) continue;
+        const int wtap = ky * g.kws + kx;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = 32 * cb + (e & 3) + 8 * (e >> 2) + 4 * h;
+            wg_put(part, dwp + (size_t)wtap * g.wts + (size_t)c * g.wcs + (size_t)n * g.wns, acc[kx][e]);
+        }
+    }
+    if (do_bias && h == 0) wg_put(part, wg_db(p, grp) + n, accb[0]);
 }
 
 bool fill_geom(const pm_gather_desc* d, Geom& g, bool class_major) {

@@ -31,16 +31,16 @@ def dev():
 def rel_err(a, b):
     from tests import conftest
 
+    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
 
 def _compared():
     """a scalar of the step (loss / metrics) is about to be compared with the oracle's: the step's kernels count as compared"""
     from tests import conftest
 
     conftest.confirm_compared()
-
-    conftest.confirm_compared()          # the kernels launched so far in this test have a compared result
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
 def f32d(t):
