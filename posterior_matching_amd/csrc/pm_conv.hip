@@ -4483,6 +4483,30 @@ static int gather_wgrad_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, c
             }
         }
     }
+    {   // 64 x 64-channel layers on grids <= 8 wide (the PM-VAE's 14x14 <-> 7x7 stride-2 layers): one tap row per class
+        static const bool rt_off = getenv("PM_NO_ROWTAP_WGRAD") != nullptr;          // A/B switch for measurements
+        const Geom& g = a.g;
+        if (!rt_off && !gtab && d->groups == 1 && g.d == 1 && g.C == 64 && g.N == 64 && g.in_act == PM_ACT_NONE &&
+            g.KW == 5 && g.KH >= 1 && g.KH <= 8 && g.OW >= 4 && g.OW <= 8 && g.OH >= 2 && g.OH <= 8 && g.IW <= 16 &&
+            g.IH <= 16 && g.B >= 32) {
+            // sample groups = slots of the partial-sum arena (each 410 KB for a 5x5 kernel): 48 groups x 5 tap rows = 240
+            // workgroups of ~5 samples each (PM_RT_GROUPS for experiments)
+            static const int grp_env = getenv("PM_RT_GROUPS") ? atoi(getenv("PM_RT_GROUPS")) : 48;
+            int ngroups = grp_env > 0 ? grp_env : 48;
+            if (ngroups > g.B) ngroups = g.B;
+            PM_PART_SLOTS(ngroups);
+            const size_t lds = ((size_t)(g.OH * g.IW + 1) * 72 + (size_t)64 * 72) * 2 * sizeof(short);
+            static bool attr_rt = false;
+            if (!attr_rt) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtap_wgrad_bf16_kernel<5>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                attr_rt = true;
+            }
+            PM_KTAG("rowtap_wgrad_bf16_kernel<5>");
+            hipLaunchKernelGGL((rowtap_wgrad_bf16_kernel<5>), dim3(ngroups * g.KH), dim3(256), lds, (hipStream_t)stream, a, ngroups);
+            return pm_check_launch("pm_gather_wgrad_bf16(rowtap)");
+        }
+    }
     a.cpad = cpad ? 1 : 0;
     {
         const int rc_big = launch_big_wgrad(stream, a, d, cpad, part, slots_out);

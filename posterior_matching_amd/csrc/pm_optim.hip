@@ -327,6 +327,28 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
+    if (!(N % 4 == 0 && 1024 % N == 0)) {
+        // any other width: 256 / N row lanes (one for N > 256) of N column threads each, every thread a fixed subset of the
+        // rows; the row lanes meet in LDS in lane order
+        float* red = reinterpret_cast<float*>(accs);          // 1024 floats
+        const int lanes = N <= 256 ? 256 / N : 1;
+        for (int n0 = 0; n0 < N; n0 += 256) {                 // column passes (one unless N > 256)
+            const int n = n0 + (N <= 256 ? (int)threadIdx.x % N : (int)threadIdx.x);
+            const int rl = N <= 256 ? (int)threadIdx.x / N : 0;
+            float sacc = 0.f;
+            if (rl < lanes && n < N)
+                for (long long r = r0 + rl; r < r1; r += lanes) sacc += x[r * N + n];
+            __syncthreads();
+            if (rl < lanes && n < N) red[rl * (N <= 256 ? N : 256) + (n - n0)] = sacc;
+            __syncthreads();
+            if (rl == 0 && n < N) {
+                float t = 0.f;
+                for (int l = 0; l < lanes; ++l) t += red[l * (N <= 256 ? N : 256) + (n - n0)];
+                part[(size_t)blockIdx.x * part_stride + n] = t;
+            }
+        }
+        return;
+    }
     const long long e0 = r0 * N, e1 = r1 * N;                 // rows_per_block * N % 1024 == 0: e0 % 4 == 0
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
@@ -675,8 +697,7 @@ static int colsum_rows(long long M, int N) {         // rows per workgroup: ~256
 }
 
 extern "C" int pm_colsum_part_slots(long long M, int N, int* nslots) {
-    if (!nslots || M <= 0 || N <= 0) return PM_EINVAL;
-    if (N % 4 != 0 || 1024 % N != 0) return PM_EINVAL;          // other widths keep pm_colsum (atomics)
+    if (!nslots || M <= 0 || N <= 0 || N > 8192) return PM_EINVAL;
     const int rows = colsum_rows(M, N);
     *nslots = (int)((M + rows - 1) / rows);
     return PM_OK;
@@ -686,7 +707,7 @@ extern "C" int pm_colsum_part(pm_stream_t stream, const float* x, long long M, i
                               int nslots) {
     int need = 0;
     if (!x || !part || part_stride < N || pm_colsum_part_slots(M, N, &need) != PM_OK || need != nslots) return PM_EINVAL;
-    if (reinterpret_cast<size_t>(x) & 15) return PM_EINVAL;
+    if ((reinterpret_cast<size_t>(x) & 15) && N % 4 == 0 && 1024 % N == 0) return PM_EINVAL;     // the vector form's loads
     PM_KTAG("colsum_part_kernel");
     hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)need), dim3(256), 0, (hipStream_t)stream, x, part, part_stride, M, N,
                        colsum_rows(M, N));

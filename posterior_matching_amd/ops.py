@@ -1516,7 +1516,8 @@ def colsum(x, out) -> None:
     M = x.numel() // N
     own = partials.owner_of(out)
     ns = C.c_int()
-    if (own is not None and x.data_ptr() % 16 == 0 and out.numel() == N
+    vec = N % 4 == 0 and 1024 % N == 0
+    if (own is not None and (x.data_ptr() % 16 == 0 or not vec) and out.numel() == N
             and _lib.load().pm_colsum_part_slots(M, N, C.byref(ns)) == 0):
         buf, off = own.arena(own.offset(out), N, ns.value)
         stride = own.entries[(own.offset(out), N)][2]

@@ -88,6 +88,11 @@ CONV_CASES = [
     # plain-rows weight gradients with >= 1024 rows (the ResidualMLP hidden layers of a B = 256 step), ragged rows / columns
     ("dense", 8192, 1, 256, 256, 1, 1, "VALID"), ("dense", 2100, 1, 192, 256, 1, 1, "VALID"),
     ("dense", 1030, 1, 128, 132, 1, 1, "VALID"), ("dense", 1500, 1, 320, 200, 1, 1, "VALID"),
+    # 64-channel layers on grids <= 8 wide at batches >= 32: weight gradients with one tap ROW per workgroup class
+    # (rowtap_wgrad_bf16): stride 2 and 1, odd input sizes (7 / 8 output rows: a half-empty last k16 step or none), the
+    # role-swapped transposed form (flipped taps, gathered = dy), the largest sizes it takes (16 x 16 gathered, 8 x 8 dense)
+    ("conv", 64, 14, 64, 64, 5, 2, "SAME"), ("conv", 33, 13, 64, 64, 5, 2, "SAME"), ("conv", 48, 8, 64, 64, 5, 1, "SAME"),
+    ("convT", 40, 8, 64, 64, 5, 2, "SAME"), ("conv", 32, 16, 64, 64, 5, 2, "SAME"),
 ]
 
 
@@ -132,6 +137,7 @@ def test_layer_fwd_dgrad_wgrad(kind, B, H, ci, co, k, s, padding):
     from posterior_matching_amd.models.core import ParamStore
     st = ParamStore()
     st.add("w", geom.weight_shape, fan_in=1)
+    st.add("b", (co,))
     hf, hd = st.request_split("w", geom, "fwd"), st.request_split("w", geom, "dgrad")
     st.allocate(d)
     st.load_dict({"w": w})
@@ -168,6 +174,18 @@ def test_layer_fwd_dgrad_wgrad(kind, B, H, ci, co, k, s, padding):
     ops.layer_wgrad(geom, xd, dpre, dwd, dbd, bf16=True)           # bf16x3 where the shape qualifies
     assert rel_err(dwd, wr.grad) < 3e-5
     assert (dbd.cpu().double() - br.grad).abs().max().item() < 3e-5 * db_scale
+    # the same launches with gradients that live in a ParamStore: every kernel form leaves per-split PARTIAL SUMS (plain
+    # stores into the store's arenas), added in a fixed order when the gradients are read - twice the same bits, both modes
+    for use_bf16 in (False, True):
+        runs = []
+        for _ in range(2):
+            st.zero_grad()
+            ops.layer_wgrad(geom, xd, dpre, st.g["w"], st.g["b"], bf16=use_bf16)
+            gd = st.to_dict("g")
+            runs.append((gd["w"].clone(), gd["b"].clone()))
+        assert rel_err(runs[0][0], wr.grad) < (3e-5 if use_bf16 else 2e-6)
+        assert (runs[0][1].cpu().double() - br.grad).abs().max().item() < (3e-5 if use_bf16 else 2e-6) * db_scale
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
 
 
 def test_epilogue_aux_res_inact():

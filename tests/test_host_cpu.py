@@ -447,7 +447,8 @@ def test_planners_and_argument_checks_without_a_gpu():
     assert len(seen) > 1                                            # persistent forms (one slot per workgroup) and m-splits
     n = C.c_int()
     assert lib.pm_colsum_part_slots(256 * 784, 32, C.byref(n)) == 0 and n.value >= 1
-    assert lib.pm_colsum_part_slots(100, 30, C.byref(n)) != 0       # 1024 % N != 0: the atomics form keeps these
+    assert lib.pm_colsum_part_slots(100, 30, C.byref(n)) == 0 and n.value == 1     # any width (column-per-thread form)
+    assert lib.pm_colsum_part_slots(100, 0, C.byref(n)) != 0
     d = LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME")._desc(256, "wgrad")
     assert lib.pm_thin_wgrad_part_slots(C.byref(d), aligned, aligned, C.byref(n)) == 0 and n.value == 256
     # argument validation returns before anything is launched (no device needed): NULL operands, bad shapes, bad tables
