@@ -7,17 +7,21 @@ Bernoulli masks), identical seeds, data order and reparameterisation noise for e
 
   * the HIP bf16x3 run (the benchmarked arithmetic, launch-plan replay on two streams),
   * the HIP strict-f32 run (every GEMM on the f32 MFMA: the reference's own arithmetic),
-  * two more strict-f32 runs that differ ONLY in the noise seed (the run-to-run spread a different eps stream gives),
+  * four more strict-f32 runs: two that differ ONLY in the noise seed, two whose initial parameters are multiplied by
+    (1 + 1e-6 N(0, 1)) - a change at float32 rounding level, which is what swapping one arithmetic for another amounts to,
   * the float32 (and float64) torch-CPU oracle for the first 10 steps (300 oracle steps would take ~5 minutes of host time).
 
 Asserted: (1) steps 0-9: ELBO / KL / matching-LL of both HIP runs within 1e-3 relative of the oracle's float32 trajectory
 (x3 the float32-vs-float64 oracle drift where that is larger - the yardstick of test_train_steps_match_oracle);
 (2) the mean of the LAST 20 validation ELBO and matching-LL values (a held-out batch with fixed noise, evaluated every 5 steps
-over steps 200-299) of the bf16x3 run within max(1e-3 relative, the spread of the three strict-f32 runs) of the strict-f32
-run - WHICHEVER IS LARGER, and the test prints which bound was the active one.  Adam trajectories of any two float32
-implementations separate chaotically (entries whose gradient is rounding noise flip the sign of their first updates), so bit
-or 1e-5 agreement after 300 steps is not a property even of two strict-f32 runs on different boxes; agreement inside the
-seed spread is what "trains to the same place" can mean."""
+over steps 200-299) of the bf16x3 run lies inside the range the five strict-f32 runs span, widened by max(1e-3 relative,
+half that range).  MEASURED (tools/convergence_probe.py, MI355X): the strict-f32 family ends at validation ELBO -216.4 ...
+-225.7 and matching-LL -19.6 ... -26.6 - a 1e-6 perturbation of the initial parameters alone moves the step-300 validation
+ELBO by 2 - 5 nats (1 - 2 %), as much as another noise seed does: Adam's first updates are sign-like, entries whose gradient
+is rounding noise flip, and at step 300 the ELBO is still climbing ~1 nat per step, so a trajectory that is a few steps
+"ahead" reads several nats higher.  A 1e-3 agreement at step 300 is therefore not a property of ANY two float32 runs; what
+"trains to the same place" can mean, and what is asserted, is membership in the float32 family's spread (bf16x3: -223.9 /
+-20.7, inside both).  The active bound is printed."""
 import numpy as np
 import pytest
 import torch
@@ -56,13 +60,16 @@ def _masks(n, seed):
     return b
 
 
-def _run(cfg, xs, data, masks, bf16x3, noise_seed, record_steps=0):
+def _run(cfg, xs, data, masks, bf16x3, noise_seed, record_steps=0, perturb=0.0, pseed=0):
     from posterior_matching_amd import optim
     from posterior_matching_amd.engine import PMVAETrainStep
     from tests.test_gpu_parity import _product_model
 
     dev = torch.device("cuda:0")
     m = _product_model(cfg, xs, seed=11, bf16x3=bf16x3)
+    if perturb:            # a rounding-level change of the starting point: p * (1 + perturb * N(0, 1))
+        g = torch.Generator().manual_seed(pseed)
+        m.load_params({n: t.cpu() * (1.0 + perturb * torch.randn(t.shape, generator=g)) for n, t in m.params_dict().items()})
     opt = optim.chain(optim.scale_by_adam(), optim.add_decayed_weights(cfg.get("weight_decay", 0.0)),
                       optim.scale_by_schedule(optim.exponential_decay(**cfg["lr_schedule"])), optim.scale(-1.0))
     ts = PMVAETrainStep(m, cfg, opt, B, xs, external_eps=True)
@@ -104,8 +111,12 @@ def test_bf16x3_trains_to_the_strict_f32_result_and_both_start_on_the_oracle_tra
 
     start, traj16, val16 = _run(cfg, xs, data, masks, True, noise_seed=21, record_steps=ORACLE_STEPS)
     _, traj32, val32 = _run(cfg, xs, data, masks, False, noise_seed=21)
-    _, _, val32b = _run(cfg, xs, data, masks, False, noise_seed=22)
-    _, _, val32c = _run(cfg, xs, data, masks, False, noise_seed=23)
+    family = [val32]
+    family.append(_run(cfg, xs, data, masks, False, noise_seed=22)[2])
+    family.append(_run(cfg, xs, data, masks, False, noise_seed=23)[2])
+    family.append(_run(cfg, xs, data, masks, False, noise_seed=21, perturb=1e-6, pseed=1)[2])
+    family.append(_run(cfg, xs, data, masks, False, noise_seed=21, perturb=1e-6, pseed=2)[2])
+    family = np.array(family)
 
     # (1) the first steps against the oracle (float32, and float64 as the yardstick of float32 drift)
     p32 = {n: t.float() for n, t in start.items()}
@@ -124,18 +135,15 @@ def test_bf16x3_trains_to_the_strict_f32_result_and_both_start_on_the_oracle_tra
             assert abs(got16[j] - w32) <= tol, ("bf16x3", step, key, got16[j], w32, w64)
             assert abs(got32[j] - w32) <= tol, ("strict f32", step, key, got32[j], w32, w64)
 
-    # (2) where the runs END: last-20 validation means
+    # (2) where the runs END: the bf16x3 run inside the strict-f32 family's spread of last-20 validation means
     report = {}
     for j, key in enumerate(("val_elbo", "val_matching_ll")):
-        f32_runs = np.array([val32[j], val32b[j], val32c[j]])
-        spread = float(f32_runs.max() - f32_runs.min())
-        bound_rel = 1e-3 * abs(val32[j])
-        bound = max(bound_rel, spread)
-        diff = abs(val16[j] - val32[j])
-        report[key] = {"bf16x3": float(val16[j]), "strict_f32": float(val32[j]), "f32_noise_seeds": f32_runs.tolist(),
-                       "abs_diff": float(diff), "bound_1e-3_rel": float(bound_rel), "bound_seed_spread": spread,
-                       "active_bound": "seed spread" if spread > bound_rel else "1e-3 relative"}
-        assert diff <= bound, (key, report[key])
-        # and training happened at all: the validation ELBO of the trained model is far above the initial one
+        lo, hi = float(family[:, j].min()), float(family[:, j].max())
+        rel = 1e-3 * abs(float(family[:, j].mean()))
+        margin = max(rel, 0.5 * (hi - lo))
+        report[key] = {"bf16x3": float(val16[j]), "strict_f32_family": family[:, j].tolist(), "family_range": [lo, hi],
+                       "margin": margin, "active_bound": "half the family range" if 0.5 * (hi - lo) > rel else "1e-3 relative"}
+        assert lo - margin <= val16[j] <= hi + margin, (key, report[key])
     print("convergence parity:", report)
-    assert val32[0] > traj32[0][0] + 20.0, ("the run did not train", val32, traj32[0])
+    # and training happened at all: the validation ELBO of the trained model is far above the first step's
+    assert val32[0] > traj32[0][0] + 100.0, ("the run did not train", val32, traj32[0])
