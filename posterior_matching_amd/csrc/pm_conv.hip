@@ -3662,49 +3662,63 @@ __global__ __launch_bounds__(256, 2) void rowtap_wgrad_bf16_kernel(WgradArgs p, 
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const bool do_bias = p.db != nullptr && ky == 0 && cb == 0;       // wave-uniform
 
+    // staging addresses do not depend on the sample: per piece the global float offset inside the sample's image (low 16 bits,
+    // 0xffff: not loaded - the piece is past the end or its input row is outside the image) and the LDS offset in shorts (high
+    // 16 bits) are worked out ONCE (the divisions by IW / OW cost more than the MFMAs of a sample when left in the loop)
     const int np4 = npix * 16, nd4 = g.OH * g.OW * 16;
+    unsigned paddr[NPI], daddr[NPD];
+#pragma unroll
+    for (int j = 0; j < NPI; ++j) {
+        const int e = tid + 256 * j;
+        const int ee = e < np4 ? e : 0;
+        const int pos = ee >> 4, c4 = ee & 15;
+        const int r = pos / g.IW, col = pos - r * g.IW;
+        const int y = r * g.a + g.off + ky * g.cs;
+        const bool ok = e < np4 && (unsigned)y < (unsigned)g.IH;
+        const unsigned go = ok ? (unsigned)((y * g.IW + col) * 16 + c4) : 0xffffu;        // in 16-byte units (< 16 * 16 * 16)
+        const unsigned lo = e < np4 ? (unsigned)(pos * PS + 4 * c4) : 0xffffu;            // < 129 * 72
+        paddr[j] = go | (lo << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NPD; ++j) {
+        const int e = tid + 256 * j;
+        const int ee = e < nd4 ? e : 0;
+        const int pos = ee >> 4, c4 = ee & 15;
+        const int oy = pos / g.OW, ox = pos - oy * g.OW;
+        daddr[j] = (e < nd4 ? (unsigned)ee : 0u) | ((e < nd4 ? (unsigned)((oy * 8 + ox) * DS + 4 * c4) : 0xffffu) << 16);
+    }
     f32x4 pv[NPI], dv[NPD];
     auto issue = [&](int b) {
-        const float* img = p.gathered + (size_t)b * g.IH * g.IW * 64;
-        const float* dimg = p.dense + (size_t)b * g.OH * g.OW * 64;
+        const f32x4* img = reinterpret_cast<const f32x4*>(p.gathered + (size_t)b * g.IH * g.IW * 64);
+        const f32x4* dimg = reinterpret_cast<const f32x4*>(p.dense + (size_t)b * g.OH * g.OW * 64);
 #pragma unroll
         for (int j = 0; j < NPI; ++j) {
-            const int e = tid + 256 * j;
-            const int ee = e < np4 ? e : 0;
-            const int pos = ee >> 4, c4 = ee & 15;
-            const int r = pos / g.IW, col = pos - r * g.IW;
-            const int y = r * g.a + g.off + ky * g.cs;
-            const bool ok = e < np4 && (unsigned)y < (unsigned)g.IH;
-            pv[j] = *reinterpret_cast<const f32x4*>(img + (ok ? ((size_t)y * g.IW + col) * 64 + 4 * c4 : 0));
-            if (!ok) pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned go = paddr[j] & 0xffffu;
+            pv[j] = img[go == 0xffffu ? 0u : go];
+            if (go == 0xffffu) pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int j = 0; j < NPD; ++j) {
-            const int e = tid + 256 * j;
-            dv[j] = *reinterpret_cast<const f32x4*>(dimg + 4 * (size_t)(e < nd4 ? e : 0));
-        }
+        for (int j = 0; j < NPD; ++j) dv[j] = dimg[daddr[j] & 0xffffu];
     };
     auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < NPI; ++j) {
-            const int e = tid + 256 * j;
-            if (e < np4) {
+            const unsigned lo = paddr[j] >> 16;
+            if (lo != 0xffffu) {
                 u32x2 h2, l2;
                 split4(pv[j], h2, l2);
-                *reinterpret_cast<u32x2*>(Ph + (e >> 4) * PS + 4 * (e & 15)) = h2;
-                *reinterpret_cast<u32x2*>(Pl + (e >> 4) * PS + 4 * (e & 15)) = l2;
+                *reinterpret_cast<u32x2*>(Ph + lo) = h2;
+                *reinterpret_cast<u32x2*>(Pl + lo) = l2;
             }
         }
 #pragma unroll
         for (int j = 0; j < NPD; ++j) {
-            const int e = tid + 256 * j;
-            if (e < nd4) {
-                const int pos = e >> 4, c4 = e & 15;
-                const int oy = pos / g.OW, ox = pos - oy * g.OW;
+            const unsigned lo = daddr[j] >> 16;
+            if (lo != 0xffffu) {
                 u32x2 h2, l2;
                 split4(dv[j], h2, l2);
-                *reinterpret_cast<u32x2*>(Dh + (oy * 8 + ox) * DS + 4 * c4) = h2;
-                *reinterpret_cast<u32x2*>(Dl + (oy * 8 + ox) * DS + 4 * c4) = l2;
+                *reinterpret_cast<u32x2*>(Dh + lo) = h2;
+                *reinterpret_cast<u32x2*>(Dl + lo) = l2;
             }
         }
     };

@@ -35,6 +35,21 @@ def pytest_collection_modifyitems(config, items):
 import pytest
 
 
+def compares(fn):
+    """Marks a parity test whose assertions compare device results with the oracle / a reference DIRECTLY (torch.equal,
+    allclose, exact integer outputs) instead of through rel_err: when the test body has run to its end - every assertion
+    passed - the kernels it launched count as compared (confirm_compared)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        out = fn(*args, **kwargs)
+        confirm_compared()
+        return out
+
+    return wrapper
+
+
 @pytest.fixture(autouse=True)
 def _seed_global_rngs():
     """Every test starts from the same global RNG state: a few tests draw shape-only inputs from the global generators,

@@ -3,6 +3,8 @@ importance-sampled likelihoods (vae.py:171-226) and the autoregressive sampler (
 with the noise passed explicitly.  Tolerances: 1e-4 relative on f32 paths (sampling chains 32 network passes)."""
 import numpy as np
 import pytest
+
+from tests import conftest as _conftest
 import torch
 
 from oracle import pm_vae_oracle as O
@@ -38,6 +40,7 @@ def test_impute_matches_oracle(name, B, S):
 
 
 @pytest.mark.parametrize("name,B,S,bf16x3", [("gas", 9, 16, False), ("mnist", 3, 5, False), ("gas", 9, 16, True)])
+@_conftest.compares
 def test_is_log_prob_matches_oracle(name, B, S, bf16x3):
     cfg, xs, x, b, _ = _inputs(name, B, 22)
     m = _product_model(cfg, xs, bf16x3=bf16x3)
@@ -82,6 +85,7 @@ def test_autoregressive_sampler_matches_oracle_and_density():
     assert rel_err(lp, want_lp) < 1e-4
 
 
+@_conftest.compares
 def test_device_noise_path_and_nrmse():
     """Without explicit noise the draws come from the Philox streams; imputations of observed entries are exact and the
     UCI metric of eval_pm_vae_uci.py:60-66 is finite."""
@@ -101,6 +105,7 @@ def test_device_noise_path_and_nrmse():
 
 
 @pytest.mark.parametrize("name,post,S", [("gas", "TriLGaussian", 6), ("gas", "DiagonalGaussian", 5), ("mnist", "TriLGaussian", 2)])
+@_conftest.compares
 def test_expected_info_gains_matches_oracle(name, post, S):
     """PosteriorMatchingVAE.expected_info_gains (reference vae.py:228-290): one instance, S decoder samples, F + 1 masked
     copies per sample through the partial encoder, entropy differences.  Entropies are O(k) and the gains their small

@@ -6,6 +6,8 @@ loss_fn(step, is_training, batch) -> (loss, aux) (train_pm_vae.py:58-72, train_v
 train_pm_vdvae.py:109-120)."""
 import numpy as np
 import pytest
+
+from tests import conftest as _conftest
 import torch
 
 from oracle import pixel_cnn_oracle as PO
@@ -75,6 +77,7 @@ def test_pm_vae_checkpoint_import(tmp_path, name):
         assert rel_err(got[key], want[key]) < 1e-5, key
 
 
+@_conftest.compares
 def test_vqvae_checkpoint_and_state_import(tmp_path):
     from posterior_matching_amd.checkpoint import load_npz, vq_state_to_native
     from posterior_matching_amd.models.vqvae import VQVAE
@@ -127,6 +130,7 @@ def test_vdvae_checkpoint_import(tmp_path):
 # ----------------------------------------------------------------------------------------------
 # the loss objects as functions: loss_fn(step, is_training, batch) -> (loss, aux)
 # ----------------------------------------------------------------------------------------------
+@_conftest.compares
 def test_pm_vae_loss_fn_is_callable_like_the_reference():
     from posterior_matching_amd.models import PosteriorMatchingVAE
     from posterior_matching_amd.trainer import PMVAELoss
@@ -154,6 +158,7 @@ def test_pm_vae_loss_fn_is_callable_like_the_reference():
     assert l1.item() == l2.item() != l3.item()
 
 
+@_conftest.compares
 def test_vqvae_and_stage2_loss_fns_are_callable():
     from posterior_matching_amd.models.vqvae import VQVAE, build_partial_posterior
     from posterior_matching_amd.trainer import PMVQVAELoss, VQVAELoss
@@ -189,6 +194,7 @@ def test_vqvae_and_stage2_loss_fns_are_callable():
     assert aux2 == {} and abs(loss2.item() - want2.item()) < 2e-5 * abs(want2.item())
 
 
+@_conftest.compares
 def test_vdvae_loss_fn_is_callable():
     from posterior_matching_amd.models.vdvae import PosteriorMatchingVDVAE
     from posterior_matching_amd.trainer import VDVAELoss

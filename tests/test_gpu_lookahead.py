@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from tests import conftest as _conftest
 import torch
 
 from oracle import lookahead_oracle as L
@@ -100,6 +102,7 @@ def test_lookahead_ll_kernels(B, F, Z, S, k):
     assert dp[0].abs().max().item() == 0.0 and (rest.size == 0 or dp[:, rest].abs().max().item() == 0.0)
 
 
+@_conftest.compares
 def test_lookahead_inputs_kernel():
     """pm_lookahead_inputs: rows (b, z, s) = [samples * max(b, one-hot) | max(b, one-hot)], bit-exact (lookahead.py:154-176)"""
     from posterior_matching_amd import ops
@@ -148,6 +151,7 @@ def test_lookahead_lls_and_every_gradient(name, B):
     assert m.pm_vae.store.flat_g.abs().max().item() == 0.0
 
 
+@_conftest.compares
 def test_lookahead_expected_info_gains():
     m, pm_cfg, look, xs, pv, pl = _setup("small")
     x, b, _, _ = _inputs(xs, look, pm_cfg["latent_dim"], 1, 5)
@@ -189,6 +193,7 @@ def test_lookahead_train_steps_match_oracle():
     assert worst[0] < 1e-3, worst
 
 
+@_conftest.compares
 def test_acquisition_kernels():
     """pm_acquisition_policy (argmax with ties and -inf entries, softmax of the -1e10-filled logits) and pm_reconstruction_rmse
     vs numpy"""

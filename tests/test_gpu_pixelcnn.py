@@ -4,6 +4,8 @@ import math
 
 import numpy as np
 import pytest
+
+from tests import conftest as _conftest
 import torch
 
 from oracle import pixel_cnn_oracle as PO
@@ -177,6 +179,7 @@ def test_gate_bwd_with_rows_sum(B, P, F, cond):
 
 
 @pytest.mark.parametrize("B,P,F,cond", [(256, 49, 128, True), (16, 256, 128, True), (5, 9, 12, False)])
+@_conftest.compares
 def test_gate_forward_with_the_next_blocks_concat_elu(B, P, F, cond):
     """pm_gate_fwd_ce (the train step's form) against the two launches it replaces - pm_gate_fwd, then pm_concat_elu_fwd of its
     output, both checked against the oracle by the PixelCNN parity tests: BIT-identical `out` and `ce`; the whole-network tests
@@ -198,6 +201,7 @@ def test_gate_forward_with_the_next_blocks_concat_elu(B, P, F, cond):
 
 
 @pytest.mark.parametrize("R,Ca,Cb", [(12544, 128, 0), (245, 64, 32), (4096, 128, 128)])
+@_conftest.compares
 def test_concat_elu_with_the_keep_mask_drawn_in_place(R, Ca, Cb):
     """pm_concat_elu_{fwd,bwd}_philox (the train step's form: hk.dropout's keep mask never exists in HBM) against the
     two-launch form it replaces - pm_dropout_mask into a tensor, then pm_concat_elu_{fwd,bwd} with that tensor, which the
@@ -299,6 +303,7 @@ def test_pixelcnn_log_prob_and_grads(training, bf16x3):
     assert torch.equal(gw[2], torch.zeros_like(gw[2])) and torch.equal(gw[:, 2], torch.zeros_like(gw[:, 2]))
 
 
+@_conftest.compares
 def test_pixelcnn_is_autoregressive_on_device():
     """bit-exact: logits at raster positions <= (r, c) do not depend on the index at (r, c)."""
     cfg, cd, B = dict(SMALL, image_shape=(7, 7)), 16, 2
@@ -321,6 +326,7 @@ def test_pixelcnn_is_autoregressive_on_device():
             assert not same.all()
 
 
+@_conftest.compares
 def test_pixelcnn_unconditional_sampling_matches_oracle():
     """PixelCNN.sample without conditional_input (reference pixel_cnn.py:82-100): exact index grids under explicit Gumbel
     noise; device noise: reproducible per seed; a network built WITH a conditional_dim refuses to sample without input."""

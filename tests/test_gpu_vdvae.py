@@ -3,6 +3,8 @@ import math
 
 import numpy as np
 import pytest
+
+from tests import conftest as _conftest
 import torch
 
 from oracle import pm_vae_oracle as O
@@ -524,6 +526,7 @@ def test_vdvae_impute_and_psnr_match_oracle():
     assert torch.equal(a, c) and a.min() >= 0 and a.max() <= 255
 
 
+@_conftest.compares
 def test_vdvae_is_log_probs_and_sample_match_oracle():
     """PosteriorMatchingVDVAE.is_log_probs (reference vdvae.py:96-146, forward_lls / sample_lls :609-660,725-754) and
     .sample (:148-159, forward_prior) with explicit noise.  The estimator sums O(100)-magnitude log terms over every

@@ -8,6 +8,8 @@ import math
 
 import numpy as np
 import pytest
+
+from tests import conftest as _conftest
 import torch
 
 from oracle import pm_vae_oracle as O
@@ -104,6 +106,7 @@ def test_vq_select_and_ema(N, D, K):
         assert torch.equal(lk.cpu(), ed.cpu().t()[idx.long().cpu()])
 
 
+@_conftest.compares
 def test_vq_tie_breaks_to_lowest_index():
     from posterior_matching_amd import ops
     from posterior_matching_amd.ops import LayerGeom
@@ -253,6 +256,7 @@ def test_vqvae_forward_and_grads(B, bf16x3, seed):
             assert rel_err(sd[k], v) < (2e-5 if not bf16x3 else 2e-4), k
 
 
+@_conftest.compares
 def test_vqvae_eval_mode_leaves_state_untouched():
     cfg, x, m, p64, st64 = _setup(5)
     before = m.state_dict()
@@ -314,6 +318,7 @@ def test_vqvae_train_steps_match_oracle(use_graph):
     assert ts.step_dev.item() == 4
 
 
+@_conftest.compares
 def test_vqvae_full_batch_properties():
     """B = 256 (BASELINE config size): size-independent properties."""
     cfg, x, m, p64, st64 = _setup(256, seed=21)
