@@ -342,6 +342,34 @@ for step in range(2):
     red.finish()
     assert torch.allclose(st.flat_g, both[0] + both[1], rtol=0, atol=0), step
     assert red.calls_last_step == 2 and red.calls_before_finish_last_step == 1, (red.calls_last_step, red.calls_before_finish_last_step)
+# replicas start identical (ADVICE r3): rank-local initial parameters (train_vade.py fits its GMM per rank) are replaced by
+# rank 0's before the first step - Trainer._broadcast_initial_state on a model whose stores hold rank-dependent values
+from posterior_matching_amd.trainer import Trainer
+class _St:
+    def __init__(self, n, seed):
+        self.flat_p = torch.randn(n, generator=torch.Generator().manual_seed(seed + 17 * rank))
+        self.splits = 0
+    def split_all(self):
+        self.splits += 1
+class _Vq:
+    def __init__(self):
+        self.state = {{"embeddings": torch.full((4, 3), float(rank)), "counter": torch.tensor([rank], dtype=torch.int32)}}
+class _Model:
+    def __init__(self):
+        self.store, self.partial_store, self.vq = _St(100, 1), _St(40, 2), _Vq()
+class _Lf:
+    partial_encoder = None
+    pixel_cnn = None
+tr = Trainer.__new__(Trainer)
+tr.world, tr.rank = world, rank
+mdl = _Model()
+tr._broadcast_initial_state(mdl, _Lf())
+for t in (mdl.store.flat_p, mdl.partial_store.flat_p, mdl.vq.state["embeddings"].reshape(-1), mdl.vq.state["counter"].float()):
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    assert all(torch.equal(gathered[0], g) for g in gathered), "replicas differ after the broadcast"
+assert torch.equal(mdl.store.flat_p, torch.randn(100, generator=torch.Generator().manual_seed(1)))      # rank 0's values
+assert mdl.store.splits == 1 and mdl.partial_store.splits == 1                                          # bf16 copies refreshed
 dist.barrier()
 if rank == 0:
     print("DP-OK")
