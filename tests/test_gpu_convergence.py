@@ -9,9 +9,10 @@ Bernoulli masks), identical seeds, data order and reparameterisation noise for e
   * the HIP strict-f32 run (every GEMM on the f32 MFMA: the reference's own arithmetic),
   * four more strict-f32 runs: two that differ ONLY in the noise seed, two whose initial parameters are multiplied by
     (1 + 1e-6 N(0, 1)) - a change at float32 rounding level, which is what swapping one arithmetic for another amounts to,
-  * the float32 (and float64) torch-CPU oracle for the first 10 steps (300 oracle steps would take ~5 minutes of host time).
+  * the float32 (and float64) torch-CPU oracle for the first 3 steps (an oracle step pair costs ~10 s of host time;
+    tests/test_gpu_parity.py::test_bf16x3_training_trajectory_within_1e3 follows the oracle for 4 - 6 steps on other data).
 
-Asserted: (1) steps 0-9: ELBO / KL / matching-LL of both HIP runs within 1e-3 relative of the oracle's float32 trajectory
+Asserted: (1) steps 0-2: ELBO / KL / matching-LL of both HIP runs within 1e-3 relative of the oracle's float32 trajectory
 (x3 the float32-vs-float64 oracle drift where that is larger - the yardstick of test_train_steps_match_oracle);
 (2) the mean of the LAST 20 validation ELBO and matching-LL values (a held-out batch with fixed noise, evaluated every 5 steps
 over steps 200-299) of the bf16x3 run lies inside the range the five strict-f32 runs span, widened by max(1e-3 relative,
@@ -28,7 +29,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-B, STEPS, ORACLE_STEPS, NDATA = 64, 300, 10, 512
+B, STEPS, ORACLE_STEPS, NDATA = 64, 300, 3, 512
 
 
 def _strokes(n, seed):
@@ -79,13 +80,16 @@ def _run(cfg, xs, data, masks, bf16x3, noise_seed, record_steps=0, perturb=0.0, 
     xv, bv = data[NDATA:NDATA + B].to(dev), masks[NDATA:NDATA + B].to(dev)      # held-out validation batch, fixed noise
     ev = torch.randn((B, k), generator=torch.Generator().manual_seed(999)).to(dev)
     start = {n: t.cpu().clone() for n, t in m.params_dict().items()}
+    data_d, masks_d = data.to(dev), masks.to(dev)               # everything a run reads is resident before its first step
+    eps_all = torch.randn((STEPS, B, k), generator=gen)
+    eps_d = eps_all.to(dev)
     traj, val = [], []
     for step in range(STEPS):
         idx = torch.as_tensor(order[(step * B) % NDATA:(step * B) % NDATA + B].copy())
-        eps = torch.randn((B, k), generator=gen)
         if step < record_steps:
-            traj.append((idx, eps.clone()))
-        ts.set_batch(data[idx].to(dev), masks[idx].to(dev), eps.to(dev))
+            traj.append((idx, eps_all[step].clone()))
+        idx_d = idx.to(dev)
+        ts.set_batch(data_d[idx_d], masks_d[idx_d], eps_d[step])
         ts.step()
         if step < ORACLE_STEPS:
             met = ts.read_metrics()
