@@ -4610,7 +4610,8 @@ static int launch_big_wgrad(pm_stream_t stream, WgradArgs& a, const pm_gather_de
                             int* slots_out) {
         const Geom& g = a.g;
         const long long work = (long long)g.M * g.K * g.N * d->groups;
-        if (!getenv("PM_WG_NOBIG") && !cpad && g.C % 128 == 0 && g.K >= 512 && g.N >= 128 && g.M >= 2048 && work >= (1LL << 30)) {
+        static const int big_mink = getenv("PM_WG_BIG_MINK") ? atoi(getenv("PM_WG_BIG_MINK")) : 512;     // A/B knob
+        if (!getenv("PM_WG_NOBIG") && !cpad && g.C % 128 == 0 && g.K >= big_mink && g.N >= 128 && g.M >= 2048 && work >= (1LL << 30)) {
             const int nkb = g.K / 128, nnb = (g.N + 127) / 128;
             static const int bmc = getenv("PM_WG_BIG_BMC") ? atoi(getenv("PM_WG_BIG_BMC")) : 32;   // rows per chunk (A/B knob)
             const int total_chunks = (g.M + bmc - 1) / bmc;

@@ -15,8 +15,8 @@ Bernoulli masks), identical seeds, data order and reparameterisation noise for e
 Asserted: (1) steps 0-2: ELBO / KL / matching-LL of both HIP runs within 1e-3 relative of the oracle's float32 trajectory
 (x3 the float32-vs-float64 oracle drift where that is larger - the yardstick of test_train_steps_match_oracle);
 (2) the mean of the LAST 20 validation ELBO and matching-LL values (a held-out batch with fixed noise, evaluated every 5 steps
-over steps 200-299) of the bf16x3 run lies inside the range the five strict-f32 runs span, widened by max(1e-3 relative,
-half that range).  MEASURED (tools/convergence_probe.py, MI355X): the strict-f32 family ends at validation ELBO -216.4 ...
+over steps 200-299) of the bf16x3 run lies within max(1e-3 relative, 4 sigma) of the five strict-f32 runs' mean, sigma =
+their standard deviation, floored at the measured chaos level (1 % of the ELBO, 2 nats of matching-LL).  MEASURED (tools/convergence_probe.py, MI355X): the strict-f32 family ends at validation ELBO -216.4 ...
 -225.7 and matching-LL -19.6 ... -26.6 - a 1e-6 perturbation of the initial parameters alone moves the step-300 validation
 ELBO by 2 - 5 nats (1 - 2 %), as much as another noise seed does: Adam's first updates are sign-like, entries whose gradient
 is rounding noise flip, and at step 300 the ELBO is still climbing ~1 nat per step, so a trajectory that is a few steps
@@ -142,12 +142,18 @@ def test_bf16x3_trains_to_the_strict_f32_result_and_both_start_on_the_oracle_tra
     # (2) where the runs END: the bf16x3 run inside the strict-f32 family's spread of last-20 validation means
     report = {}
     for j, key in enumerate(("val_elbo", "val_matching_ll")):
-        lo, hi = float(family[:, j].min()), float(family[:, j].max())
-        rel = 1e-3 * abs(float(family[:, j].mean()))
-        margin = max(rel, 0.5 * (hi - lo))
-        report[key] = {"bf16x3": float(val16[j]), "strict_f32_family": family[:, j].tolist(), "family_range": [lo, hi],
-                       "margin": margin, "active_bound": "half the family range" if 0.5 * (hi - lo) > rel else "1e-3 relative"}
-        assert lo - margin <= val16[j] <= hi + margin, (key, report[key])
+        mean, std = float(family[:, j].mean()), float(family[:, j].std(ddof=1))
+        # five samples of a chaotic quantity estimate its spread poorly (the strict-f32 runs are not even run-to-run
+        # identical: their split-K data gradients use atomics), so sigma is floored at the MEASURED sensitivity: 1 % of the
+        # value (ELBO) / 2 nats (matching-LL) is what a 1e-6 perturbation of the start does (tools/convergence_probe.py)
+        floor = max(0.01 * abs(mean), 2.0 if key == "val_matching_ll" else 0.0)
+        sigma = max(std, floor)
+        bound = max(1e-3 * abs(mean), 4.0 * sigma)
+        report[key] = {"bf16x3": float(val16[j]), "strict_f32_family": family[:, j].tolist(), "family_mean": mean,
+                       "family_std": std, "sigma_used": sigma, "bound_4_sigma": bound,
+                       "active_bound": "1e-3 relative" if bound == 1e-3 * abs(mean) else
+                       ("4 x family std" if sigma == std else "4 x measured chaos floor")}
+        assert abs(val16[j] - mean) <= bound, (key, report[key])
     print("convergence parity:", report)
     # and training happened at all: the validation ELBO of the trained model is far above the first step's
     assert val32[0] > traj32[0][0] + 100.0, ("the run did not train", val32, traj32[0])
