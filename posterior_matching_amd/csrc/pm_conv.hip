@@ -3412,7 +3412,17 @@ __global__ __launch_bounds__(256) void image_wgrad_bf16_kernel(WgradArgs p, int 
     const int ntaps = g.KH * g.KW;
 
     // the taps are dealt to nsub workgroup classes (sub = blockIdx.x % nsub), inside a class to its 4 waves: TPW each
-    const int sub = blockIdx.x % nsub, b_first = blockIdx.x / nsub, b_step = gridDim.x / nsub;
+    // (the nsub classes of a sample slot on ONE XCD when the slots divide over the eight: they stage the same samples)
+    const int b_step = gridDim.x / nsub;
+    int sub, b_first;
+    if (b_step % 8 == 0) {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        sub = r % nsub;
+        b_first = xcd + 8 * (r / nsub);
+    } else {
+        sub = blockIdx.x % nsub;
+        b_first = blockIdx.x / nsub;
+    }
     int tdy[TPW], tdx[TPW];                        // pixel offsets of this wave's taps
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
@@ -3612,7 +3622,18 @@ __global__ __launch_bounds__(256, 2) void rowtap_wgrad_bf16_kernel(WgradArgs p, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave >> 1, nb = wave & 1;       // this wave's 32 x 32 block of every tap's 64 x 64 tile
     const int i = lane & 31, h = lane >> 5;
-    const int ky = blockIdx.x % g.KH, grp = blockIdx.x / g.KH;
+    // the KH classes of a sample group stage the same samples: keep them on one XCD (blocks b, b + 8, .. share an L2 under
+    // round-robin placement - speed only) when the groups divide over the eight XCDs; measured without: every sample crosses
+    // the fabric once per class (profiles/r04_final_pmc_traffic.txt: 62 MB for 16 MB of operands)
+    int ky, grp;
+    if (ngroups % 8 == 0) {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        ky = r % g.KH;
+        grp = xcd + 8 * (r / g.KH);
+    } else {
+        ky = blockIdx.x % g.KH;
+        grp = blockIdx.x / g.KH;
+    }
     const int npix = g.OH * g.IW;                  // staged gathered pixels: OH rows of IW
     short* Ph = reinterpret_cast<short*>(dsm);
     short* Pl = Ph + (npix + 1) * PS;
