@@ -1097,3 +1097,56 @@ def test_miniboone_train_steps_and_device_dropout():
     assert not torch.equal(drawn[0], drawn[1]) and not torch.equal(drawn[1], drawn[2])
     assert not torch.equal(m.encoder_net.buf("g/mask_0", (B, 256)), m.encoder_net.buf("g/mask_1", (B, 256)))
     assert not torch.equal(m.encoder_net.buf("g/mask_0", (B, 256)), m.partial_encoder_net.buf("g/mask_0", (B, 256)))
+
+
+@pytest.mark.parametrize("slots", [(1, 3), (8, 37), (2, 256)])
+def test_partial_sums_reduce_and_fused_adam(slots):
+    """pm_reduce_partials adds the slots of every run in a fixed order (== the float64 sum to f32 rounding, and bit-identical
+    when repeated); pm_adam_step_jobs (the optimizer reading the partial sums itself) gives bit for bit the parameters /
+    moments of pm_reduce_partials + pm_adam_step, for runs with few slots (a thread walks them), many (the four waves deal
+    them) and none, ragged run lengths, and direct contributions already sitting in g."""
+    from posterior_matching_amd import ops, optim
+    from posterior_matching_amd.partials import PartialSums
+
+    d = dev()
+    gen = torch.Generator().manual_seed(sum(slots))
+    n = 5000                                                       # a multiple of 4, like every ParamStore buffer
+    runs = [(0, 1030, slots[0]), (1032, 257, slots[1]), (2000, 2048, slots[0] + 1)]       # (g_off, count, nslots); gaps between
+    g0 = torch.randn(n, generator=gen).to(d)                       # direct contributions (biases, heads)
+    p0, m0, v0 = (torch.randn(n, generator=gen).to(d), torch.randn(n, generator=gen).to(d) * 0.1,
+                  torch.rand(n, generator=gen).to(d) * 0.01)
+    cfg = optim.adam(1e-3).adam_cfg(grad_scale=0.5)
+    cfg.zero_grad = 1
+    step = torch.full((1,), 7, dtype=torch.int32, device=d)
+
+    def fill(ps):
+        want = g0.double().cpu().clone()
+        for off, cnt, S in runs:
+            buf, src = ps.arena(off, cnt, S)
+            stride = ps.entries[(off, cnt)][2]
+            vals = torch.randn((S, stride), generator=torch.Generator().manual_seed(off + S))
+            vals[:, cnt:] = 0.0                                    # the pad of a slot stays zero, as the kernels leave it
+            buf.view(S, stride).copy_(vals)
+            want[off:off + cnt] += vals[:, :cnt].double().sum(0)
+        return want
+
+    outs = []
+    for fused in (False, True, False):
+        g, p, m, v = g0.clone(), p0.clone(), m0.clone(), v0.clone()
+        ps = PartialSums(g)
+        want = fill(ps)
+        if fused:
+            table, njobs, _ = ps.adam_table()
+            ops.adam_step_jobs(table, njobs, p, g, m, v, 3000, step, cfg)
+        else:
+            ps.reduce()
+            assert rel_err(g, want) < 1e-6
+            ops.adam_step(p, g, m, v, 3000, step, cfg)
+        torch.cuda.synchronize()
+        assert not ps.pending and float(g.abs().max()) == 0.0      # consumed and zeroed
+        outs.append((p, m, v))
+    _compared()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                                   # fused == reduce + Adam, bit for bit
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)                                   # and the same bits when repeated
