@@ -228,6 +228,7 @@ SIGNATURES = {
     "pm_pmvae_loss": [_P, _P, _P, _P, _I, C.POINTER(LossCfg), _P, _P, _P, _P, _P],
     "pm_adam_step": [_P, _P, _P, _P, _P, _LL, _LL, _P, C.POINTER(AdamCfg)],
     "pm_counter_increment": [_P, _P],
+    "pm_counter_snapshot_increment": [_P, _P, _P],
     "pm_stamp": [_P, _P],
     "pm_normal_fill": [_P, _P, _LL, C.c_ulonglong, _P, _I],
     "pm_fill_zero": [_P, _P, _LL],

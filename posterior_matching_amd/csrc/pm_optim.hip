@@ -614,6 +614,20 @@ extern "C" int pm_stamp(pm_stream_t stream, unsigned long long* dst) {
     return pm_check_launch("pm_stamp");
 }
 
+// snap = count; count += 1: the optimizer of step k reads `snap` on another stream while the head kernels of step k + 1
+// (noise, schedules) already read the incremented counter
+__global__ void counter_snapshot_increment_kernel(int* c, int* snap) {
+    const int v = c[0];
+    snap[0] = v;
+    c[0] = v + 1;
+}
+
+extern "C" int pm_counter_snapshot_increment(pm_stream_t stream, int* count_dev, int* snapshot_dev) {
+    if (!count_dev || !snapshot_dev) return PM_EINVAL;
+    hipLaunchKernelGGL(counter_snapshot_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, count_dev, snapshot_dev);
+    return pm_check_launch("pm_counter_snapshot_increment");
+}
+
 extern "C" int pm_counter_increment(pm_stream_t stream, int* count_dev) {
     if (!count_dev) return PM_EINVAL;
     hipLaunchKernelGGL(counter_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, count_dev);

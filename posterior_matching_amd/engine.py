@@ -253,13 +253,30 @@ class PMVAETrainStep(_PlannedStep):
 
     def _update(self) -> None:
         s = self.model.store
-        self._adam_step(s, self.step_dev)
-        self._grads_consumed(s)
-        # refresh the pre-split bf16 weight copies (one launch).  Two-stream steps: on the SIDE stream, beside the counter
-        # increment, the next batch's copies and the next step's head kernels - its first consumers (the second layer of each
-        # encoder) wait for `_split_done` (PM_SPLIT_MAIN=1: on the main stream as before, A/B)
         m = self.model
         self._split_on_side = bool(m.concurrent and not self.use_graph and not os.environ.get("PM_SPLIT_MAIN"))
+        if self._split_on_side and not os.environ.get("PM_ADAM_MAIN"):
+            # Two-stream steps: the optimizer (the one kernel that runs ALONE on the chip: 57 us for 266 MB) and the refresh
+            # of the pre-split bf16 weight copies go to the SIDE stream; the main stream advances the step counter (the
+            # optimizer reads a snapshot of it), takes the next batch's copies and runs the next step's head kernels (noise,
+            # upstream gradients) beside them, and waits for `_split_done` in front of the first layer (_wait_split).
+            # PM_ADAM_MAIN=1: optimizer on the main stream as before; PM_SPLIT_MAIN=1: everything on the main stream (A/B)
+            main, side = torch.cuda.current_stream(self.x.device), m._side_stream(self.x.device)
+            if getattr(self, "_split_done", None) is None:
+                self._split_done = torch.cuda.Event()
+                self._opt_step = torch.zeros(1, dtype=torch.int32, device=self.x.device)
+            ops.counter_snapshot_increment(self.step_dev, self._opt_step)
+            ops.wait_stream(side, main)
+            with torch.cuda.stream(side):
+                self._adam_step(s, self._opt_step)
+                s.split_all()
+                ops.record_event(self._split_done, side)
+            self._grads_consumed(s)
+            return
+        self._adam_step(s, self.step_dev)
+        self._grads_consumed(s)
+        # refresh the pre-split bf16 weight copies (one launch): on the side stream beside the counter increment, the next
+        # batch's copies and the next step's head kernels
         if self._split_on_side:
             main, side = torch.cuda.current_stream(self.x.device), m._side_stream(self.x.device)
             if getattr(self, "_split_done", None) is None:

@@ -1490,6 +1490,10 @@ def adam_step_jobs(table, njobs: int, p, g, m, v, n_decay, count_dev, cfg: _lib.
           C.byref(cfg), tag="adam_jobs_kernel", work={"bytes": passes * 4.0 * p.numel() + part_bytes})
 
 
+def counter_snapshot_increment(count_dev, snapshot_dev) -> None:
+    _call("pm_counter_snapshot_increment", _iptr(count_dev), _iptr(snapshot_dev))
+
+
 def counter_increment(count_dev) -> None:
     _call("pm_counter_increment", _iptr(count_dev))
 

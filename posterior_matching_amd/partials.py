@@ -108,6 +108,11 @@ class PartialSums:
             g_off, count = key
             per = 256 if nslots >= 8 else 1024
             base = buf.data_ptr() + 4 * src_off
+            # whole 16-byte vectors when the run is aligned (the pad elements are zero in the arena and belong to nobody in
+            # the flat buffer): the kernel then takes its vector path for the ragged tail too - the same summation order as
+            # pm_adam_step_jobs, so the fused and the unfused optimizer give the same bits
+            if g_off % 4 == 0 and stride % 4 == 0 and src_off % 4 == 0 and self.flat.numel() % 4 == 0:
+                count = (count + 3) // 4 * 4
             for o in range(0, count, per):
                 j = ReduceJob()
                 j.src = base + 4 * o
