@@ -27,8 +27,89 @@ class _PlannedStep:
     eager path; a KernelTimer (bench.py's profiling pass) also forces it."""
 
     use_plan = True
-    _plan: Optional["ops.LaunchPlan"] = None
-    _warm = False
+
+    # ---- double-buffered step inputs -------------------------------------------------------------------------------------
+    # A recorded launch plan reads its inputs at fixed addresses, so a new batch has to be COPIED into them; on the step's own
+    # stream those copies (two 6 us kernels plus their launch gaps and a cross-stream wait: ~40 us of a 1.33 ms PM-VAE step,
+    # tools/pace_probe.py) sit between two steps with nothing else to run.  With two input sets and one recorded plan per set,
+    # set_batch() fills the set the NEXT step reads on a feed stream while the current step is still running.
+    # PM_NO_FEED_OVERLAP=1: one set, copies on the step's stream (A/B).
+    def _init_inputs(self, dev, shapes, double: bool) -> None:
+        n = 2 if (double and not os.environ.get("PM_NO_FEED_OVERLAP")) else 1
+        self._in = [{k: torch.zeros(v, device=dev) for k, v in shapes.items()} for _ in range(n)]
+        self._cur = 0
+        self._plans, self._warms = [None] * n, [False] * n
+        self._feed = torch.cuda.Stream(device=dev) if n > 1 else None
+        self._ready = [None] * n                 # event behind the copies into set i (None: nothing fed since its last step)
+        self._free = [None] * n                  # event behind the last step that read set i
+
+    def _input_property(name):          # noqa: N805 - steps without input sets (single static buffers) keep plain attributes
+        def get(self):
+            sets = self.__dict__.get("_in")
+            return sets[self._cur][name] if sets is not None and name in sets[0] else self.__dict__["_" + name]
+
+        def put(self, value):
+            self.__dict__["_" + name] = value
+
+        return property(get, put)
+
+    x, b, eps = _input_property("x"), _input_property("b"), _input_property("eps")
+
+    def _feed_inputs(self, **srcs) -> None:
+        """copies the given tensors into the input set the next step() will read"""
+        dev = self._in[0]["x"].device
+        if self._feed is None:
+            self.stream.wait_stream(torch.cuda.current_stream(dev))          # producers of the batch
+            with torch.cuda.stream(self.stream):
+                for k, t in srcs.items():
+                    if t is not None:
+                        self._in[0][k].copy_(t.reshape(self._in[0][k].shape), non_blocking=True)
+            return
+        self._cur ^= 1
+        cur = self._cur
+        self._feed.wait_stream(torch.cuda.current_stream(dev))
+        if self._free[cur] is not None:
+            self._feed.wait_event(self._free[cur])                          # the step that last read this set has finished
+        with torch.cuda.stream(self._feed):
+            for k, t in srcs.items():
+                if t is not None:
+                    self._in[cur][k].copy_(t.reshape(self._in[cur][k].shape), non_blocking=True)
+        if self._ready[cur] is None:
+            self._ready[cur] = torch.cuda.Event()
+        self._ready[cur].record(self._feed)
+
+    def _inputs_acquire(self) -> None:
+        """step(): the step's stream waits for the copies into the current set"""
+        if self._feed is not None and self._ready[self._cur] is not None:
+            self.stream.wait_event(self._ready[self._cur])
+
+    def _inputs_release(self) -> None:
+        if self._feed is not None:
+            if self._free[self._cur] is None:
+                self._free[self._cur] = torch.cuda.Event()
+            self._free[self._cur].record(self.stream)
+
+    @property
+    def _plan(self):
+        return self._plans[self._cur] if getattr(self, "_plans", None) else getattr(self, "_plan1", None)
+
+    @_plan.setter
+    def _plan(self, v):
+        if getattr(self, "_plans", None):
+            self._plans[self._cur] = v
+        else:
+            self._plan1 = v
+
+    @property
+    def _warm(self):
+        return self._warms[self._cur] if getattr(self, "_warms", None) else getattr(self, "_warm1", False)
+
+    @_warm.setter
+    def _warm(self, v):
+        if getattr(self, "_warms", None):
+            self._warms[self._cur] = v
+        else:
+            self._warm1 = v
 
     def _planned(self, sequence) -> None:
         if ops._timer is not None:      # per-kernel timing (ops.KernelTimer): always the eager path, also when a plan exists
@@ -53,7 +134,10 @@ class _PlannedStep:
             self._warm = True
 
     def invalidate_plan(self) -> None:
-        self._plan, self._warm = None, False
+        if getattr(self, "_plans", None):
+            self._plans, self._warms = [None] * len(self._plans), [False] * len(self._warms)
+        else:
+            self._plan, self._warm = None, False
 
     def _grad_store(self):
         return getattr(self, "store", None) or getattr(getattr(self, "model", None), "store", None)
@@ -183,9 +267,8 @@ class PMVAETrainStep(_PlannedStep):
         self.reducer = _make_reducer(model.store, world_size, overlap_allreduce and not use_graph)
         x_shape = tuple(x_shape)
         b_shape = x_shape[:-1] + (1,) if len(x_shape) == 3 else x_shape
-        self.x = torch.zeros((batch_size,) + x_shape, device=dev)
-        self.b = torch.zeros((batch_size,) + b_shape, device=dev)
-        self.eps = torch.zeros((batch_size, model.latent_dim), device=dev)
+        self._init_inputs(dev, {"x": (batch_size,) + x_shape, "b": (batch_size,) + b_shape,
+                                "eps": (batch_size, model.latent_dim)}, double=model.concurrent and not use_graph)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.metrics = torch.zeros(8, device=dev)       # loss, rec, kl, mll, beta
         self.g_rec = torch.zeros(batch_size, device=dev)
@@ -300,8 +383,10 @@ class PMVAETrainStep(_PlannedStep):
 
     # -- one optimizer step on whatever is in self.x / self.b (/ self.eps) ---------------------
     def step(self) -> None:
+        self._inputs_acquire()
         with torch.cuda.stream(self.stream):
             self._step()
+        self._inputs_release()
 
     def _step(self) -> None:
         if not self.use_graph:
@@ -332,12 +417,7 @@ class PMVAETrainStep(_PlannedStep):
             self._graph_opt.launch()
 
     def set_batch(self, x: torch.Tensor, b: torch.Tensor, eps: Optional[torch.Tensor] = None) -> None:
-        self.stream.wait_stream(torch.cuda.current_stream(self.x.device))   # producers of x / b / eps
-        with torch.cuda.stream(self.stream):
-            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
-            self.b.copy_(b.reshape(self.b.shape), non_blocking=True)
-            if eps is not None:
-                self.eps.copy_(eps, non_blocking=True)
+        self._feed_inputs(x=x, b=b, eps=eps)
 
     def synchronize(self) -> None:
         self.stream.synchronize()
