@@ -33,9 +33,11 @@ class _PlannedStep:
     # stream those copies (two 6 us kernels plus their launch gaps and a cross-stream wait: ~40 us of a 1.33 ms PM-VAE step,
     # tools/pace_probe.py) sit between two steps with nothing else to run.  With two input sets and one recorded plan per set,
     # set_batch() fills the set the NEXT step reads on a feed stream while the current step is still running.
-    # PM_NO_FEED_OVERLAP=1: one set, copies on the step's stream (A/B).
+    # MEASURED (same box, three pairs, profiles/r04_ab_tail_head.txt): 1.349 / 1.354 / 1.370 ms with the feed stream against
+    # 1.335 / 1.335 / 1.340 ms with the copies on the step's own stream - a third stream's copies disturb the two queues' balance
+    # more than their 40 us are worth, like every third stream tried on this step: OFF unless PM_FEED_OVERLAP=1.
     def _init_inputs(self, dev, shapes, double: bool) -> None:
-        n = 2 if (double and not os.environ.get("PM_NO_FEED_OVERLAP")) else 1
+        n = 2 if (double and os.environ.get("PM_FEED_OVERLAP")) else 1
         self._in = [{k: torch.zeros(v, device=dev) for k, v in shapes.items()} for _ in range(n)]
         self._cur = 0
         self._plans, self._warms = [None] * n, [False] * n
@@ -338,12 +340,14 @@ class PMVAETrainStep(_PlannedStep):
         s = self.model.store
         m = self.model
         self._split_on_side = bool(m.concurrent and not self.use_graph and not os.environ.get("PM_SPLIT_MAIN"))
-        if self._split_on_side and not os.environ.get("PM_ADAM_MAIN"):
+        if self._split_on_side and os.environ.get("PM_ADAM_SIDE"):
             # Two-stream steps: the optimizer (the one kernel that runs ALONE on the chip: 57 us for 266 MB) and the refresh
             # of the pre-split bf16 weight copies go to the SIDE stream; the main stream advances the step counter (the
             # optimizer reads a snapshot of it), takes the next batch's copies and runs the next step's head kernels (noise,
             # upstream gradients) beside them, and waits for `_split_done` in front of the first layer (_wait_split).
-            # PM_ADAM_MAIN=1: optimizer on the main stream as before; PM_SPLIT_MAIN=1: everything on the main stream (A/B)
+            # MEASURED: 1.349 / 1.340 / 1.342 ms against 1.346 / 1.345 / 1.339 ms with the optimizer on the main stream - no
+            # effect, so the simpler order stays the default (PM_ADAM_SIDE=1 enables this one; PM_SPLIT_MAIN=1: the weight split
+            # on the main stream too)
             main, side = torch.cuda.current_stream(self.x.device), m._side_stream(self.x.device)
             if getattr(self, "_split_done", None) is None:
                 self._split_done = torch.cuda.Event()
