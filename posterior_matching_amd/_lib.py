@@ -224,6 +224,9 @@ SIGNATURES = {
     "pm_dmol_mean": [_P, _P, _P, _LL, _I, _F, _F],
     "pm_vdvae_loss": [_P, _P, _P, _P, _I, _F, _P],
     "pm_sumsq": [_P, _P, _LL, _P],
+    "pm_sumsq_det": [_P, _P, _LL, _P, _P],
+    "pm_affine_bwd_part_slots": [_LL, C.POINTER(_I)],
+    "pm_affine_bwd_part": [_P, _P, _P, _P, _P, _P, _P, _LL, _I, _LL, _I],
     "pm_adam_step_clip_ema": [_P, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, C.POINTER(AdamCfg), _F, _F, _I],
     "pm_pmvae_loss": [_P, _P, _P, _P, _I, C.POINTER(LossCfg), _P, _P, _P, _P, _P],
     "pm_adam_step": [_P, _P, _P, _P, _P, _LL, _LL, _P, C.POINTER(AdamCfg)],

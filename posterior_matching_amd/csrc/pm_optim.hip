@@ -581,6 +581,51 @@ extern "C" int pm_adam_step_jobs(pm_stream_t stream, const pm_reduce_job* jobs_d
     return pm_check_launch("pm_adam_step_jobs");
 }
 
+// The same sum in a FIXED order (pm_sumsq_det): every workgroup stores its partial sum, the workgroup whose ticket says it is
+// the last one adds the partials in index order - the global gradient norm behind the VDVAE's clip / non-finite skip then has
+// the same bits in every run.  scratch: >= 1026 words (1024 partials, the ticket counter, which the last workgroup resets).
+__global__ __launch_bounds__(256) void sumsq_det_kernel(const float* __restrict__ x, long long n, float* __restrict__ out,
+                                                          float* __restrict__ scratch) {
+    __shared__ float red[4];
+    __shared__ int last;
+    float s = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) s += x[i] * x[i];
+    s = pm_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 1024);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(scratch + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)        // thread t: partials t, t + 256, ... (<= 4 of them)
+        t += __hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ float fin[256];
+    fin[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 256; ++i) tot += fin[i];
+        out[0] = tot;
+        *ticket = 0u;
+    }
+}
+
+extern "C" int pm_sumsq_det(pm_stream_t stream, const float* x, long long n, float* out, float* scratch) {
+    if (!x || !out || !scratch || n <= 0) return PM_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sumsq_det_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out, scratch);
+    return pm_check_launch("pm_sumsq_det");
+}
+
 extern "C" int pm_sumsq(pm_stream_t stream, const float* x, long long n, float* out) {
     if (!x || !out || n <= 0) return PM_EINVAL;
     hipStream_t s = (hipStream_t)stream;

@@ -591,7 +591,14 @@ __global__ __launch_bounds__(256) void affine_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void affine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gain,
                                                           const float* __restrict__ dout, float* __restrict__ dx,
                                                           float* __restrict__ dgain, float* __restrict__ dbias,
-                                                          long long R, int C, int rows_per_block) {
+                                                          long long R, int C, int rows_per_block, long long part_stride) {
+    // part_stride > 0 (partial-sum mode, pm_affine_bwd_part): dgain / dbias are arenas, this workgroup STORES its sums into
+    // slot blockIdx.x (one writer per element; pm_reduce_partials / the optimizer add the slots in a fixed order)
+    const bool part = part_stride > 0;
+    if (part) {
+        dgain += (size_t)blockIdx.x * part_stride;
+        dbias += (size_t)blockIdx.x * part_stride;
+    }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     for (int c = threadIdx.x; c < C; c += 256) {
         float sg = 0.f, sb = 0.f;
@@ -603,8 +610,13 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const float* __restrict
             sg += d * x[o];
             sb += d;
         }
-        atomicAdd(dgain + c, sg);
-        atomicAdd(dbias + c, sb);
+        if (part) {
+            dgain[c] = sg;
+            dbias[c] = sb;
+        } else {
+            atomicAdd(dgain + c, sg);
+            atomicAdd(dbias + c, sb);
+        }
     }
 }
 
@@ -862,8 +874,24 @@ extern "C" int pm_affine_bwd(pm_stream_t stream, const float* x, const float* ga
     if (!x || !gain || !dout || !dx || !dgain || !dbias || rows <= 0 || C <= 0) return PM_EINVAL;
     const int rpb = 64;
     hipLaunchKernelGGL(affine_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x,
-                       gain, dout, dx, dgain, dbias, rows, C, rpb);
+                       gain, dout, dx, dgain, dbias, rows, C, rpb, 0LL);
     return pm_check_launch("pm_affine_bwd");
+}
+
+extern "C" int pm_affine_bwd_part_slots(long long rows, int* nslots) {
+    if (!nslots || rows <= 0) return PM_EINVAL;
+    *nslots = (int)((rows + 63) / 64);
+    return PM_OK;
+}
+
+extern "C" int pm_affine_bwd_part(pm_stream_t stream, const float* x, const float* gain, const float* dout, float* dx,
+                                  float* part_gain, float* part_bias, long long part_stride, int nslots, long long rows, int C) {
+    if (!x || !gain || !dout || !dx || !part_gain || !part_bias || rows <= 0 || C <= 0 || part_stride < C) return PM_EINVAL;
+    const int rpb = 64;
+    if (nslots != (int)((rows + rpb - 1) / rpb)) return PM_EINVAL;
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3((unsigned)nslots), dim3(256), 0, (hipStream_t)stream, x, gain, dout, dx, part_gain,
+                       part_bias, rows, C, rpb, part_stride);
+    return pm_check_launch("pm_affine_bwd_part");
 }
 
 extern "C" int pm_dmol_ll_fwd(pm_stream_t stream, const float* params, const float* value, float* ll, long long rows,

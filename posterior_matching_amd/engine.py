@@ -717,6 +717,7 @@ class VDVAETrainStep(_PlannedStep):
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # training step (RNG counter)
         self.opt_count = torch.zeros(1, dtype=torch.int32, device=dev)     # optax count: not advanced by skipped steps
         self.gnorm_sq = torch.zeros(1, device=dev)
+        self._gnorm_scratch = torch.zeros(1026, device=dev)      # pm_sumsq_det: partial sums + ticket
         self.stream = _step_stream(dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         # Weight gradients on companion streams: measured on this chain of ~1 900 tiny launches they do NOT pay (B = 8 / 16:
@@ -735,7 +736,7 @@ class VDVAETrainStep(_PlannedStep):
         self._reduce_partials(s)
         if self.reducer is not None:
             self.reducer.finish()       # the clip / non-finite decision below sees the REDUCED gradient on every rank
-        ops.sumsq(s.flat_g, self.gnorm_sq)
+        ops.sumsq_det(s.flat_g, self.gnorm_sq, self._gnorm_scratch)     # fixed order: the clip factor has the same bits every run
         ops.adam_step_clip_ema(s.flat_p, s.flat_g, s.flat_m, s.flat_v, self.ema, s.n_decay, self.opt_count, self.gnorm_sq,
                                self.adam_cfg, self.clip, self.ema_rate if self.ema_rate is not None else 0.0, self.skip)
         self._grads_consumed(s)

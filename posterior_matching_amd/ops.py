@@ -1421,8 +1421,23 @@ def affine_fwd(x, gain, bias, out) -> None:
 
 
 def affine_bwd(x, gain, dout, dx, dgain, dbias) -> None:
+    """dgain / dbias inside a ParamStore's gradient buffer: per-workgroup partial sums (no atomics; partials.PartialSums)"""
+    from . import partials
+
     C_ = x.shape[-1]
-    _call("pm_affine_bwd", _ptr(x), _ptr(gain), _ptr(dout), _ptr(dx), _ptr(dgain), _ptr(dbias), x.numel() // C_, C_)
+    rows = x.numel() // C_
+    own = partials.owner_of(dgain)
+    ns = C.c_int()
+    if (own is not None and partials.owner_of(dbias) is own and dgain.numel() == C_ and dbias.numel() == C_
+            and _lib.load().pm_affine_bwd_part_slots(rows, C.byref(ns)) == 0):
+        gbuf, goff = own.arena(own.offset(dgain), C_, ns.value)
+        bbuf, boff = own.arena(own.offset(dbias), C_, ns.value)
+        stride = own.entries[(own.offset(dgain), C_)][2]
+        assert own.entries[(own.offset(dbias), C_)][2] == stride
+        _call("pm_affine_bwd_part", _ptr(x), _ptr(gain), _ptr(dout), _ptr(dx), gbuf.data_ptr() + 4 * goff,
+              bbuf.data_ptr() + 4 * boff, stride, ns.value, rows, C_)
+        return
+    _call("pm_affine_bwd", _ptr(x), _ptr(gain), _ptr(dout), _ptr(dx), _ptr(dgain), _ptr(dbias), rows, C_)
 
 
 def dmol_ll_fwd(params, value, ll, nm: int, P: int, low: float = 0.0, high: float = 255.0) -> None:
@@ -1443,6 +1458,12 @@ def vdvae_loss(rec, kl, pm_kl, num_dims: float, out) -> None:
 
 def sumsq(x, out) -> None:
     _call("pm_sumsq", _ptr(x), x.numel(), _ptr(out))
+
+
+def sumsq_det(x, out, scratch) -> None:
+    """sum x^2 added in a fixed order (scratch: >= 1026 floats, zero before its first use)"""
+    assert scratch.numel() >= 1026
+    _call("pm_sumsq_det", _ptr(x), x.numel(), _ptr(out), _ptr(scratch))
 
 
 def adam_step_clip_ema(p, g, m, v, ema, n_decay, count_dev, gnorm_sq, cfg: _lib.AdamCfg, clip: float, ema_rate: float,

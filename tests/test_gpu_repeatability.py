@@ -2,9 +2,10 @@
 
 Round 4: every weight / bias gradient leaves its kernel as per-split PARTIAL SUMS (plain stores) that pm_reduce_partials adds in
 a fixed order, and no split-K data gradient runs in the PM-VAE step - its gradients are asserted BIT-IDENTICAL between runs
-(what jax.grad gives the reference, train_pm_vae.py:58-72).  The VDVAE and the PixelCNN still hold a few atomic accumulations
-outside the weight-gradient family (embedding scatter, per-resolution bias sums, split-K data gradients of short grids): their
-convolution / dense WEIGHT gradients are asserted bit-identical, everything else within 1e-5 of the tensor's own largest entry -
+(what jax.grad gives the reference, train_pm_vae.py:58-72).  The VDVAE's too (its last atomics - the gain / bias sums of the
+final affine and the global gradient norm - became partial sums / a fixed-order sum), step and parameter EMA included.  The
+PixelCNN still holds atomic accumulations outside the weight-gradient family (embedding scatter, split-K data gradients of
+short grids at small batches): its gradients are compared within 1e-5 of the tensor's own largest entry -
 well above the level an f32 sum of a few thousand terms moves when its order changes; the hazard this test was written for
 (the packed-FP32 instability of the thin weight-gradient kernel) produced 1e-4 ... 1e-2."""
 import numpy as np
@@ -80,7 +81,30 @@ def test_vdvae_gradients_repeat():
         m.backward()
         torch.cuda.synchronize()
         runs.append({n: t.clone() for n, t in m.grads_dict().items()})
-    _compare(runs)
+    assert _compare(runs, exact=lambda name: True) == []          # round 4: affine_bwd's gain / bias sums were the last atomics
+
+
+def test_vdvae_train_step_is_bit_reproducible():
+    """two VDVAETrainStep objects from the same seed (fused Blocks, grouped weight gradients on side streams, global-norm
+    clip through pm_sumsq_det, parameter EMA): parameters AND EMA equal bit for bit after 4 optimizer steps"""
+    from posterior_matching_amd.engine import VDVAETrainStep
+    from tests.ref_configs import pm_vdvae_mnist
+    from tests.test_gpu_vdvae import _setup, f32d
+
+    finals = []
+    for _ in range(2):
+        cfg = pm_vdvae_mnist()
+        m, _, x, b, eps = _setup(cfg, 8, seed=8, bf16x3=True)
+        ts = VDVAETrainStep(m, cfg["lr"], 8, gradient_clip=cfg["gradient_clip"], ema_rate=cfg["ema_rate"], seed=5,
+                            external_eps=True)
+        ts.set_batch(f32d(x), f32d(b), [f32d(e) for e in eps])
+        for _ in range(4):
+            ts.step()
+        ts.synchronize()
+        finals.append((m.store.flat_p.clone(), ts.ema.clone(), ts.read_metrics()["loss"]))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+    # (the reported loss sums per-example KL / log-likelihood values with atomics: a metric, equal to ~1e-7 relative only)
+    assert abs(finals[0][2] - finals[1][2]) <= 1e-5 * abs(finals[0][2])
 
 
 def test_pm_vqvae_gradients_repeat():
@@ -102,4 +126,4 @@ def test_pm_vqvae_gradients_repeat():
             ts.penc.backward(ts.pcnn.backward(ts.g_ll))
         ts.synchronize()
         runs.append({n: t.clone() for n, t in ts.store.to_dict("g").items()})
-    _compare(runs)
+    print("pm_vqvae: not bit-identical between runs:", _compare(runs))
