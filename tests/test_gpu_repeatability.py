@@ -107,13 +107,14 @@ def test_vdvae_train_step_is_bit_reproducible():
     assert abs(finals[0][2] - finals[1][2]) <= 1e-5 * abs(finals[0][2])
 
 
-def test_pm_vqvae_gradients_repeat():
+@pytest.mark.parametrize("B", [32, 256])
+def test_pm_vqvae_gradients_repeat(B):
     from posterior_matching_amd import ops
     from tests.ref_configs import pm_vqvae_mnist, vqvae_mnist
     from tests.test_gpu_pixelcnn import _batch, _stage2, f32d
 
     cfg, vq_cfg = pm_vqvae_mnist(), vqvae_mnist()["model"]
-    B, xs = 32, (28, 28, 1)
+    xs = (28, 28, 1)
     ts, _, _, _ = _stage2(cfg, vq_cfg, xs, B, seed=6, bf16x3=True)
     x, b = _batch(np.random.default_rng(2), B, xs)
     ts.set_batch(f32d(x), f32d(b))
