@@ -163,6 +163,7 @@ SIGNATURES = {
     "pm_gmm_logprob_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "pm_embed_fwd": [_P, _P, _P, _P, _LL, _I, _I],
     "pm_embed_bwd": [_P, _P, _P, _P, _LL, _I, _I],
+    "pm_embed_bwd_exact": [_P, _P, _P, _P, _LL, _I, _I, _P],
     "pm_concat_elu_fwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_concat_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P],
     "pm_gate_bwd_rows_sum": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],

@@ -36,39 +36,71 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
     atomicAdd(dtable + (size_t)k * F + f, dout[i]);
 }
 
-// The same scatter-add WITHOUT atomics (round 4): one wave owns one table row k, scans the index vector 64 rows at a time
-// (coalesced), and for every match - in increasing row order, so the sum has the same bits in every run - adds that row of
-// dout (F <= 1024: up to four 16-byte vectors per lane) to its registers; the table row is read-modified-written once by its
-// owner.  12 544 rows x 512 codes: every wave scans 50 KB of indices and reads ~25 matching rows, against 3.2 M f32
-// atomics onto a 512 KB table (170 us at the memory side, the embedding's gradient different in every run).
-__global__ __launch_bounds__(256) void embed_bwd_scan_kernel(const int* __restrict__ idx, const float* __restrict__ dout,
-                                                              float* __restrict__ dtable, long long rows, int F, int K) {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= K) return;                                        // wave-uniform
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nv = F >> 2;                                     // 16-byte vectors per row (F % 4 == 0)
-    for (long long r0 = 0; r0 < rows; r0 += 64) {
-        const long long r = r0 + lane;
-        int kk = r < rows ? idx[r] : -1;
-        if (r < rows) kk = kk < 0 ? 0 : (kk >= K ? K - 1 : kk);   // jnp indexing clamps out-of-range indices
-        unsigned long long m = __ballot(kk == k);
-        while (m) {
-            const int bit = __builtin_ctzll(m);
-            m &= m - 1;
-            const f32x4* row = reinterpret_cast<const f32x4*>(dout + (size_t)(r0 + bit) * F);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (lane + 64 * j < nv) acc[j] += row[lane + 64 * j];
-        }
+// The same scatter-add with an ORDER-INDEPENDENT result (round 4): every contribution is converted to 64-bit fixed point and
+// added with integer atomics - integer addition is associative, so the sum has the same bits whatever order the memory side
+// applies the atomics in - then converted back once per table element.  The scale is a power of two chosen per call from
+// max |dout| (itself order-independent) so that rows x max cannot overflow 62 bits: the fixed-point sum is EXACT to
+// 2^-(62 - log2 rows) of the largest possible sum, i.e. more accurate than an f32 accumulation.  A non-finite dout gives NaN rows
+// (as the f32 sum would).  (One wave per table row scanning the index vector - no atomics at all - was measured first: 11.5 ms
+// per pm_vqvae_mnist step against 9.75: early in training a handful of codes own thousands of rows each, and their waves add
+// those rows one after the other.)
+__global__ __launch_bounds__(256) void embed_amax_kernel(const float* __restrict__ dout, long long total, unsigned* __restrict__ amax) {
+    unsigned m = 0u;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const unsigned u = __builtin_bit_cast(unsigned, dout[i]) & 0x7fffffffu;     // |x| as bits: monotone, NaN above inf
+        m = u > m ? u : m;
     }
-    f32x4* dst = reinterpret_cast<f32x4*>(dtable + (size_t)k * F);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (lane + 64 * j < nv) dst[lane + 64 * j] = dst[lane + 64 * j] + acc[j];
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = __shfl_xor(m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(amax, m);
 }
+
+// scale = 2^e with rows * max|dout| * 2^e < 2^61 (e from the exponent bits of the maximum; 0 when everything is zero)
+__device__ __forceinline__ bool embed_scale(unsigned amax_bits, long long rows, double& scale) {
+    if (amax_bits >= 0x7f800000u) return false;                 // inf / NaN somewhere
+    const int ex = (int)(amax_bits >> 23) - 127 + 1;            // max|dout| < 2^ex
+    int lr = 0;
+    while ((1LL << lr) < rows) ++lr;                            // rows <= 2^lr
+    scale = ldexp(1.0, 61 - lr - ex);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_fixed_kernel(const int* __restrict__ idx, const float* __restrict__ dout,
+                                                               unsigned long long* __restrict__ acc, const unsigned* __restrict__ amax,
+                                                               long long total, long long rows, int F, int K) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    double scale;
+    if (!embed_scale(amax[0], rows, scale)) return;             // the finalize kernel writes NaN
+    const long long r = i / F;
+    const int f = (int)(i - r * F);
+    int k = idx[r];
+    k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+    const long long q = __double2ll_rn((double)dout[i] * scale);
+    if (q) atomicAdd(acc + (size_t)k * F + f, (unsigned long long)q);
+}
+
+__global__ __launch_bounds__(256) void embed_finalize_kernel(unsigned long long* __restrict__ acc, const unsigned* __restrict__ amax,
+                                                              float* __restrict__ dtable, long long n, long long rows) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double scale;
+    if (!embed_scale(amax[0], rows, scale)) {
+        dtable[i] = __builtin_nanf("");
+        return;
+    }
+    const long long q = (long long)acc[i];
+    if (q) {
+        dtable[i] += (float)((double)q / scale);
+        acc[i] = 0ull;                                          // left zero for the next call
+    }
+}
+
+__global__ void embed_reset_kernel(unsigned* amax) { amax[0] = 0u; }
 
 // logical x = [a | b] (widths Ca, Cb; b may be absent) ; out[r] = [elu(x) | elu(-x)] * drop[r]
 __global__ __launch_bounds__(256) void concat_elu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -522,17 +554,29 @@ extern "C" int pm_embed_fwd(pm_stream_t stream, const int* idx, const float* tab
 extern "C" int pm_embed_bwd(pm_stream_t stream, const int* idx, const float* dout, float* dtable, long long rows, int F,
                             int K) {
     if (!idx || !dout || !dtable || rows <= 0 || F <= 0 || K <= 0) return PM_EINVAL;
-    static const bool scan_off = getenv("PM_EMBED_ATOMIC") != nullptr;        // A/B switch for measurements
-    if (!scan_off && F % 4 == 0 && F <= 1024 && al16(dout) && al16(dtable)) {
-        PM_KTAG("embed_bwd_scan_kernel");
-        hipLaunchKernelGGL(embed_bwd_scan_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, dout,
-                           dtable, rows, F, K);
-        return pm_check_launch("pm_embed_bwd(scan)");
-    }
     PM_KTAG("embed_bwd_kernel");
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, idx, dout, dtable,
                        rows * F, F, K);
     return pm_check_launch("pm_embed_bwd");
+}
+
+extern "C" int pm_embed_bwd_exact(pm_stream_t stream, const int* idx, const float* dout, float* dtable, long long rows, int F,
+                                  int K, void* scratch) {
+    if (!idx || !dout || !dtable || !scratch || rows <= 0 || F <= 0 || K <= 0 || (reinterpret_cast<size_t>(scratch) & 7))
+        return PM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(scratch);
+    unsigned* amax = reinterpret_cast<unsigned*>(acc + (size_t)K * F);
+    const long long total = rows * F;
+    long long ab = (total + 255) / 256;
+    if (ab > 1024) ab = 1024;
+    hipLaunchKernelGGL(embed_reset_kernel, dim3(1), dim3(1), 0, s, amax);
+    hipLaunchKernelGGL(embed_amax_kernel, dim3((unsigned)ab), dim3(256), 0, s, dout, total, amax);
+    PM_KTAG("embed_bwd_fixed_kernel");
+    hipLaunchKernelGGL(embed_bwd_fixed_kernel, dim3(blocks_for(total)), dim3(256), 0, s, idx, dout, acc, amax, total, rows, F, K);
+    hipLaunchKernelGGL(embed_finalize_kernel, dim3(blocks_for((long long)K * F)), dim3(256), 0, s, acc, amax, dtable,
+                       (long long)K * F, rows);
+    return pm_check_launch("pm_embed_bwd_exact");
 }
 
 extern "C" int pm_concat_elu_fwd(pm_stream_t stream, const float* a, const float* b, const float* drop, float* out,

@@ -976,9 +976,23 @@ def embed_fwd(idx, table, out) -> None:
     _call("pm_embed_fwd", _iptr(idx), _ptr(table), _ptr(out), idx.numel(), F, K)
 
 
+_embed_scratch = {}
+
+
 def embed_bwd(idx, dout, dtable) -> None:
+    """dtable[idx[r]] += dout[r]: 64-bit fixed-point integer atomics (pm_embed_bwd_exact) - the same bits in every run;
+    PM_EMBED_ATOMIC=1: the f32-atomic form (A/B)"""
     K, F = dtable.shape
-    _call("pm_embed_bwd", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K)
+    if os.environ.get("PM_EMBED_ATOMIC"):
+        _call("pm_embed_bwd", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K)
+        return
+    key = (dtable.data_ptr(), K, F)
+    scratch = _embed_scratch.get(key)
+    if scratch is None:
+        if len(_embed_scratch) > 64:
+            _embed_scratch.clear()
+        scratch = _embed_scratch[key] = torch.zeros(K * F + 1, dtype=torch.int64, device=dtable.device)
+    _call("pm_embed_bwd_exact", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K, scratch.data_ptr())
 
 
 @dataclass
