@@ -127,4 +127,25 @@ def test_pm_vqvae_gradients_repeat(B):
             ts.penc.backward(ts.pcnn.backward(ts.g_ll))
         ts.synchronize()
         runs.append({n: t.clone() for n, t in ts.store.to_dict("g").items()})
-    print("pm_vqvae: not bit-identical between runs:", _compare(runs))
+    inexact = _compare(runs, exact=(lambda name: True) if B == 256 else (lambda name: False))
+    # B = 256 (the benchmarked batch): every gradient bit-identical - weight gradients as partial sums, the embedding
+    # scatter in order-independent fixed point; B = 32: the short grids split K over workgroups and meet with f32 atomics
+    print(f"pm_vqvae B = {B}: not bit-identical between runs: {len(inexact)} tensors")
+
+
+def test_pm_vqvae_train_step_is_bit_reproducible():
+    """two PMVQVAETrainStep objects (35.0 M trainable parameters, in-place Philox dropout, two chains, grouped weight gradients)
+    from the same seeds at the benchmarked batch: parameters equal bit for bit after 3 optimizer steps"""
+    from tools.workloads import build
+
+    finals = []
+    for _ in range(2):
+        w = build("pm_vqvae_mnist", 256)
+        w.feed()
+        for _ in range(3):
+            w.step()
+        w.synchronize()
+        finals.append(w.ts.store.flat_p.clone())
+        del w
+        torch.cuda.empty_cache()
+    assert torch.equal(finals[0], finals[1])
