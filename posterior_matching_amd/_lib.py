@@ -121,6 +121,9 @@ SIGNATURES = {
     "pm_gather_wgrad": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P],
     "pm_gather_gemm_bf16": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],
     "pm_gather_gemm_bf16_dual": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P, _P, _I],
+    "pm_gemm_splitk_floats": [C.POINTER(GatherDesc), _I, _I, C.POINTER(C.c_longlong)],
+    "pm_gather_gemm_sk": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P, _P, C.c_longlong],
+    "pm_gather_gemm_bf16_sk": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P, _P, _I, _P, C.c_longlong],
     "pm_gather_gemm_bf16_insum": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P, _P],
     "pm_image_conv_insum_applies": [C.POINTER(GatherDesc)],
     "pm_split_weights": [_P, _P, _P, _P, _I, _I],
@@ -153,7 +156,9 @@ SIGNATURES = {
     "pm_tril_sample_kl_bwd2": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "pm_normal_ll_fwd": [_P, _P, _P, _P, _P, _I, _I, _F],
     "pm_normal_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F],
+    "pm_normal_ll_bwd_det": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "pm_vq_select": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "pm_vq_dw_exact": [_P, _P, _P, _P, _I, _I, _I],
     "pm_vq_ema_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F],
     "pm_vq_lookup": [_P, _P, _P, _P, _I, _I, _I],
     "pm_vqvae_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],

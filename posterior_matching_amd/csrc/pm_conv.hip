@@ -50,6 +50,10 @@ struct GemmArgs {
     float* out2;   // optional second store: out2 = act2(out) (a layer's pre-activation AND its activation in one launch)
     int act2;
     float* in_colsum;   // image-resident form only: in_colsum[c] += sum over every position of in[.., c] (a bias gradient)
+    // split-K slabs (round 4): sk != NULL -> K-slice ks STORES its partial tile into sk + ks * sk_stride (one writer per
+    // element) and the epilogue kernel adds the slices in order - no zero-fill, no f32 atomics, run-to-run identical outputs
+    float* sk;
+    long long sk_stride;
 };
 
 struct WgradArgs {
@@ -564,9 +568,13 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmArgs p) {
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
         if (p.ksplit > 1) {  // partial sum of a K slice: the epilogue kernel finishes the tile
+            float* slab = p.sk ? p.sk + (size_t)ks * p.sk_stride : nullptr;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (ro[e] >= 0) atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+                if (ro[e] >= 0) {
+                    if (slab) slab[(size_t)ro[e] + n] = acc[r][e];
+                    else atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+                }
             continue;
         }
         pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, nullptr, PM_ACT_NONE, g.aux_act, g.out_act, g.slope);
@@ -584,7 +592,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p, long l
     const long long stride = (long long)gridDim.x * 256;
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total_per_group; o += stride) {
         int n = (int)(o % g.N);
-        float v = out[o] + (bias ? bias[n] : 0.f);
+        float sum;
+        if (p.sk) {                                    // K slices in slabs: added in slice order (groups == 1 with split-K)
+            sum = 0.f;
+            for (int ks = 0; ks < p.ksplit; ++ks) sum += p.sk[(size_t)ks * p.sk_stride + o];
+        } else {
+            sum = out[o];
+        }
+        float v = sum + (bias ? bias[n] : 0.f);
         v = pm_epilogue(v, aux, res, o, g.aux_act, g.out_act, g.slope);
         out[o] = v;
         if (p.out2) p.out2[(size_t)grp * p.out_gs + o] = pm_act(v, p.act2, g.slope);
@@ -809,9 +824,13 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
         if (p.ksplit > 1) {
+            float* slab = p.sk ? p.sk + (size_t)ks * p.sk_stride : nullptr;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (ro[e] >= 0) atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+                if (ro[e] >= 0) {
+                    if (slab) slab[(size_t)ro[e] + n] = acc[r][e];
+                    else atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+                }
             continue;
         }
         pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, nullptr, PM_ACT_NONE, g.aux_act, g.out_act, g.slope);
@@ -1083,9 +1102,13 @@ __global__ __launch_bounds__(256) void direct_gemm_bf16_kernel(GemmArgs p, const
         if (n >= g.N) continue;
         float bv = bias ? bias[n] : 0.f;
         if (p.ksplit > 1) {
+            float* slab = p.sk ? p.sk + (size_t)ks * p.sk_stride : nullptr;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (ro[e] >= 0) atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+                if (ro[e] >= 0) {
+                    if (slab) slab[(size_t)ro[e] + n] = acc[r][e];
+                    else atomicAdd(out + (size_t)ro[e] + n, acc[r][e]);
+                }
             continue;
         }
         pm_epilogue_tile(acc[r], ro, n, bv, aux, res, out, p.out2 ? p.out2 + (size_t)grp * p.out_gs : nullptr, p.act2, g.aux_act,
@@ -4114,10 +4137,13 @@ __global__ __launch_bounds__(256, BMC == 32 ? 3 : 2) void gather_wgrad_bf16_big_
 
 }  // namespace
 
-extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w,
-                              const float* bias, const float* aux, const float* res, float* out) {
+// sk / sk_floats: caller's slab scratch for the split-K form (NULL: f32 atomics into the zero-filled output, as before round 4);
+// query != NULL: no launch, *query = floats of scratch this problem's split-K form wants (0: it does not split K)
+static int gather_gemm_impl(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w, const float* bias,
+                            const float* aux, const float* res, float* out, float* sk, long long sk_floats,
+                            long long* query) {
     GemmArgs a;
-    if (!fill_geom(d, a.g, true) || !in || !w || !out) return PM_EINVAL;
+    if (!fill_geom(d, a.g, true) || (!query && (!in || !w || !out))) return PM_EINVAL;
     a.in = in; a.w = w; a.bias = bias; a.aux = aux; a.res = res; a.out = out;
     a.out2 = nullptr; a.act2 = PM_ACT_NONE; a.in_colsum = nullptr;
     a.in_gs = d->in_gs; a.w_gs = d->w_gs; a.out_gs = d->out_gs; a.bias_gs = d->bias_gs;
@@ -4126,8 +4152,16 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
     const int G = d->groups;
     const GemmPlan p = plan_gemm(a.g, G, vec4);
     a.ksplit = p.ksplit;
+    a.sk = nullptr; a.sk_stride = (long long)a.g.M * a.g.N;
+    if (query) {
+        *query = p.ksplit > 1 ? a.sk_stride * p.ksplit : 0;
+        return PM_OK;
+    }
     if (p.ksplit > 1) {
-        if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
+        if (sk) {
+            if (sk_floats < a.sk_stride * p.ksplit || !aligned16(sk)) return PM_EINVAL;
+            a.sk = sk;
+        } else if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
     }
     if (p.direct) {
         const int rn = a.g.N > 32 ? 2 : 1;
@@ -4149,6 +4183,18 @@ extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks, G), dim3(256), 0, s, a, total);
     }
     return pm_check_launch("pm_gather_gemm");
+}
+
+extern "C" int pm_gather_gemm(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w,
+                              const float* bias, const float* aux, const float* res, float* out) {
+    return gather_gemm_impl(stream, d, in, w, bias, aux, res, out, nullptr, 0, nullptr);
+}
+
+extern "C" int pm_gather_gemm_sk(pm_stream_t stream, const pm_gather_desc* d, const float* in, const float* w,
+                                 const float* bias, const float* aux, const float* res, float* out, float* scratch,
+                                 long long scratch_floats) {
+    if (!scratch) return PM_EINVAL;
+    return gather_gemm_impl(stream, d, in, w, bias, aux, res, out, scratch, scratch_floats, nullptr);
 }
 
 // Partial-sum mode of the weight-gradient entry points.  `part` != NULL: dw / db are ignored, the launch STORES into the arenas
@@ -4237,9 +4283,16 @@ static bool image_insum_ok(const Geom& g, const ImagePlan& ip) {
 
 static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
                                  const float* bias, const float* aux, const float* res, float* out, float* out2, int act2,
-                                 float* in_colsum = nullptr) {
+                                 float* in_colsum = nullptr, float* sk = nullptr, long long sk_floats = 0,
+                                 long long* query = nullptr) {
     GemmArgs a;
     a.out2 = out2; a.act2 = act2; a.in_colsum = in_colsum;
+    a.sk = nullptr; a.sk_stride = 0;
+    if (query) {                                       // pm_gemm_splitk_floats: the dispatch below without its launches
+        *query = 0;
+        static float dummy_in[4] __attribute__((aligned(16)));
+        in = dummy_in; wsplit = dummy_in; out = dummy_in;
+    }
     if (!fill_geom(d, a.g, true) || !in || !wsplit || !out) return PM_EINVAL;
     if (d->C % 8 != 0 || (d->groups != 1 && d->w_gs % 8 != 0)) return PM_EINVAL;   // C % 32 != 0: zero-padded weight chunks
     if (!aligned16(in) || !aligned16(wsplit) || (d->in_gs % 4) != 0) return PM_EINVAL;
@@ -4271,6 +4324,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     }
     if (plan_skinny(a.g, G)) {                         // one output position, few rows, long K: one launch, K over the waves
         a.ksplit = 1;
+        if (query) return PM_OK;
         PM_KTAG("skinny_gemm_bf16_kernel");
         hipLaunchKernelGGL(skinny_gemm_bf16_kernel, dim3((a.g.M + 15) / 16, (a.g.N + 15) / 16), dim3(64 * SK_NW), 0, s, a, ws,
                            npad, plane);
@@ -4280,6 +4334,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     static const bool image_off = getenv("PM_NO_IMAGE_CONV") != nullptr;   // A/B switch for measurements
     if (!image_off && plan_image(a.g, G, ip)) {       // whole input image of a workgroup resident in LDS
         a.ksplit = 1;
+        if (query) return PM_OK;
         if (ip.nw == 8 && ip.t == 4) launch_image<8, 4>(ip, s, a, ws, npad, plane);
         else if (ip.nw == 8 && ip.t == 2) launch_image<8, 2>(ip, s, a, ws, npad, plane);
         else if (ip.nw == 8) launch_image<8, 1>(ip, s, a, ws, npad, plane);
@@ -4290,6 +4345,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     }
     if (!image_off && plan_image_d2(a.g, G, ip)) {    // zero-dilated problems: class-major walk over the resident source image
         a.ksplit = 1;
+        if (query) return PM_OK;
         if (ip.t == 4) launch_image_d2<4>(ip, s, a, ws, npad, plane);
         else if (ip.t == 2) launch_image_d2<2>(ip, s, a, ws, npad, plane);
         else launch_image_d2<1>(ip, s, a, ws, npad, plane);
@@ -4299,6 +4355,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     static const bool patch_off = getenv("PM_NO_PATCH") != nullptr;      // A/B switch for measurements
     if (!patch_off && plan_patch(a.g, G, rn, pp)) {   // stride-1 convs on grids >= 12 wide: patch-staged form
         a.ksplit = 1;
+        if (query) return PM_OK;
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_bf16_kernel<1>),
@@ -4332,6 +4389,7 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     const int rn_d2 = a.g.N > 32 ? 2 : 1;
     if (!d2_off && plan_patch_d2(a.g, G, rn_d2, pd)) {   // zero-dilated problems: four residue classes off one staged patch
         a.ksplit = 1;
+        if (query) return PM_OK;
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_d2_bf16_kernel<1>),
@@ -4347,8 +4405,16 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     }
     const GemmPlan p = plan_gemm(a.g, G, true);
     a.ksplit = p.ksplit;
+    a.sk_stride = (long long)a.g.M * a.g.N;
+    if (query) {
+        *query = p.ksplit > 1 ? a.sk_stride * p.ksplit : 0;
+        return PM_OK;
+    }
     if (p.ksplit > 1) {
-        if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
+        if (sk) {
+            if (sk_floats < a.sk_stride * p.ksplit || !aligned16(sk)) return PM_EINVAL;
+            a.sk = sk;
+        } else if (pm_zero_async(s, out, (size_t)a.g.M * a.g.N * sizeof(float))) return PM_ELAUNCH;
     }
     dim3 grid((a.g.M + 127) / 128, (a.g.N + 32 * rn - 1) / (32 * rn), G * a.ksplit);
     if (rn == 1 && d->d == 1) launch_direct_bf16<1, 1>(s, a, grid, ws, npad, plane);
@@ -4397,6 +4463,26 @@ extern "C" int pm_gather_gemm_bf16_dual(pm_stream_t stream, const pm_gather_desc
                                         int act2) {
     if (!out2) return PM_EINVAL;
     return gather_gemm_bf16_impl(stream, d, in, wsplit, bias, aux, res, out, out2, act2);
+}
+
+// Split-K without atomics (round 4): the K slices of a short-grid GEMM store their partial tiles into the caller's scratch slabs
+// and the epilogue kernel adds them in slice order.  pm_gemm_splitk_floats: how many floats of scratch (0: this problem does not
+// split K - any scratch is ignored).  scratch == NULL is PM_EINVAL in the _sk entry points; the plain entry points keep the
+// f32-atomic form.
+extern "C" int pm_gemm_splitk_floats(const pm_gather_desc* d, int bf16, int in_aligned16, long long* floats) {
+    if (!d || !floats) return PM_EINVAL;
+    *floats = 0;
+    if (bf16) return gather_gemm_bf16_impl(nullptr, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, PM_ACT_NONE,
+                                           nullptr, nullptr, 0, floats);
+    const float* fake = in_aligned16 ? reinterpret_cast<const float*>(16) : reinterpret_cast<const float*>(4);
+    return gather_gemm_impl(nullptr, d, fake, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, floats);
+}
+
+extern "C" int pm_gather_gemm_bf16_sk(pm_stream_t stream, const pm_gather_desc* d, const float* in, const void* wsplit,
+                                      const float* bias, const float* aux, const float* res, float* out, float* out2,
+                                      int act2, float* scratch, long long scratch_floats) {
+    if (!scratch) return PM_EINVAL;
+    return gather_gemm_bf16_impl(stream, d, in, wsplit, bias, aux, res, out, out2, act2, nullptr, scratch, scratch_floats);
 }
 
 extern "C" int pm_split_weights(pm_stream_t stream, const float* params, void* out_bf16, const pm_split_job* jobs_dev,

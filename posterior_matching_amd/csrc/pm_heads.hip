@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void normal_ll_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void normal_ll_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ x,
                                                               const float* __restrict__ log_scale,
                                                               const float* __restrict__ g, float* __restrict__ dloc,
-                                                              float* __restrict__ d_log_scale, int D, float scale_eps) {
+                                                              float* __restrict__ d_log_scale, int D, float scale_eps,
+                                                              float* __restrict__ scratch) {
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * D;
     const float e = expf(log_scale[0]);
@@ -288,7 +289,37 @@ __global__ __launch_bounds__(256) void normal_ll_bwd_kernel(const float* __restr
         s += gb * (u * u - 1.f);  // sigma * d/d sigma of (-0.5 u^2 - log sigma)
     }
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) atomicAdd(d_log_scale, s * e * inv);  // d sigma / d log_scale = exp(log_scale)
+    if (!scratch) {
+        if (threadIdx.x == 0) atomicAdd(d_log_scale, s * e * inv);  // d sigma / d log_scale = exp(log_scale)
+        return;
+    }
+    // fixed-order form: every example's term goes to scratch[b]; the workgroup that draws the last ticket adds them in example
+    // order and makes the ONE += - the same bits on every run (the atomic form adds the B terms in arrival order)
+    __shared__ int last;
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + gridDim.x);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(scratch + blockIdx.x, s * e * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int nb = (int)gridDim.x;
+    const int per = (nb + 255) / 256;                       // thread t: examples [t * per, (t + 1) * per)
+    float t = 0.f;
+    for (int i = threadIdx.x * per; i < nb && i < (threadIdx.x + 1) * per; ++i)
+        t += __hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ float fin[256];
+    fin[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 256; ++i) tot += fin[i];
+        d_log_scale[0] += tot;
+        *ticket = 0u;
+    }
 }
 
 // DiagonalGaussian head (reference distributions.py:58-84): params [B, 2k] = (loc | raw), scale = softplus(raw) + 1e-5.
@@ -548,8 +579,18 @@ extern "C" int pm_normal_ll_bwd(pm_stream_t stream, const float* loc, const floa
                                 const float* g, float* dloc, float* d_log_scale, int B, int D, float scale_eps) {
     if (!loc || !x || !log_scale || !g || !dloc || !d_log_scale || B <= 0 || D <= 0) return PM_EINVAL;
     hipLaunchKernelGGL(normal_ll_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, x, log_scale, g, dloc,
-                       d_log_scale, D, scale_eps);
+                       d_log_scale, D, scale_eps, (float*)nullptr);
     return pm_check_launch("pm_normal_ll_bwd");
+}
+
+// scratch: B + 1 floats, the last one zero before the first call (the kernel leaves it zero)
+extern "C" int pm_normal_ll_bwd_det(pm_stream_t stream, const float* loc, const float* x, const float* log_scale,
+                                    const float* g, float* dloc, float* d_log_scale, int B, int D, float scale_eps,
+                                    float* scratch) {
+    if (!loc || !x || !log_scale || !g || !dloc || !d_log_scale || !scratch || B <= 0 || D <= 0) return PM_EINVAL;
+    hipLaunchKernelGGL(normal_ll_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, x, log_scale, g, dloc,
+                       d_log_scale, D, scale_eps, scratch);
+    return pm_check_launch("pm_normal_ll_bwd_det");
 }
 
 extern "C" int pm_mask_concat(pm_stream_t stream, const float* x, const float* b, float* out, long long R, int C,

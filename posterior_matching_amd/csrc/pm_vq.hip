@@ -116,6 +116,38 @@ __global__ __launch_bounds__(64 * VQ_WAVES) void vq_select_kernel(
     }
 }
 
+// dw[d, k] = sum over the rows assigned to code k of z[row, d], WITHOUT atomics: one workgroup per code walks the index array
+// (N ints, L2-resident after the first workgroup) with RL row lanes x D dimension lanes; a lane adds its matching rows in
+// ascending row order, the RL lane sums are added in lane order.  The result is an exact function of (z, idx) - the same bits
+// on every run - where the LDS / global float atomics of vq_select_kernel add in arrival order.  Every dw element is written
+// (zeros for unused codes), so no zero-fill precedes it.
+__global__ __launch_bounds__(1024) void vq_dw_exact_kernel(const float* __restrict__ z, const int* __restrict__ idx,
+                                                            float* __restrict__ dw, int N, int D, int K, int RL) {
+    __shared__ float part[1024];
+    const int k = blockIdx.x;
+    const int l = threadIdx.x / D, d = threadIdx.x - l * D;
+    float s = 0.f;
+    if (l < RL) {
+        int r = l;
+        for (; r + 3 * RL < N; r += 4 * RL) {            // four independent index loads in flight
+            const int i0 = idx[r], i1 = idx[r + RL], i2 = idx[r + 2 * RL], i3 = idx[r + 3 * RL];
+            if (i0 == k) s += z[(size_t)r * D + d];
+            if (i1 == k) s += z[(size_t)(r + RL) * D + d];
+            if (i2 == k) s += z[(size_t)(r + 2 * RL) * D + d];
+            if (i3 == k) s += z[(size_t)(r + 3 * RL) * D + d];
+        }
+        for (; r < N; r += RL)
+            if (idx[r] == k) s += z[(size_t)r * D + d];
+        part[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (l == 0) {
+        float t = 0.f;
+        for (int j = 0; j < RL; ++j) t += part[j * D + d];
+        dw[(size_t)d * K + k] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void vq_lookup_kernel(const int* __restrict__ idx, const float* __restrict__ emb,
                                                          float* __restrict__ quant, long long total, int D, int K) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -223,6 +255,13 @@ extern "C" int pm_vq_select(pm_stream_t stream, const float* z, const float* emb
                            counts, dw, N, D, K, commit_coef);
     }
     return pm_check_launch("pm_vq_select");
+}
+
+extern "C" int pm_vq_dw_exact(pm_stream_t stream, const float* z, const int* idx, float* dw, int N, int D, int K) {
+    if (!z || !idx || !dw || N <= 0 || D <= 0 || D > 1024 || K <= 0) return PM_EINVAL;
+    const int RL = 1024 / D;
+    hipLaunchKernelGGL(vq_dw_exact_kernel, dim3(K), dim3(1024), 0, (hipStream_t)stream, z, idx, dw, N, D, K, RL);
+    return pm_check_launch("pm_vq_dw_exact");
 }
 
 extern "C" int pm_vq_ema_update(pm_stream_t stream, const float* counts, const float* dw, float* cs_hidden,

@@ -400,6 +400,28 @@ def _detail(d: GatherDesc) -> str:
     return (f"B{d.B} in{d.IH}x{d.IW}x{d.C} out{d.OH}x{d.OW}x{d.N} k{d.KH} a{d.a} d{d.d} g{d.groups}")
 
 
+_SK_SCRATCH: dict = {}      # stream -> [float32 tensors]: slab scratch of the split-K GEMMs launched on that stream
+SPLITK_SLABS = not os.environ.get("PM_SPLITK_ATOMIC")      # A/B knob: the f32-atomic split-K of rounds 1-3
+
+
+def _splitk_scratch(desc: GatherDesc, bf16: bool, inp):
+    """The slab scratch of a GEMM that splits K (pm_gemm_splitk_floats), None when it does not.  One buffer per stream, reused by
+    every launch on it (stream order keeps a launch's epilogue ahead of the next launch's slices); buffers only ever grow by
+    adding a new one, so a recorded LaunchPlan's pointers stay valid."""
+    if not SPLITK_SLABS:
+        return None
+    n = C.c_longlong(0)
+    if _lib.load().pm_gemm_splitk_floats(C.byref(desc), int(bf16), int(inp.data_ptr() % 16 == 0), C.byref(n)) or n.value <= 0:
+        return None
+    bufs = _SK_SCRATCH.setdefault((inp.device.index, _stream()), [])
+    for t in bufs:
+        if t.numel() >= n.value:
+            return t
+    size = 1 << max(18, (n.value - 1).bit_length())
+    bufs.append(torch.empty(size, dtype=torch.float32, device=inp.device))
+    return bufs[-1]
+
+
 def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
     tag = work = None
     if _timer is not None:
@@ -411,6 +433,11 @@ def gather_gemm(desc: GatherDesc, inp, w, bias, aux, res, out) -> None:
         else:
             tag = f"gather_gemm_kernel<{bm.value},{bn.value},{_MODES[vec.value]}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, w, aux, res, out), "detail": _detail(desc)}
+    sk = _splitk_scratch(desc, False, inp)
+    if sk is not None:
+        _call("pm_gather_gemm_sk", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out),
+              sk.data_ptr(), sk.numel(), tag=tag, work=work)
+        return
     _call("pm_gather_gemm", C.byref(desc), _ptr(inp), _ptr(w), _ptr(bias), _ptr(aux), _ptr(res), _ptr(out), tag=tag,
           work=work)
 
@@ -476,6 +503,11 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=No
         elif _patch_d2_form(desc):
             tag = f"patch_d2_bf16_kernel<{2 if desc.N > 32 else 1}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}
+    sk = _splitk_scratch(desc, True, inp) if in_colsum is None else None
+    if sk is not None:
+        _call("pm_gather_gemm_bf16_sk", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
+              _ptr(out), _ptr(out2), act2, sk.data_ptr(), sk.numel(), tag=tag, work=work)
+        return
     if out2 is not None:
         assert in_colsum is None
         _call("pm_gather_gemm_bf16_dual", C.byref(desc), _ptr(inp), wsplit.data_ptr(), _ptr(bias), _ptr(aux), _ptr(res),
@@ -919,8 +951,19 @@ def normal_ll_fwd(loc, x, log_scale, ll, scale_eps: float = 0.0) -> None:
     _call("pm_normal_ll_fwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(ll), B, x.numel() // B, scale_eps)
 
 
+_NLL_SCRATCH: dict = {}     # (device, stream, B) -> [B + 1] floats: example terms + the ticket of pm_normal_ll_bwd_det
+
+
 def normal_ll_bwd(loc, x, log_scale, g, dloc, d_log_scale, scale_eps: float = 0.0) -> None:
     B = x.shape[0]
+    if not os.environ.get("PM_NLL_ATOMIC"):                 # A/B knob: the f32-atomic d_log_scale of rounds 1-3
+        key = (x.device.index, _stream(), B)               # launches on one stream run in order: one scratch per stream
+        scratch = _NLL_SCRATCH.get(key)
+        if scratch is None:
+            scratch = _NLL_SCRATCH[key] = torch.zeros(B + 1, dtype=torch.float32, device=x.device)
+        _call("pm_normal_ll_bwd_det", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(g), _ptr(dloc), _ptr(d_log_scale), B,
+              x.numel() // B, scale_eps, scratch.data_ptr())
+        return
     _call("pm_normal_ll_bwd", _ptr(loc), _ptr(x), _ptr(log_scale), _ptr(g), _ptr(dloc), _ptr(d_log_scale), B,
           x.numel() // B, scale_eps)
 
@@ -931,6 +974,12 @@ def vq_select(z, emb, dots, e2, idx, quant, commit_grad, sqerr, counts, dw, comm
     D, K = emb.shape
     N = z.numel() // D
     work = {"bytes": _nbytes(z, dots, quant, commit_grad), "detail": f"N{N} D{D} K{K}"}
+    if dw is not None and D <= 1024 and not os.environ.get("PM_VQ_DW_ATOMIC"):     # A/B knob: dw from float atomics
+        _call("pm_vq_select", _ptr(z), _ptr(emb), _ptr(dots), _ptr(e2), _iptr(idx), _ptr(quant), _ptr(commit_grad),
+              _ptr(sqerr), _ptr(counts), None, N, D, K, commit_coef, work=work)
+        _call("pm_vq_dw_exact", _ptr(z), _iptr(idx), _ptr(dw), N, D, K,
+              work={"bytes": _nbytes(z, dw) + 4 * N, "detail": f"N{N} D{D} K{K}"})
+        return
     _call("pm_vq_select", _ptr(z), _ptr(emb), _ptr(dots), _ptr(e2), _iptr(idx), _ptr(quant), _ptr(commit_grad),
           _ptr(sqerr), _ptr(counts), _ptr(dw), N, D, K, commit_coef, work=work)
 

@@ -93,6 +93,9 @@ CONV_CASES = [
     # role-swapped transposed form (flipped taps, gathered = dy), the largest sizes it takes (16 x 16 gathered, 8 x 8 dense)
     ("conv", 64, 14, 64, 64, 5, 2, "SAME"), ("conv", 33, 13, 64, 64, 5, 2, "SAME"), ("conv", 48, 8, 64, 64, 5, 1, "SAME"),
     ("convT", 40, 8, 64, 64, 5, 2, "SAME"), ("conv", 32, 16, 64, 64, 5, 2, "SAME"),
+    # short tile grids under a long K: the split-K form, K slices in slabs added in slice order (8 - 24 slices; the CelebA
+    # PixelCNN's 8 x 8 x 256 layers at per-GPU batch 16, MLP layers at small batch, a ragged one)
+    ("conv", 16, 8, 256, 256, 3, 1, "SAME"), ("dense", 64, 1, 2048, 512, 1, 1, "VALID"), ("dense", 100, 1, 1100, 200, 1, 1, "VALID"),
 ]
 
 
@@ -1150,3 +1153,145 @@ def test_partial_sums_reduce_and_fused_adam(slots):
         assert torch.equal(a, b)                                   # fused == reduce + Adam, bit for bit
     for a, b in zip(outs[0], outs[2]):
         assert torch.equal(a, b)                                   # and the same bits when repeated
+
+
+SPLITK_CASES = [   # kind, B, H, ci, co, k, s, padding, direction
+    ("conv", 16, 8, 256, 256, 3, 1, "SAME", "fwd"), ("conv", 16, 8, 256, 256, 3, 1, "SAME", "dgrad"),
+    ("conv", 2, 14, 64, 64, 5, 2, "SAME", "fwd"), ("convT", 2, 7, 64, 64, 5, 2, "SAME", "dgrad"),
+    ("dense", 64, 1, 2048, 512, 1, 1, "VALID", "fwd"), ("dense", 100, 1, 1100, 200, 1, 1, "VALID", "fwd"),
+    ("conv", 5, 7, 64, 128, 7, 1, "VALID", "fwd"), ("conv", 1, 32, 64, 64, 5, 1, "SAME", "dgrad"),
+]
+
+
+@pytest.mark.parametrize("kind,B,H,ci,co,k,s,padding,direction", SPLITK_CASES)
+def test_splitk_slabs_are_bit_identical_and_agree_with_the_atomic_form(kind, B, H, ci, co, k, s, padding, direction):
+    """Short-grid GEMMs split K over workgroups.  Rounds 1-3 finished them with f32 atomics into a zero-filled output (the last
+    source of run-to-run differences in the data path); now every K slice stores its tile into its own slab and the epilogue
+    adds the slabs in slice order (pm_gather_gemm_sk / pm_gather_gemm_bf16_sk).  Checked: the problem really takes the
+    split-K form (pm_gemm_splitk_floats > 0 on at least one arithmetic), both forms against float64, two slab runs bit for bit,
+    an output buffer full of garbage beforehand (no zero-fill is needed any more), bias + leaky epilogue on the forward case."""
+    import ctypes as C
+
+    from posterior_matching_amd import _lib, ops
+    from posterior_matching_amd.models.core import ParamStore
+    from posterior_matching_amd.ops import ACT_LEAKY, LayerGeom
+
+    gen = torch.Generator().manual_seed(77 + B + ci)
+    geom = (LayerGeom.conv(H, H, ci, co, k, s, padding) if kind == "conv" else
+            LayerGeom.conv_t(H, H, ci, co, k, s, padding) if kind == "convT" else LayerGeom.dense(ci, co))
+    desc = geom._desc(B, direction)
+    want = {}
+    for bf16 in (0, 1):
+        n = C.c_longlong(0)
+        rc = _lib.load().pm_gemm_splitk_floats(C.byref(desc), bf16, 1, C.byref(n))
+        want[bf16] = n.value if rc == 0 else 0
+    assert max(want.values()) > 0, "this case was chosen because it splits K"
+
+    x = g32((B, geom.IH, geom.IW, ci), gen)
+    w = g32(geom.weight_shape, gen, 1.0 / math.sqrt(k * k * ci))
+    bias = g32((co,), gen, 0.1)
+    dy = g32((B, geom.OH, geom.OW, co), gen)
+    xr = x.clone().requires_grad_(True)
+    if kind == "conv":
+        pre = O.conv2d(xr, w, bias, s, padding)
+    elif kind == "convT":
+        pre = O.conv2d_transpose(xr, w, bias, s, padding)
+    else:
+        pre = (xr.reshape(B, ci) @ w + bias).reshape(B, 1, 1, co)
+    if direction == "fwd":
+        ref = O.leaky_relu(pre).detach()
+    else:
+        pre.backward(dy)
+        ref = xr.grad
+
+    d = dev()
+    st = ParamStore()
+    st.add("w", geom.weight_shape, fan_in=1)
+    h = st.request_split("w", geom, direction)
+    st.allocate(d)
+    st.load_dict({"w": w})
+    xd, wd, bd, dyd = x.float().to(d), w.float().to(d), bias.float().to(d), dy.float().to(d)
+
+    def run(wsplit):
+        out = torch.full(tuple(ref.shape), float("nan"), device=d)       # garbage in the output: nothing may depend on it
+        if direction == "fwd":
+            ops.layer_forward(geom, xd, wd, bd, out, out_act=ACT_LEAKY, wsplit=wsplit)
+        else:
+            ops.layer_dgrad(geom, dyd, wd, out, wsplit=wsplit)
+        return out
+
+    for bf16, wsplit in ((0, None), (1, st.split_view(h))):
+        if bf16 and wsplit is None:
+            continue
+        tol = 3e-5 if bf16 else 2e-6
+        a, b = run(wsplit), run(wsplit)
+        assert rel_err(a, ref) < tol
+        assert torch.equal(a, b)
+        ops.SPLITK_SLABS = False
+        try:
+            c = run(wsplit)                       # the atomic form: same value to rounding, not necessarily the same bits
+        finally:
+            ops.SPLITK_SLABS = True
+        assert rel_err(c, ref) < tol
+        assert rel_err(a, c) < 1e-6
+
+
+def test_vq_dw_exact_and_normal_scale_gradient_fixed_order(monkeypatch):
+    """The two remaining float-atomic reductions of the BASELINE configs' train steps, now in a fixed order:
+    (1) VectorQuantizerEMA's dw[:, idx] += z (reference vqvae.py:66-72 -> hk.nets.VectorQuantizerEMA): pm_vq_dw_exact, one
+        workgroup per code, rows in ascending order - against float64, against the atomic form, twice the same bits, with codes
+        that take no row and one code that takes most rows;
+    (2) the Normal decoder's d log_scale (reference distributions.py Normal with a learned scalar scale, UCI configs):
+        pm_normal_ll_bwd_det, example terms in scratch, the last workgroup adds them in example order and makes ONE +=."""
+    from posterior_matching_amd import ops
+
+    d = dev()
+    gen = torch.Generator().manual_seed(31)
+    for N, D, K in ((1000, 64, 256), (12544, 64, 512), (77, 24, 40)):
+        z = g32((N, D), gen)
+        z[: N // 2] = z[0] + 0.01 * z[: N // 2]            # half the rows crowd around one code
+        emb = g32((D, K), gen)
+        emb[:, 3] = z[0]
+        emb[:, K - 5:] = 100.0                             # codes no row is near
+        zd, ed = z.float().to(d), emb.float().to(d)
+        dots = (zd @ ed).contiguous()
+        outs = []
+        for mode in ("exact", "exact", "atomic"):
+            if mode == "atomic":
+                monkeypatch.setenv("PM_VQ_DW_ATOMIC", "1")
+            e2, idx = torch.empty(K, device=d), torch.empty(N, dtype=torch.int32, device=d)
+            quant, cg, sq = torch.empty_like(zd), torch.empty_like(zd), torch.empty(N, device=d)
+            counts, dw = torch.empty(K, device=d), torch.full((D, K), float("nan"), device=d)
+            ops.vq_select(zd, ed, dots, e2, idx, quant, cg, sq, counts, dw, 0.25)
+            outs.append((idx.clone(), counts.clone(), dw.clone()))
+            monkeypatch.delenv("PM_VQ_DW_ATOMIC", raising=False)
+        idx = outs[0][0].long().cpu()
+        ref = torch.zeros((K, D), dtype=F64).index_add_(0, idx, zd.double().cpu()).t()
+        assert (outs[0][1].cpu() == torch.bincount(idx, minlength=K).float()).all()
+        assert idx.bincount(minlength=K).max() >= N // 2 and (idx.bincount(minlength=K) == 0).any()
+        scale = zd.abs().max().item() * max(1, int(idx.bincount().max()))
+        assert (outs[0][2].cpu().double() - ref).abs().max().item() < 1e-6 * scale
+        assert rel_err(outs[0][2], ref) < 5e-6 and rel_err(outs[2][2], ref) < 5e-6
+        assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[2][0])
+
+    for B, D in ((700, 8), (9, 21), (256, 43)):
+        loc, xs, g = g32((B, D), gen), g32((B, D), gen), g32((B,), gen)
+        ls = torch.tensor(0.3, dtype=F64)
+        lr_, lsr = loc.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+        nl = O.normal_log_prob(xs, lr_, torch.exp(lsr)).sum(-1)
+        (nl * g).sum().backward()
+        lsd = ls.float().reshape(()).to(d)
+        runs = []
+        for _ in range(3):                                    # the third reuses the scratch (its ticket went back to zero)
+            dloc, dls = torch.empty((B, D), device=d), torch.full((), 0.5, device=d)
+            ops.normal_ll_bwd(loc.float().to(d), xs.float().to(d), lsd, g.float().to(d), dloc, dls)
+            runs.append((dloc.clone(), dls.clone()))
+        tscale = (g.abs() * D).sum().item()
+        assert rel_err(runs[0][0], lr_.grad) < 2e-6
+        assert abs(runs[0][1].item() - 0.5 - lsr.grad.item()) < 2e-6 * tscale
+        assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][0], runs[2][0])
+        monkeypatch.setenv("PM_NLL_ATOMIC", "1")
+        dloc, dls = torch.empty((B, D), device=d), torch.full((), 0.5, device=d)
+        ops.normal_ll_bwd(loc.float().to(d), xs.float().to(d), lsd, g.float().to(d), dloc, dls)
+        monkeypatch.delenv("PM_NLL_ATOMIC")
+        assert abs(dls.item() - 0.5 - lsr.grad.item()) < 2e-6 * tscale and torch.equal(dloc, runs[0][0])

@@ -4,10 +4,12 @@ Round 4: every weight / bias gradient leaves its kernel as per-split PARTIAL SUM
 a fixed order, and no split-K data gradient runs in the PM-VAE step - its gradients are asserted BIT-IDENTICAL between runs
 (what jax.grad gives the reference, train_pm_vae.py:58-72).  The VDVAE's too (its last atomics - the gain / bias sums of the
 final affine and the global gradient norm - became partial sums / a fixed-order sum), step and parameter EMA included.  The
-PixelCNN still holds atomic accumulations outside the weight-gradient family (embedding scatter, split-K data gradients of
-short grids at small batches): its gradients are compared within 1e-5 of the tensor's own largest entry -
-well above the level an f32 sum of a few thousand terms moves when its order changes; the hazard this test was written for
-(the packed-FP32 instability of the thin weight-gradient kernel) produced 1e-4 ... 1e-2."""
+PixelCNN's as well: its embedding scatter runs in order-independent 64-bit fixed point (pm_embed_bwd_exact) and the split-K data
+gradients of short grids keep their K slices in slabs added in slice order (pm_gather_gemm_bf16_sk).  The last three sources -
+VectorQuantizerEMA's dw (pm_vq_dw_exact), the Normal decoder's d log_scale (pm_normal_ll_bwd_det) and split-K at small batches -
+went the same way, so a train step of EVERY BASELINE.json config is asserted bit-reproducible below.  (TOL is what _compare
+falls back to for a tensor a test does not declare exact; the hazard this file was first written for - the packed-FP32
+instability of the thin weight-gradient kernel, DESIGN.md section 6 - produced 1e-4 ... 1e-2.)"""
 import numpy as np
 import pytest
 import torch
@@ -127,10 +129,10 @@ def test_pm_vqvae_gradients_repeat(B):
             ts.penc.backward(ts.pcnn.backward(ts.g_ll))
         ts.synchronize()
         runs.append({n: t.clone() for n, t in ts.store.to_dict("g").items()})
-    inexact = _compare(runs, exact=(lambda name: True) if B == 256 else (lambda name: False))
-    # B = 256 (the benchmarked batch): every gradient bit-identical - weight gradients as partial sums, the embedding
-    # scatter in order-independent fixed point; B = 32: the short grids split K over workgroups and meet with f32 atomics
-    print(f"pm_vqvae B = {B}: not bit-identical between runs: {len(inexact)} tensors")
+    inexact = _compare(runs, exact=lambda name: True)
+    # every gradient bit-identical at both batches - weight gradients as partial sums, the embedding scatter in
+    # order-independent fixed point, and (B = 32) the short grids' split-K data gradients as slabs added in slice order
+    assert not inexact
 
 
 def test_pm_vqvae_train_step_is_bit_reproducible():
@@ -149,3 +151,31 @@ def test_pm_vqvae_train_step_is_bit_reproducible():
         del w
         torch.cuda.empty_cache()
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("name,B", [("pm_vqvae_celeb_a", 16), ("vqvae_mnist", 256), ("pm_vae_gas", 128)])
+def test_remaining_baseline_configs_train_steps_are_bit_reproducible(name, B):
+    """the BASELINE.json configurations the tests above do not cover, at their bench batch sizes (tools/workloads.py): two
+    objects from the same seeds, 3 optimizer steps, parameters (and the VQ-VAE's EMA codebook state) equal bit for bit"""
+    from tools.workloads import build
+
+    finals = []
+    for _ in range(2):
+        w = build(name, B)
+        w.feed()
+        for _ in range(3):
+            w.step()
+        w.synchronize()
+        st = w.ts.store if hasattr(w.ts, "store") else w.ts.model.store
+        state = [st.flat_p.clone()]
+        vq = getattr(getattr(w.ts, "model", None), "state", None)          # VQVAE: the EMA codebook and its statistics
+        if isinstance(vq, dict):
+            state += [t.clone() for _, t in vq.items() if torch.is_tensor(t)]
+        if name == "vqvae_mnist":
+            assert len(state) > 1
+        finals.append(state)
+        del w
+        torch.cuda.empty_cache()
+    assert len(finals[0]) == len(finals[1])
+    for a, b in zip(finals[0], finals[1]):
+        assert torch.equal(a, b), (name, (a.float() - b.float()).abs().max().item())
