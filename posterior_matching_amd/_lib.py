@@ -158,7 +158,8 @@ SIGNATURES = {
     "pm_normal_ll_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F],
     "pm_normal_ll_bwd_det": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "pm_vq_select": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
-    "pm_vq_dw_exact": [_P, _P, _P, _P, _I, _I, _I],
+    "pm_vq_dw_exact": [_P, _P, _P, _P, _I, _I, _I, _P, C.c_longlong],
+    "pm_vq_dw_exact_floats": [_I, _I, _I, C.POINTER(C.c_longlong)],
     "pm_vq_ema_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F],
     "pm_vq_lookup": [_P, _P, _P, _P, _I, _I, _I],
     "pm_vqvae_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],

@@ -116,36 +116,83 @@ __global__ __launch_bounds__(64 * VQ_WAVES) void vq_select_kernel(
     }
 }
 
-// dw[d, k] = sum over the rows assigned to code k of z[row, d], WITHOUT atomics: one workgroup per code walks the index array
-// (N ints, L2-resident after the first workgroup) with RL row lanes x D dimension lanes; a lane adds its matching rows in
-// ascending row order, the RL lane sums are added in lane order.  The result is an exact function of (z, idx) - the same bits
-// on every run - where the LDS / global float atomics of vq_select_kernel add in arrival order.  Every dw element is written
-// (zeros for unused codes), so no zero-fill precedes it.
+// dw[d, k] = sum over the rows assigned to code k of z[row, d], WITHOUT atomics.  Workgroup (k, s) owns code k on row segment s
+// (<= VQ_SEG rows): its 1024 threads read the segment's indices once (coalesced), compact the matching rows IN ROW ORDER into an
+// LDS list (wave ballots + a prefix over the 16 waves), then RL row lanes x D dimension lanes add the listed rows - lane l takes
+// list entries l, l + RL, ... in order, the RL lane sums are added in lane order.  Segment sums go to part[s][d][k] (plain
+// stores) and vq_dw_sum_kernel adds the segments in order.  The result is an exact function of (z, idx) - the same bits on
+// every run - where the float atomics of vq_select_kernel add in arrival order.  Segments keep the work balanced when a
+// handful of codes takes every row (perplexity 2 - 5 early in training): the first form of this kernel, one workgroup per
+// code scanning all N rows, took 160 us for N = 12544 against ~15 us for the atomics.
+#ifndef PM_VQ_SEG
+#define PM_VQ_SEG 2048
+#endif
+constexpr int VQ_SEG = PM_VQ_SEG;
+constexpr int VQ_LPT = (VQ_SEG + 1023) / 1024;                  // index loads per thread
+
 __global__ __launch_bounds__(1024) void vq_dw_exact_kernel(const float* __restrict__ z, const int* __restrict__ idx,
-                                                            float* __restrict__ dw, int N, int D, int K, int RL) {
+                                                            float* __restrict__ out, int N, int D, int K, int RL, int seg) {
+    __shared__ int list[VQ_SEG];
+    __shared__ int wcount[VQ_LPT][16];
     __shared__ float part[1024];
-    const int k = blockIdx.x;
+    const int k = blockIdx.x, sgm = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = sgm * seg, r1 = min(N, r0 + seg);
+    // the segment's indices: VQ_LPT per thread, all loads in flight
+    bool mt[VQ_LPT];
+    unsigned long long bt[VQ_LPT];
+#pragma unroll
+    for (int i = 0; i < VQ_LPT; ++i) {
+        const int r = r0 + i * 1024 + (int)threadIdx.x;
+        mt[i] = r < r1 && idx[r] == k;
+    }
+#pragma unroll
+    for (int i = 0; i < VQ_LPT; ++i) {
+        bt[i] = __ballot(mt[i]);
+        if (lane == 0) wcount[i][wave] = __popcll(bt[i]);
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int nm = 0;                                                  // uniform over the workgroup
+#pragma unroll
+    for (int i = 0; i < VQ_LPT; ++i) {
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wcount[i][w];
+            if (w < wave) off += c;
+            tot += c;
+        }
+        if (mt[i]) list[nm + off + __popcll(bt[i] & below)] = r0 + i * 1024 + (int)threadIdx.x;
+        nm += tot;
+    }
+    __syncthreads();
     const int l = threadIdx.x / D, d = threadIdx.x - l * D;
     float s = 0.f;
     if (l < RL) {
-        int r = l;
-        for (; r + 3 * RL < N; r += 4 * RL) {            // four independent index loads in flight
-            const int i0 = idx[r], i1 = idx[r + RL], i2 = idx[r + 2 * RL], i3 = idx[r + 3 * RL];
-            if (i0 == k) s += z[(size_t)r * D + d];
-            if (i1 == k) s += z[(size_t)(r + RL) * D + d];
-            if (i2 == k) s += z[(size_t)(r + 2 * RL) * D + d];
-            if (i3 == k) s += z[(size_t)(r + 3 * RL) * D + d];
+        int m = l;
+        for (; m + 3 * RL < nm; m += 4 * RL) {                  // four independent row loads in flight, added in list order
+            const float v0 = z[(size_t)list[m] * D + d], v1 = z[(size_t)list[m + RL] * D + d];
+            const float v2 = z[(size_t)list[m + 2 * RL] * D + d], v3 = z[(size_t)list[m + 3 * RL] * D + d];
+            s += v0; s += v1; s += v2; s += v3;
         }
-        for (; r < N; r += RL)
-            if (idx[r] == k) s += z[(size_t)r * D + d];
+        for (; m < nm; m += RL) s += z[(size_t)list[m] * D + d];
         part[threadIdx.x] = s;
     }
     __syncthreads();
     if (l == 0) {
         float t = 0.f;
         for (int j = 0; j < RL; ++j) t += part[j * D + d];
-        dw[(size_t)d * K + k] = t;
+        out[((size_t)sgm * D + d) * K + k] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void vq_dw_sum_kernel(const float* __restrict__ part, float* __restrict__ dw, int DK, int S) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= DK) return;
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += part[(size_t)s * DK + j];
+    dw[j] = t;
 }
 
 __global__ __launch_bounds__(256) void vq_lookup_kernel(const int* __restrict__ idx, const float* __restrict__ emb,
@@ -257,10 +304,25 @@ extern "C" int pm_vq_select(pm_stream_t stream, const float* z, const float* emb
     return pm_check_launch("pm_vq_select");
 }
 
-extern "C" int pm_vq_dw_exact(pm_stream_t stream, const float* z, const int* idx, float* dw, int N, int D, int K) {
+static int vq_dw_segments(int N) { return (N + VQ_SEG - 1) / VQ_SEG; }
+
+extern "C" int pm_vq_dw_exact_floats(int N, int D, int K, long long* floats) {
+    if (!floats || N <= 0 || D <= 0 || D > 1024 || K <= 0) return PM_EINVAL;
+    const int S = vq_dw_segments(N);
+    *floats = S > 1 ? (long long)S * D * K : 0;
+    return PM_OK;
+}
+
+extern "C" int pm_vq_dw_exact(pm_stream_t stream, const float* z, const int* idx, float* dw, int N, int D, int K,
+                              float* scratch, long long scratch_floats) {
     if (!z || !idx || !dw || N <= 0 || D <= 0 || D > 1024 || K <= 0) return PM_EINVAL;
+    const int S = vq_dw_segments(N);
+    if (S > 65535 || (S > 1 && (!scratch || scratch_floats < (long long)S * D * K))) return PM_EINVAL;
     const int RL = 1024 / D;
-    hipLaunchKernelGGL(vq_dw_exact_kernel, dim3(K), dim3(1024), 0, (hipStream_t)stream, z, idx, dw, N, D, K, RL);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(vq_dw_exact_kernel, dim3(K, S), dim3(1024), 0, s, z, idx, S > 1 ? scratch : dw, N, D, K, RL, VQ_SEG);
+    if (S > 1)
+        hipLaunchKernelGGL(vq_dw_sum_kernel, dim3((D * K + 255) / 256), dim3(256), 0, s, scratch, dw, D * K, S);
     return pm_check_launch("pm_vq_dw_exact");
 }
 

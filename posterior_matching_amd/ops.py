@@ -969,6 +969,9 @@ def normal_ll_bwd(loc, x, log_scale, g, dloc, d_log_scale, scale_eps: float = 0.
 
 
 # ---- vector quantisation (hk.nets.VectorQuantizerEMA, reference vqvae.py:66-72,80) -----------------
+_VQ_SCRATCH: dict = {}      # (device, stream, floats) -> segment sums of pm_vq_dw_exact
+
+
 def vq_select(z, emb, dots, e2, idx, quant, commit_grad, sqerr, counts, dw, commit_coef: float) -> None:
     """z [N,D], emb [D,K], dots [N,K] = z @ emb."""
     D, K = emb.shape
@@ -977,7 +980,13 @@ def vq_select(z, emb, dots, e2, idx, quant, commit_grad, sqerr, counts, dw, comm
     if dw is not None and D <= 1024 and not os.environ.get("PM_VQ_DW_ATOMIC"):     # A/B knob: dw from float atomics
         _call("pm_vq_select", _ptr(z), _ptr(emb), _ptr(dots), _ptr(e2), _iptr(idx), _ptr(quant), _ptr(commit_grad),
               _ptr(sqerr), _ptr(counts), None, N, D, K, commit_coef, work=work)
-        _call("pm_vq_dw_exact", _ptr(z), _iptr(idx), _ptr(dw), N, D, K,
+        n = C.c_longlong(0)
+        _lib.load().pm_vq_dw_exact_floats(N, D, K, C.byref(n))
+        key = (z.device.index, _stream(), n.value)
+        scratch = _VQ_SCRATCH.get(key)
+        if scratch is None and n.value:
+            scratch = _VQ_SCRATCH[key] = torch.empty(n.value, dtype=torch.float32, device=z.device)
+        _call("pm_vq_dw_exact", _ptr(z), _iptr(idx), _ptr(dw), N, D, K, _ptr(scratch), n.value,
               work={"bytes": _nbytes(z, dw) + 4 * N, "detail": f"N{N} D{D} K{K}"})
         return
     _call("pm_vq_select", _ptr(z), _ptr(emb), _ptr(dots), _ptr(e2), _iptr(idx), _ptr(quant), _ptr(commit_grad),
