@@ -96,6 +96,9 @@ CONV_CASES = [
     # short tile grids under a long K: the split-K form, K slices in slabs added in slice order (8 - 24 slices; the CelebA
     # PixelCNN's 8 x 8 x 256 layers at per-GPU batch 16, MLP layers at small batch, a ragged one)
     ("conv", 16, 8, 256, 256, 3, 1, "SAME"), ("dense", 64, 1, 2048, 512, 1, 1, "VALID"), ("dense", 100, 1, 1100, 200, 1, 1, "VALID"),
+    # deep stride-1 layers on grids >= 12 wide whose patch only fits LDS a channel chunk at a time (patch_conv_cp_bf16): full 3 x 3
+    # kernels (128-channel passes, 24 staged pieces per thread), forward and - transposed - with flipped taps, 32-wide tiles
+    ("conv", 4, 16, 256, 128, 3, 1, "SAME"), ("convT", 3, 16, 256, 64, 3, 1, "SAME"), ("conv", 2, 24, 256, 40, 3, 1, "SAME"),
 ]
 
 
@@ -749,6 +752,9 @@ MASKED_CASES = [
     (256, 7, 128, 128, (3, 3), 1, 3),  # horizontal_stack_up
     (256, 7, 128, 128, (3, 3), 2, 1),  # horizontal_stack_left
     (16, 16, 256, 256, (3, 3), 2, 2),  # pm_vqvae_celeb_a at its per-GPU batch
+    # the channel-pass patch form (patch_conv_cp_bf16: deep layers whose patch does not fit LDS at full depth): 2 x 3 and 2 x 2
+    # masks (64-channel passes), N = 128, a ragged grid (13: half-empty tiles) and 512 channels (8 passes)
+    (16, 16, 256, 128, (3, 3), 2, 3), (3, 13, 256, 64, (3, 3), 2, 2), (2, 16, 512, 96, (3, 3), 2, 3),
 ]
 
 
