@@ -1643,13 +1643,21 @@ __global__ __launch_bounds__(256, RN == 1 ? 3 : 2) void patch_conv_bd_bf16_kerne
 // replaces it; the accumulators stay in registers across the passes.  Operand traffic: every workgroup reads its patch once
 // (9 x 18 x 256 floats = 166 KB; 42 MB per launch).  The chunk of pass c + 1 is requested from memory BEFORE the k-loop of pass c
 // (registers), so its round trip hides behind that pass's MFMAs; two barriers per pass.
-template <int RN, int NPF>
+#ifndef PM_CP_EXP
+#define PM_CP_EXP 0
+#endif
+// The k-steps of a pass are STRAIGHT-LINE code (SPC = steps per pass = 2 x taps is a template parameter): with the pass switch as a
+// branch inside the unrolled steps the compiler could not count the loads in flight at the join and drained them all
+// (s_waitcnt vmcnt(0)) at the head of every group of steps - weights requested NSET steps ahead arrived "just in time" by
+// stalling.  Here every load of the loop body is unconditional (the last pass requests a patch it never stores), the
+// prologue issues its loads in the body's order, and the waits the compiler emits are exact.
+// (Tried and dropped: two or four wave groups dealing the passes between them - 27.7 / 88 us against 24.6 us per launch.)
+template <int RN, int SPC, int NSET>
 __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, const __bf16* __restrict__ wsplit, int npad,
-                                                                    long long plane, int tw_log2, int CC) {
-    constexpr int NSET = 4;
+                                                                    long long plane, int tw_log2) {
+    constexpr int CC = 64, NPF = 12;
+    static_assert(SPC % NSET == 0, "static register-set rotation");
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    KStepB* kd = reinterpret_cast<KStepB*>(dsm);
-
     const Geom& g = p.g;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1659,15 +1667,16 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
     const int n0 = blockIdx.y * 32 * RN;
     const int TW = 1 << tw_log2, TH = 128 >> tw_log2;
     const int PH = TH + g.KH - 1, PW = TW + g.KW - 1;
-    const int PS = CC + 8;                                              // bf16 per patch position (16 B pad)
-    const int cch = g.C / BK;                                           // 32-channel chunks per tap in the weight layout
-    const int cpp = CC / BK;                                            // ... per pass
-    const int taps = g.KH * g.KW;
-    const int spc = taps * cpp;                                         // k-steps per pass (a multiple of NSET: plan_patch_cp)
+    constexpr int PS = CC + 8;                                          // bf16 per patch position (16 B pad)
+    constexpr int cpp = CC / BK;                                        // 32-channel chunks per pass
+    const int cch = g.C / BK;                                           // ... per tap in the weight layout
     const int npass = g.C / CC;
-    const int nsteps = npass * spc;
-    __bf16* Ph = reinterpret_cast<__bf16*>(dsm) + (size_t)(nsteps + 2) * (sizeof(KStepB) / 2);
-    __bf16* Pl = Ph + (size_t)PH * PW * PS;
+    const int nsteps = npass * SPC;
+    // LDS: the step table (nsteps + NSET + 2 entries), then the patch (hi plane, lo plane)
+    KStepB* kd = reinterpret_cast<KStepB*>(dsm);
+    const size_t pelems = (size_t)PH * PW * PS;
+    __bf16* Ph = reinterpret_cast<__bf16*>(kd + (nsteps + NSET + 2));
+    __bf16* Pl = Ph + pelems;
 
     const int tiles_x = (g.OW + TW - 1) >> tw_log2;
     const int tiles_y = (g.OH + TH - 1) / TH;
@@ -1680,27 +1689,28 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
     const int sy0 = y0 + g.off + (g.cs < 0 ? -(g.KH - 1) : 0);
     const int sx0 = x0 + g.offx + (g.cs < 0 ? -(g.KW - 1) : 0);
 
-    // k-step table in pass order: step s = (pass, tap, chunk of the pass); woff = offset of its [npad][32] hi block in the weights
-    for (int s = tid; s < nsteps + 2; s += 256) {
+    // k-step table in pass order: step s = (pass, tap, chunk of the pass); dy = the tap's patch offset (elements, the chunk's
+    // channel offset included), woff = offset of the step's [npad][32] hi block in the weights
+    for (int s = tid; s < nsteps + NSET + 2; s += 256) {
         KStepB k{0, 0, 0, 0};
         const int sc = s < nsteps ? s : nsteps - 1;
-        const int ps = sc / spc, r = sc - ps * spc;
+        const int ps = sc / SPC, r = sc - ps * SPC;
         const int tap = r / cpp, cl = r - tap * cpp;
         const int ky = tap / g.KW, kx = tap - ky * g.KW;
-        k.dy = g.cs > 0 ? ky : g.KH - 1 - ky;
-        k.dx = g.cs > 0 ? kx : g.KW - 1 - kx;
-        k.c0 = cl * BK;
+        const int dy = g.cs > 0 ? ky : g.KH - 1 - ky;
+        const int dx = g.cs > 0 ? kx : g.KW - 1 - kx;
+        k.dy = (dy * PW + dx) * PS + cl * BK;
         k.woff = (tap * cch + ps * cpp + cl) * npad * BK;
         kd[s] = k;
     }
 
     // the patch of one pass: NPF f32x4 pieces per thread (positions x CC / 4), zero outside the image
     const float* img = p.in + (size_t)b * g.IH * g.IW * g.C;
-    const int c4n = CC >> 2;
+    constexpr int c4n = CC >> 2;
     const int total = PH * PW * c4n;
     f32x4 pv[NPF];
     int pdst[NPF];
-    size_t psrc[NPF];
+    int psrc[NPF];                                       // element offset inside the image (B * IH * IW * C * 4 < 2^31: host check)
 #pragma unroll
     for (int j = 0; j < NPF; ++j) {
         const int e = tid + 256 * j;
@@ -1709,37 +1719,35 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
         const int py = pos / PW, px = pos - py * PW;
         const int gy = sy0 + py, gx = sx0 + px;
         const bool ok = e < total && (unsigned)gy < (unsigned)g.IH && (unsigned)gx < (unsigned)g.IW;
-        psrc[j] = ok ? ((size_t)gy * g.IW + gx) * g.C + 4 * c4 : (size_t)-1;
+        psrc[j] = ok ? (gy * g.IW + gx) * g.C + 4 * c4 : -1;
         pdst[j] = e < total ? pos * PS + 4 * c4 : -1;
     }
-    auto fetch_patch = [&](int ps) {                     // unconditional loads (clamped address): all NPF in flight at once
+    auto fetch_patch = [&](int ps) {                     // unconditional loads (clamped address): all NPF in flight
+        const int c0 = ps * CC;
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const size_t so = psrc[j] != (size_t)-1 ? psrc[j] + (size_t)ps * CC : 0;
-            pv[j] = *reinterpret_cast<const f32x4*>(img + so);
-        }
+        for (int q = 0; q < NPF; ++q) pv[q] = *reinterpret_cast<const f32x4*>(img + (psrc[q] >= 0 ? psrc[q] + c0 : 0));
     };
     auto store_patch = [&]() {
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            if (pdst[j] < 0) continue;
-            f32x4 v = pv[j];
-            if (psrc[j] == (size_t)-1) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NPF; ++q) {
+            f32x4 v = pv[q];
+            if (psrc[q] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
             u32x2 h2, l2;
             split4(v, h2, l2);
-            *reinterpret_cast<u32x2*>(Ph + pdst[j]) = h2;
-            *reinterpret_cast<u32x2*>(Pl + pdst[j]) = l2;
+            if (pdst[q] >= 0) {
+                *reinterpret_cast<u32x2*>(Ph + pdst[q]) = h2;
+                *reinterpret_cast<u32x2*>(Pl + pdst[q]) = l2;
+            }
         }
     };
-    fetch_patch(0);
 
     // B fragment of (k-step s, column tile r, half kk, plane): 16 bytes at (woff(s) + n * 32 + 16 kk + 8 h); q = 2 kk + plane
     bf16x8 bq[NSET][RN][4];
     int ncl[RN];
 #pragma unroll
     for (int r = 0; r < RN; ++r) ncl[r] = (n0 + 32 * r + i < npad ? n0 + 32 * r + i : 0) * BK + 8 * h;
-    auto load_b = [&](int s, bf16x8 (&bb)[RN][4]) {
-        const __bf16* base = wsplit + kd[s < nsteps ? s : nsteps - 1].woff;
+    auto load_b = [&](int s, bf16x8 (&bb)[RN][4]) {       // s <= nsteps + NSET - 1: the table's padding repeats the last step
+        const __bf16* base = wsplit + kd[s].woff;
 #pragma unroll
         for (int r = 0; r < RN; ++r) {
             const __bf16* src = base + ncl[r];
@@ -1765,53 +1773,52 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
-    __syncthreads();                                     // kd visible
-    load_b(0, bq[0]);
-    load_b(1, bq[1]);
-    load_b(2, bq[2]);
-    load_b(3, bq[3]);
+    __syncthreads();                                     // step table visible
+    fetch_patch(0);                                      // the prologue's loads in the loop body's order: patch, then weights
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) load_b(u, bq[u]);
 
     bf16x8 ah[2][2], al[2][2];       // [register set][k16 half]
-    auto read_a = [&](int s, int set) {
-        const KStepB k = kd[s];
-        const int o = abase + (k.dy * PW + k.dx) * PS + k.c0;
+    auto read_a = [&](int o, int set) {
         ah[set][0] = *reinterpret_cast<const bf16x8*>(Ph + o);
         ah[set][1] = *reinterpret_cast<const bf16x8*>(Ph + o + 16);
         al[set][0] = *reinterpret_cast<const bf16x8*>(Pl + o);
         al[set][1] = *reinterpret_cast<const bf16x8*>(Pl + o + 16);
     };
-    auto step = [&](int s, auto uc) {
-        constexpr int u = decltype(uc)::value;
-        read_a(s + 1, (u + 1) & 1);                         // kd[] has two entries past the end; a pass's last step reads ahead
-                                                            // into the patch of the SAME pass (unused: the next pass re-reads)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int r = 0; r < RN; ++r) {
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u & 1][kk], bq[u][r][2 * kk + 1], acc[r], 0, 0, 0);
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
-            }
-        load_b(s + NSET, bq[u]);                            // NSET k-steps ahead (clamped at the end)
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using U0 = std::integral_constant<int, 0>;
-    using U1 = std::integral_constant<int, 1>;
-    using U2 = std::integral_constant<int, 2>;
-    using U3 = std::integral_constant<int, 3>;
     for (int ps = 0; ps < npass; ++ps) {
-        store_patch();                                      // waits for this pass's pieces (requested one pass ago)
+        const int sb = ps * SPC;
+        if (ps) __syncthreads();                            // every wave is done with the old patch
+        store_patch();                                      // this pass's pieces (requested one pass ago)
         __syncthreads();
-        if (ps + 1 < npass) fetch_patch(ps + 1);            // in flight during this pass's MFMAs
-        const int sb = ps * spc;
-        read_a(sb, 0);
-        for (int s0 = sb; s0 < sb + spc; s0 += NSET) {      // spc % NSET == 0: the register-set rotation stays aligned
-            step(s0, U0{});
-            step(s0 + 1, U1{});
-            step(s0 + 2, U2{});
-            step(s0 + 3, U3{});
+#if PM_CP_EXP != 3
+        fetch_patch(ps + 1 < npass ? ps + 1 : 0);           // in flight during this pass's MFMAs (the last one is never stored)
+#endif
+        int ao[2];                                          // A offsets, read from the table one step before they are needed
+        read_a(abase + kd[sb].dy, 0);
+        ao[1] = abase + kd[sb + 1].dy;
+#pragma unroll
+        for (int q = 0; q < SPC; ++q) {                     // straight-line: q, the register sets and the waits are static
+            const int s = sb + q;
+            const int u = q % NSET;
+            if (q + 1 < SPC) read_a(ao[(q + 1) & 1], (q + 1) & 1);          // A of step s + 1
+            if (q + 2 < SPC) ao[q & 1] = abase + kd[s + 2].dy;              // the table read completes behind this step's MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r = 0; r < RN; ++r) {
+#if PM_CP_EXP == 1
+                    acc[r][0] += (float)ah[q & 1][kk][0] * (float)bq[u][r][2 * kk][0] + (float)al[q & 1][kk][1] * (float)bq[u][r][2 * kk + 1][0];
+#else
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q & 1][kk], bq[u][r][2 * kk + 1], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[q & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
+#endif
+                }
+#if PM_CP_EXP != 2
+            load_b(s + NSET, bq[u]);                        // NSET k-steps ahead (the table's padding covers the end)
+#endif
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                    // every wave is done with this pass's patch
     }
 
     const float* aux = p.aux;
@@ -1824,6 +1831,9 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
     for (int r = 0; r < RN; ++r) {
         int n = n0 + r * 32 + i;
         if (n >= g.N) continue;
+#if PM_CP_EXP == 4
+        if (acc[r][0] == 12345.f)
+#endif
         pm_epilogue_tile(acc[r], ro, n, bvr[r], aux, res, out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
     }
 }
@@ -1851,32 +1861,28 @@ bool plan_patch(const Geom& g, int groups, int rn, PatchPlan& pp) {
 }
 
 // channel-pass plan: the patch form's conditions except that the patch only has to fit LDS CC channels at a time
-struct PatchCpPlan { int tw_log2, CC, npf; size_t lds; dim3 grid; };
+struct PatchCpPlan { int tw_log2, spc, nset; size_t lds; dim3 grid; };
 bool plan_patch_cp(const Geom& g, int groups, int rn, PatchCpPlan& pp) {
-    if (groups != 1 || g.a != 1 || g.d != 1 || g.C % 64 != 0 || g.in_act != PM_ACT_NONE) return false;
+    constexpr int CC = 64;
+    if (groups != 1 || g.a != 1 || g.d != 1 || g.C % CC != 0 || g.C <= CC || g.in_act != PM_ACT_NONE) return false;
     if (g.KH * g.KW < 4 || g.OW < 12 || g.OH < 4) return false;
+    if ((long long)g.B * g.IH * g.IW * g.C * 4 >= 0x7ffffff0LL) return false;
     pp.tw_log2 = g.OW > 16 ? 5 : 4;
     const int TW = 1 << pp.tw_log2, TH = 128 >> pp.tw_log2;
     const int tiles_x = (g.OW + TW - 1) / TW, tiles_y = (g.OH + TH - 1) / TH;
     if ((long long)tiles_x * TW * tiles_y * TH * 2 > 3LL * g.OH * g.OW) return false;
     const int taps = g.KH * g.KW;
+    if (taps != 4 && taps != 6 && taps != 9) return false;               // the instantiated pass lengths: 8 / 12 / 18 k-steps
+    pp.spc = taps * (CC / BK);
+    pp.nset = pp.spc == 8 ? 4 : 6;
     const int nsteps = taps * (g.C / BK);
     if (nsteps > 4096) return false;
     const int NB = 32 * rn;
-    static const int cc_env = getenv("PM_PATCH_CP_CC") ? atoi(getenv("PM_PATCH_CP_CC")) : 0;      // A/B knob
-    for (int CC : {64, 128}) {
-        if (cc_env && CC != cc_env) continue;
-        if (g.C % CC != 0 || g.C <= CC || (taps * (CC / BK)) % 4 != 0) continue;
-        const int pieces = (TH + g.KH - 1) * (TW + g.KW - 1) * (CC / 4);
-        const int npf = (pieces + 255) / 256;
-        if (npf > 28) continue;                          // register-staged pieces per thread (12 or 28 in the instantiations)
-        const size_t lds = (size_t)(nsteps + 2) * sizeof(KStepB) + (size_t)(TH + g.KH - 1) * (TW + g.KW - 1) * (CC + 8) * 2 * 2;
-        if (lds > 150 * 1024) continue;
-        pp.CC = CC; pp.npf = npf <= 12 ? 12 : 28; pp.lds = lds;
-        pp.grid = dim3((unsigned)(g.B * tiles_y * tiles_x), (g.N + NB - 1) / NB, 1);
-        return true;
-    }
-    return false;
+    if ((TH + g.KH - 1) * (TW + g.KW - 1) * (CC / 4) > 12 * 256) return false;   // 12 register-staged pieces per thread
+    pp.lds = (size_t)(nsteps + pp.nset + 2) * sizeof(KStepB) + (size_t)(TH + g.KH - 1) * (TW + g.KW - 1) * (CC + 8) * 2 * 2;
+    if (pp.lds > 150 * 1024) return false;
+    pp.grid = dim3((unsigned)(g.B * tiles_y * tiles_x), (g.N + NB - 1) / NB, 1);
+    return true;
 }
 
 // ------------------- d = 1 convolutions with the WHOLE input image of a workgroup resident in LDS (bf16x3) -------------------
@@ -4612,19 +4618,28 @@ static int gather_gemm_bf16_impl(pm_stream_t stream, const pm_gather_desc* d, co
     if (!patch_off && !cp_off && plan_patch_cp(a.g, G, rn, pc)) {   // deep stride-1 convs: the patch CC channels at a time
         a.ksplit = 1;
         if (query) return PM_OK;
-        static bool attr_cp = false;
-        if (!attr_cp) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_cp_bf16_kernel<1, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_cp_bf16_kernel<2, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_cp_bf16_kernel<1, 28>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_cp_bf16_kernel<2, 28>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_cp = true;
+        PM_KTAG("patch_conv_cp_bf16_kernel<%d, %d>", rn, pc.spc);
+#define PM_CP(RNv, SPCv, NSv)                                                                                          \
+    do {                                                                                                               \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_conv_cp_bf16_kernel<RNv, SPCv, NSv>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                         \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((patch_conv_cp_bf16_kernel<RNv, SPCv, NSv>), pc.grid, dim3(256), pc.lds, s, a, ws, npad, plane, \
+                           pc.tw_log2);                                                                                \
+    } while (0)
+        if (rn == 1) {
+            if (pc.spc == 8) PM_CP(1, 8, 4);
+            else if (pc.spc == 12) PM_CP(1, 12, 6);
+            else PM_CP(1, 18, 6);
+        } else {
+            if (pc.spc == 8) PM_CP(2, 8, 4);
+            else if (pc.spc == 12) PM_CP(2, 12, 6);
+            else PM_CP(2, 18, 6);
         }
-        PM_KTAG("patch_conv_cp_bf16_kernel<%d, %d>", rn, pc.npf);
-        if (rn == 1 && pc.npf == 12) hipLaunchKernelGGL((patch_conv_cp_bf16_kernel<1, 12>), pc.grid, dim3(256), pc.lds, s, a, ws, npad, plane, pc.tw_log2, pc.CC);
-        else if (rn == 1) hipLaunchKernelGGL((patch_conv_cp_bf16_kernel<1, 28>), pc.grid, dim3(256), pc.lds, s, a, ws, npad, plane, pc.tw_log2, pc.CC);
-        else if (pc.npf == 12) hipLaunchKernelGGL((patch_conv_cp_bf16_kernel<2, 12>), pc.grid, dim3(256), pc.lds, s, a, ws, npad, plane, pc.tw_log2, pc.CC);
-        else hipLaunchKernelGGL((patch_conv_cp_bf16_kernel<2, 28>), pc.grid, dim3(256), pc.lds, s, a, ws, npad, plane, pc.tw_log2, pc.CC);
+#undef PM_CP
         return pm_check_launch("pm_gather_gemm_bf16(patch_cp)");
     }
     PatchD2Plan pd;

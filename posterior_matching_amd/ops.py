@@ -463,6 +463,19 @@ def _patch_form(d: GatherDesc) -> bool:
     return lds <= 150 * 1024
 
 
+def _patch_cp_form(d: GatherDesc) -> bool:
+    """mirrors plan_patch_cp (csrc/pm_conv.hip): deep stride-1 layers whose patch fits LDS a channel chunk at a time"""
+    if d.groups != 1 or d.a != 1 or d.d != 1 or d.C % 64 != 0 or d.C <= 64 or d.in_act != ACT_NONE:
+        return False
+    if d.KH * d.KW < 4 or d.OW < 12 or d.OH < 4 or os.environ.get("PM_NO_PATCH_CP"):
+        return False
+    tw = 32 if d.OW > 16 else 16
+    th = 128 // tw
+    if -(-d.OW // tw) * tw * -(-d.OH // th) * th * 2 > 3 * d.OH * d.OW:
+        return False
+    return (th + d.KH - 1) * (tw + d.KW - 1) * 16 <= 12 * 256 and (d.KH * d.KW * (d.C // 32)) % 4 == 0
+
+
 def _patch_d2_form(d: GatherDesc) -> bool:
     """mirrors plan_patch_d2 (csrc/pm_conv.hip): zero-dilated problems whose four residue classes share one staged patch"""
     if d.groups != 1 or d.a != 1 or d.d != 2 or d.C % 32 != 0 or d.in_act != ACT_NONE or d.cs not in (1, -1):
@@ -500,6 +513,8 @@ def gather_gemm_bf16(desc: GatherDesc, inp, wsplit, bias, aux, res, out, out2=No
         tag = f"direct_gemm_bf16_kernel<{rn}, {desc.d}, {desc.in_act}, {'true' if dense else 'false'}>"   # template args
         if _patch_form(desc):
             tag = f"patch_conv_bf16_kernel<{2 if desc.N > 32 else 1}>"
+        elif _patch_cp_form(desc):
+            tag = f"patch_conv_cp_bf16_kernel<{2 if desc.N > 32 else 1}>"
         elif _patch_d2_form(desc):
             tag = f"patch_d2_bf16_kernel<{2 if desc.N > 32 else 1}>"
         work = {"flops": _algorithmic_flops(desc), "bytes": _nbytes(inp, aux, res, out), "detail": _detail(desc)}

@@ -49,6 +49,11 @@ CASES = [
     ("thin enc0 wgrad", LayerGeom.conv(28, 28, 1, 32, 5, 1, "SAME"), "wgrad"),
     ("thin penc0 wgrad", LayerGeom.conv(28, 28, 2, 32, 5, 1, "SAME"), "wgrad"),
     ("thin dec6 wgrad", LayerGeom.conv_t(28, 28, 32, 1, 5, 1, "SAME"), "wgrad"),
+    # CelebA PixelCNN (PM_BENCH_B=16): masked 3x3 layers on the 16 x 16 code grid
+    ("celeb pcnn 256->256 m2x3 fwd", LayerGeom.masked_conv(16, 16, 256, 256, 3, 3, 2, 3), "fwd"),
+    ("celeb pcnn 256->128 m2x3 fwd", LayerGeom.masked_conv(16, 16, 256, 128, 3, 3, 2, 3), "fwd"),
+    ("celeb pcnn 256->256 m2x2 fwd", LayerGeom.masked_conv(16, 16, 256, 256, 3, 3, 2, 2), "fwd"),
+    ("celeb pcnn 256->256 m2x3 dgrad", LayerGeom.masked_conv(16, 16, 256, 256, 3, 3, 2, 3), "dgrad"),
 ]
 if os.environ.get("PM_CASES"):
     CASES = [c for c in CASES if any(k in c[0] for k in os.environ["PM_CASES"].split(","))]
@@ -75,7 +80,7 @@ def main():
                 st.allocate(d)
                 st.load_dict({"w": w.cpu()})
                 ws = st.split_view(hf) if os.environ.get("PM_BF16", "1") == "1" else None
-                tmp = torch.empty((B, g.IH, g.IW, g.k * g.k), device=d) if g.CO == 1 else None
+                tmp = torch.empty((B, g.IH, g.IW, g.KH * g.KW), device=d) if g.CO == 1 else None
                 fn = lambda: ops.layer_forward(g, x, w, b, y, out_act=ACT_LEAKY, wsplit=ws, tmp=tmp)
             elif what.startswith("dgrad"):
                 from posterior_matching_amd.models.core import ParamStore
@@ -106,9 +111,10 @@ def main():
             e1.record()
             e1.synchronize()
             us = e0.elapsed_ms(e1) / reps * 1e3
-            macs = B * g.OH * g.OW * g.k * g.k * g.CI * g.CO if g.kind != "convT" or g.s == 1 else B * g.IH * g.IW * g.k * g.k * g.CI * g.CO
+            kk = g.KH * g.KW
+            macs = B * g.OH * g.OW * kk * g.CI * g.CO if g.kind != "convT" or g.s == 1 else B * g.IH * g.IW * kk * g.CI * g.CO
             if g.kind == "conv" and g.s > 1:
-                macs = B * g.OH * g.OW * g.k * g.k * g.CI * g.CO
+                macs = B * g.OH * g.OW * kk * g.CI * g.CO
             kt = ops.KernelTimer()
             ops.set_timer(kt)
             for _ in range(10):
