@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs p) {
     constexpr int BTILE = DGS * NB * LDS_LD;            // floats of one weight stage
     constexpr int EPS = NB * BK / 256;                  // weight elements per thread per k-step
     constexpr int TL_F = (sizeof(TapList) + 3) / 4;
-    constexpr int KD_F = DMAXSTEPS * (sizeof(KStep) / 4);
+    constexpr int KD_F = (DMAXSTEPS + 8) * (sizeof(KStep) / 4);   // + zero entries the prefetches run into (written up to nsteps + DGS)
     __shared__ __attribute__((aligned(16))) float smem[2 * BTILE + KD_F + TL_F];
     float* Bs = smem;
     KStep* kd = reinterpret_cast<KStep*>(smem + 2 * BTILE);

@@ -190,23 +190,30 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // out[b, n] = sum_{p < P} x[(b*P + p), n].  One workgroup per (example, 32 columns): 8 row groups walk the P positions
 // with 128-byte coalesced loads and meet in LDS (a thread per (b, n) walking P strided rows serially left 16 workgroups
 // on the chip at the CelebA size: 60 us per call, 16 % of that step).
-__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                        long long total, int N, int P) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         long long total, int N, int P) {
+    // 32 row groups (1024 threads): at the CelebA size (B = 16, P = 256, N = 256: 128 workgroups) a thread adds 8 rows, four
+    // loads in flight at a time, instead of 32 rows one after the other (15.6 -> ~8 us per call, 48 calls per step)
+    __shared__ float red[32][33];
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const long long b = blockIdx.y;
     const int n = blockIdx.x * 32 + col;
     float s = 0.f;
     if (n < N) {
         const float* p = x + (size_t)b * P * N + n;
-        for (int j = rg; j < P; j += 8) s += p[(size_t)j * N];
+        int j = rg;
+        for (; j + 96 < P; j += 128) {
+            const float v0 = p[(size_t)j * N], v1 = p[(size_t)(j + 32) * N], v2 = p[(size_t)(j + 64) * N], v3 = p[(size_t)(j + 96) * N];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; j < P; j += 32) s += p[(size_t)j * N];
     }
     red[rg][col] = s;
     __syncthreads();
     if (rg == 0 && n < N) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][col];
+        for (int r = 0; r < 32; ++r) t += red[r][col];
         out[b * N + n] = t;
     }
 }
@@ -725,7 +732,7 @@ extern "C" int pm_rows_sum(pm_stream_t stream, const float* x, float* out, long 
         return pm_check_launch("pm_rows_sum");
     }
     PM_KTAG("rows_sum_kernel");
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out,
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)B), dim3(1024), 0, (hipStream_t)stream, x, out,
                        B * N, N, P);
     return pm_check_launch("pm_rows_sum");
 }
