@@ -159,6 +159,7 @@ SIGNATURES = {
     "pm_normal_ll_bwd_det": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "pm_vq_select": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "pm_vq_dw_exact": [_P, _P, _P, _P, _I, _I, _I, _P, C.c_longlong],
+    "pm_embed_bwd_sorted": [_P, _P, _P, _P, C.c_longlong, _I, _I, _P, C.c_longlong],
     "pm_vq_dw_exact_floats": [_I, _I, _I, C.POINTER(C.c_longlong)],
     "pm_vq_ema_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F],
     "pm_vq_lookup": [_P, _P, _P, _P, _I, _I, _I],

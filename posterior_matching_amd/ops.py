@@ -1053,11 +1053,19 @@ _embed_scratch = {}
 
 
 def embed_bwd(idx, dout, dtable) -> None:
-    """dtable[idx[r]] += dout[r]: 64-bit fixed-point integer atomics (pm_embed_bwd_exact) - the same bits in every run;
-    PM_EMBED_ATOMIC=1: the f32-atomic form (A/B)"""
+    """dtable[idx[r]] += dout[r] in a fixed order (pm_embed_bwd_sorted; F > 1024 or PM_EMBED_FIXEDPOINT=1: 64-bit fixed-point
+    integer atomics, pm_embed_bwd_exact) - the same bits in every run; PM_EMBED_ATOMIC=1: the f32-atomic form (A/B)"""
     K, F = dtable.shape
     if os.environ.get("PM_EMBED_ATOMIC"):
         _call("pm_embed_bwd", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K)
+        return
+    if F <= 1024 and not os.environ.get("PM_EMBED_FIXEDPOINT"):        # A/B knob: the fixed-point atomic form
+        n = -(-idx.numel() // 2048) * K * F
+        key = (dtable.device.index, _stream(), n)
+        scratch = _VQ_SCRATCH.get(key)
+        if scratch is None:
+            scratch = _VQ_SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=dtable.device)
+        _call("pm_embed_bwd_sorted", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K, scratch.data_ptr(), n)
         return
     key = (dtable.data_ptr(), K, F)
     scratch = _embed_scratch.get(key)

@@ -108,7 +108,7 @@ def test_rows_sum_forms(B, N, P):
     assert rel_err(out, x.sum(1)) < 2e-6
 
 
-def test_embed_categorical_and_dropout_mask():
+def test_embed_categorical_and_dropout_mask(monkeypatch):
     from posterior_matching_amd import ops
 
     gen = torch.Generator().manual_seed(1)
@@ -126,6 +126,17 @@ def test_embed_categorical_and_dropout_mask():
         ops.embed_bwd(idd, f32d(dout), dt)
         want = torch.ones((K, F), dtype=F64).index_add_(0, idx, dout)
         assert rel_err(dt, want) < 1e-6, (B, P, K, F)
+        # the fixed-order form (pm_embed_bwd_sorted, the default) twice: the same bits; the fixed-point atomic form
+        # (pm_embed_bwd_exact) and the f32-atomic one agree with it to rounding
+        dt2 = torch.ones((K, F), device=dev())
+        ops.embed_bwd(idd, f32d(dout), dt2)
+        assert torch.equal(dt, dt2)
+        for knob in ("PM_EMBED_FIXEDPOINT", "PM_EMBED_ATOMIC"):
+            monkeypatch.setenv(knob, "1")
+            dt3 = torch.ones((K, F), device=dev())
+            ops.embed_bwd(idd, f32d(dout), dt3)
+            monkeypatch.delenv(knob)
+            assert rel_err(dt3, want) < 1e-6 and rel_err(dt3, dt) < 1e-6, (knob, B, P, K, F)
     B, P, K, F = 5, 49, 256, 128
     R = B * P
     idx = torch.randint(0, K, (R,), generator=gen)
