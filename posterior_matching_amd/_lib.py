@@ -180,6 +180,7 @@ SIGNATURES = {
     "pm_gate_fwd_ce": [_P, _P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_gate_bwd": [_P, _P, _P, _P, _P, _LL, _I, _I],
     "pm_rows_sum": [_P, _P, _P, _LL, _I, _I],
+    "pm_rows_sum_multi": [_P, _P, _I, _P, C.c_longlong, _I, _I],
     "pm_groups_sum": [_P, _P, _P, _LL, _I, _LL, _I],
     "pm_elu_fwd": [_P, _P, _P, _LL],
     "pm_elu_bwd": [_P, _P, _P, _P, _LL, _I],

@@ -218,6 +218,36 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict_
     }
 }
 
+// G tensors of the same shape in ONE launch (blockIdx.z picks the tensor): the row sums of every gated block's dy - the
+// conditional projection's gradient, read only at the end of the backward pass - were one 4 us launch-floor kernel per block
+// (48 per step at the CelebA PixelCNN's size).
+constexpr int RSM_MAX = 64;
+struct RowsSumMulti { const float* x[RSM_MAX]; };
+__global__ __launch_bounds__(1024) void rows_sum_multi_kernel(RowsSumMulti a, float* __restrict__ out, long long B, int N, int P) {
+    __shared__ float red[32][33];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long long b = blockIdx.y;
+    const int n = blockIdx.x * 32 + col;
+    float s = 0.f;
+    if (n < N) {
+        const float* p = a.x[blockIdx.z] + (size_t)b * P * N + n;
+        int j = rg;
+        for (; j + 96 < P; j += 128) {
+            const float v0 = p[(size_t)j * N], v1 = p[(size_t)(j + 32) * N], v2 = p[(size_t)(j + 64) * N], v3 = p[(size_t)(j + 96) * N];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; j < P; j += 32) s += p[(size_t)j * N];
+    }
+    red[rg][col] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][col];
+        out[((size_t)blockIdx.z * B + b) * N + n] = t;
+    }
+}
+
 // The same sum with 16-byte loads, one workgroup per (example, 256 columns): 64 column quads x 4 row groups, every thread's
 // P / 4 loads are independent (the 32-column form above is 2048 workgroups of 6 KB each at the mnist PixelCNN's size: 18 us
 // for 12.8 MB).  N % 4 == 0, 16-byte aligned x / out.
@@ -720,6 +750,19 @@ extern "C" int pm_gate_bwd_rows_sum(pm_stream_t stream, const float* y, const fl
     hipLaunchKernelGGL(gate_bwd_rows_sum_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (cp)y, (cp)h, (cp)dout,
                        (pc_f32x4*)dy, (pc_f32x4*)dh, (unsigned)F4, (unsigned)P);
     return pm_check_launch("pm_gate_bwd_rows_sum");
+}
+
+extern "C" int pm_rows_sum_multi(pm_stream_t stream, const float* const* xs, int G, float* out, long long B, int N, int P) {
+    if (!xs || !out || G <= 0 || G > RSM_MAX || B <= 0 || B > 65535 || N <= 0 || P <= 0) return PM_EINVAL;
+    RowsSumMulti a;
+    for (int g = 0; g < RSM_MAX; ++g) {
+        a.x[g] = xs[g < G ? g : 0];
+        if (!a.x[g]) return PM_EINVAL;
+    }
+    PM_KTAG("rows_sum_multi_kernel");
+    hipLaunchKernelGGL(rows_sum_multi_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)B, (unsigned)G), dim3(1024), 0,
+                       (hipStream_t)stream, a, out, B, N, P);
+    return pm_check_launch("pm_rows_sum_multi");
 }
 
 extern "C" int pm_rows_sum(pm_stream_t stream, const float* x, float* out, long long B, int N, int P) {

@@ -333,15 +333,25 @@ extern "C" int pm_vq_dw_exact(pm_stream_t stream, const float* z, const int* idx
 // dtable[idx[r], :] += dout[r, :] (the gradient of an embedding lookup: PixelCNN input embedding, reference pixel_cnn.py:372-380
 // under jax.grad) in a FIXED order, two launches: the segment kernel above with [K][F] sums, then dtable += the segments in
 // order.  Replaces the four launches of pm_embed_bwd_exact (64-bit fixed-point atomics: 175 us at the CelebA PixelCNN's 4096 rows
-// x 128 features x 512 codes, at the very end of the backward pass) where F <= 1024.  scratch: ceil(rows / 2048) * K * F floats.
+// x 128 features x 512 codes, at the very end of the backward pass) where F <= 1024.  scratch: >= ceil(rows / 2048) * K * F floats
+// (ceil(rows / 512) * K * F lets it use the shortest segments).
 extern "C" int pm_embed_bwd_sorted(pm_stream_t stream, const int* idx, const float* dout, float* dtable, long long rows, int F,
                                    int K, float* scratch, long long scratch_floats) {
     if (!idx || !dout || !dtable || !scratch || rows <= 0 || rows > 0x7fffffffLL || F <= 0 || F > 1024 || K <= 0) return PM_EINVAL;
-    const int N = (int)rows, S = vq_dw_segments(N);
+    // Shorter segments bound the work of a code that takes most rows (a random-init codebook: perplexity 2 - 5; the workgroup
+    // of such a code adds seg / RL rows one after the other - 84 us at 4096 rows x 512 codes with 2048-row segments), as long as
+    // the grid stays <= 4096 workgroups; never more segments than the caller's scratch holds.
+    const int N = (int)rows;
+    int seg = VQ_SEG;
+    for (int cand : {512, 1024}) {
+        const long long S2 = (N + cand - 1) / cand;
+        if ((long long)K * S2 <= 4096 && scratch_floats >= S2 * F * K) { seg = cand; break; }
+    }
+    const int S = (N + seg - 1) / seg;
     if (S > 65535 || scratch_floats < (long long)S * F * K) return PM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     PM_KTAG("vq_dw_exact_kernel<true>");
-    hipLaunchKernelGGL(vq_dw_exact_kernel<true>, dim3(K, S), dim3(1024), 0, s, dout, idx, scratch, N, F, K, 1024 / F, VQ_SEG);
+    hipLaunchKernelGGL(vq_dw_exact_kernel<true>, dim3(K, S), dim3(1024), 0, s, dout, idx, scratch, N, F, K, 1024 / F, seg);
     hipLaunchKernelGGL(vq_dw_sum_kernel<true>, dim3((F * K + 255) / 256), dim3(256), 0, s, scratch, dtable, F * K, S);
     return pm_check_launch("pm_embed_bwd_sorted");
 }

@@ -347,7 +347,10 @@ class PixelCNN(Module):
         else:
             ops.gate_bwd(y, hp, dout, dy, P)
             if dh_all is not None:
-                ops.rows_sum(dy.view(R, 2 * F), dh_all[blk.group], P)
+                if self._dy_pending is not None:
+                    self._dy_pending.append((blk.group, dy.view(R, 2 * F)))   # summed over positions by ONE launch at the tail
+                else:
+                    ops.rows_sum(dy.view(R, 2 * F), dh_all[blk.group], P)
         ce2 = self.buf(f"{n}/ce2", sh(2 * F))
         self._wg(blk.conv2, ce2, dy)
         dce2 = self.buf(f"{n}/dce2", sh(2 * F))
@@ -432,6 +435,8 @@ class PixelCNN(Module):
 
         ops.elu_bwd(self._up_h, dx_out, gbuf(self._up_h, gname(self._up_h)), accumulate=True)
         dh_all = self.buf("dhproj", (G, B, 2 * F)) if self._hproj is not None else None
+        # blocks that do not take the fused gate + row-sum launch leave their dy here; one pm_rows_sum_multi at the tail
+        self._dy_pending = None if os.environ.get("PM_NO_ROWS_SUM_MULTI") else []
 
         # Two chains again (see logits): a horizontal block's backward writes gradients of horizontal tensors and of ONE
         # vertical tensor (its extra_a); a vertical block only touches vertical tensors.  With the horizontal blocks'
@@ -511,6 +516,16 @@ class PixelCNN(Module):
         self._gslab_used[B] = used[0]
         if dh_all is None:
             return None
+        pend = self._dy_pending or []
+        if pend:
+            P_ = self._event_shape[0] * self._event_shape[1]
+            pend.sort(key=lambda t: t[0])
+            if len(pend) == G and [g_ for g_, _ in pend] == list(range(G)) and G <= ops.ROWS_SUM_MULTI_MAX:
+                ops.rows_sum_multi([t for _, t in pend], dh_all, P_)
+            else:
+                for g_, t in pend:
+                    ops.rows_sum(t, dh_all[g_], P_)
+            self._dy_pending = []
         gw, gb_ = self._cond_params("g")
         kw = self._cond_kw(B)
         ops.layer_wgrad(self.g_cond, self._cond, dh_all, gw, gb_, bf16=False, **kw)

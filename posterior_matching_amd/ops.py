@@ -1060,7 +1060,7 @@ def embed_bwd(idx, dout, dtable) -> None:
         _call("pm_embed_bwd", _iptr(idx), _ptr(dout), _ptr(dtable), idx.numel(), F, K)
         return
     if F <= 1024 and not os.environ.get("PM_EMBED_FIXEDPOINT"):        # A/B knob: the fixed-point atomic form
-        n = -(-idx.numel() // 2048) * K * F
+        n = -(-idx.numel() // 512) * K * F             # room for the shortest segments (pm_embed_bwd_sorted picks)
         key = (dtable.device.index, _stream(), n)
         scratch = _VQ_SCRATCH.get(key)
         if scratch is None:
@@ -1154,6 +1154,17 @@ def gate_bwd(y, h, dout, dy, P: int) -> None:
 def rows_sum(x, out, P: int) -> None:
     N = x.shape[-1]
     _call("pm_rows_sum", _ptr(x), _ptr(out), x.numel() // (N * P), N, P, work={"bytes": _nbytes(x, out)})
+
+
+ROWS_SUM_MULTI_MAX = 64
+
+
+def rows_sum_multi(xs, out, P: int) -> None:
+    """out[g] = rows_sum(xs[g]) for <= 64 tensors of one shape in one launch (pm_rows_sum_multi)"""
+    N = xs[0].shape[-1]
+    arr = _ptr_array(xs)                    # host array of device pointers: lives in the recorded call's argument tuple
+    _call("pm_rows_sum_multi", arr, len(xs), _ptr(out), xs[0].numel() // (N * P), N, P,
+          work={"bytes": sum(_nbytes(x) for x in xs) + _nbytes(out)})
 
 
 def groups_sum(x, out, G: int, accumulate: bool = False) -> None:
