@@ -174,8 +174,25 @@ class _PlannedStep:
 
     def _adam_step(self, s, step_dev) -> None:
         """optax.scale_by_adam -> add_decayed_weights -> schedule -> apply_updates on the flat buffers.  With partial sums
-        pending (one GPU) the optimizer kernel adds them as it reads g; otherwise g already holds the gradient."""
+        pending (one GPU) the optimizer kernel adds them as it reads g; otherwise g already holds the gradient.  Ranges an
+        early update of this step already covered (_early_adam) are left out."""
         ps = s.partials
+        early = getattr(self, "_early_done", None) or []
+        self._early_done = []
+        if early:                                   # the complement of the ranges updated during the backward pass
+            rest, pos = [], 0
+            for a, b in sorted(early):
+                if a > pos:
+                    rest.append((pos, a))
+                pos = b
+            if pos < s.flat_p.numel():
+                rest.append((pos, s.flat_p.numel()))
+            tab = ps.adam_table(rest)
+            if tab is None:
+                raise RuntimeError("early optimizer ranges left a gradient run straddling their boundary")
+            table, njobs, nbytes = tab
+            ops.adam_step_jobs(table, njobs, s.flat_p, s._flat_g, s.flat_m, s.flat_v, s.n_decay, step_dev, self.adam_cfg, nbytes)
+            return
         if ps is not None and ps.pending and s.reducer is None and self._fuse_adam():
             tab = ps.adam_table()
             if tab is not None:
@@ -185,6 +202,33 @@ class _PlannedStep:
                 return
             s.reduce_partials()
         ops.adam_step(s.flat_p, s.flat_g, s.flat_m, s.flat_v, s.n_decay, step_dev, self.adam_cfg)
+
+    early_adam = not os.environ.get("PM_NO_EARLY_ADAM")          # A/B switch
+
+    def _early_adam(self, s, prefixes, step_dev) -> bool:
+        """A model's backward pass reports (on the stream those launches ran on) that the WEIGHTS under `prefixes` have their
+        final gradients and are not read again this step: their optimizer update - HBM-bound, 8 passes over the range - runs
+        now, on the current stream, beside the rest of the backward pass instead of after it.  One GPU, plain Adam, fused
+        partial sums only; the update at the end of the step covers the complement.  Same arithmetic per element, so the
+        step's results do not change."""
+        ps = s.partials
+        if not (self.early_adam and ps is not None and s.reducer is None and self._fuse_adam()) or self.adam_cfg is None:
+            return False
+        offs = [(o, o + n) for name, (o, n) in s.offsets.items()
+                if o < s.n_decay and any(name == p or name.startswith(p + "/") for p in prefixes)]
+        if not offs:
+            return False
+        lo, hi = min(a for a, _ in offs), max(b for _, b in offs)
+        hi = (hi + 3) // 4 * 4
+        if sum((b - a + 3) // 4 * 4 for a, b in offs) != hi - lo or lo % 4:
+            return False                            # not one contiguous run of the flat buffer
+        tab = ps.adam_table([(lo, hi)])
+        if tab is None:
+            return False
+        table, njobs, nbytes = tab
+        ops.adam_step_jobs(table, njobs, s.flat_p, s._flat_g, s.flat_m, s.flat_v, s.n_decay, step_dev, self.adam_cfg, nbytes)
+        self._early_done = (getattr(self, "_early_done", None) or []) + [(lo, hi)]
+        return True
 
     def _fresh_grads_before_graph(self, store) -> None:
         """A captured step was recorded while the gradient buffer was known to be zero (no zero-fill inside the graph): if host
@@ -611,6 +655,13 @@ class PMVQVAETrainStep(_PlannedStep):
             # as soon as its data gradients are done; the latency-bound rest of the pass (embedding scatter, conditional
             # projection, the partial encoder's chain) runs beside them on the second stream
             tail = batched and not self.reducer and not os.environ.get("PM_PX_SERIAL_TAIL")
+            # PM_PX_EARLY_ADAM=1 (one GPU): the optimizer update of the up pass's weights runs on a third stream beside the down
+            # pass's backward chains (_early_adam).  MEASURED, same box, two pairs: pm_vqvae_celeb_a 7.39 vs 7.10 ms,
+            # pm_vqvae_mnist 9.61 vs 9.44 ms WITHOUT it - a third stream of HBM-bound work slows the two latency-bound chains more
+            # than the shorter tail returns (the same verdict as every third-stream experiment of rounds 3 and 4): off by default
+            self.pcnn.early_update = ((lambda prefixes: self._early_adam(s, prefixes, self.step_dev))
+                                      if (batched and not self.reducer and self.adam_cfg is not None and self.early_adam
+                                          and os.environ.get("PM_PX_EARLY_ADAM", "0") == "1") else None)
             dcond = self.pcnn.backward(self.g_ll, overlap_tail=tail)
             ts = self.pcnn.tail_stream if tail else None
             if ts is not None:

@@ -465,7 +465,8 @@ class PixelCNN(Module):
         for blk in reversed(self.blocks):
             vertical = blk.stack == "vertical"
             if (two and fs is None and blk.name.startswith("down")
-                    and (os.environ.get("PM_PIXELCNN_MID_FLUSH") or self.store.reducer is not None)):
+                    and (os.environ.get("PM_PIXELCNN_MID_FLUSH") or self.store.reducer is not None
+                         or getattr(self, "early_update", None) is not None)):
                 # (measured neutral on one GPU: celeb_a 1638 -> 1622 img/s, mnist 20.3k -> 20.5k; off unless asked for.  Data-
                 # parallel: ON - the up pass's weights (half of the 140 / 273 MB gradient) are final after this flush, so
                 # their buckets are all-reduced beside the whole down pass instead of after the last launch)
@@ -478,6 +479,11 @@ class PixelCNN(Module):
                 ops.wait_stream(fs, vs)
                 with torch.cuda.stream(fs):
                     self.ws.wgrad_batch.flush()
+                    if getattr(self, "early_update", None) is not None:
+                        # one GPU: the up pass's WEIGHTS (half of the network) have their final gradients and no later launch
+                        # of this step reads them - the train step runs their optimizer update here, on this third stream,
+                        # beside the two latency-bound chains of the down pass (engine._PlannedStep._early_adam)
+                        self.early_update([f"{self.prefix}/{b_.name}" for b_ in self.blocks if not b_.name.startswith("down")])
             if two and vertical:
                 # its output was read (as extra_a) by the horizontal block right behind it in execution order
                 ops.wait_event(vs, self._hev[blk.group + 1])
@@ -496,7 +502,7 @@ class PixelCNN(Module):
         self._wg(self.v_init, emb, dv0)
         self._wg(self.h_up, emb, dh0)
         self._wg(self.h_left, emb, dh0)
-        if overlap_tail and two and fs is None:
+        if overlap_tail and two:
             self.tail_stream = vs
             ops.wait_stream(vs, main)
             self.ws.wgrad_batch.flush()                      # main: every convolution's weight gradient of this network

@@ -140,15 +140,25 @@ class PartialSums:
         nbytes = sum((self.entries[k][1] + 2) * k[1] * 4.0 for k in keys)
         ops.reduce_partials(table, njobs, self.flat, nbytes)
 
-    def adam_table(self):
+    def adam_table(self, ranges=None):
         """Job table of pm_adam_step_jobs: every pending run, plus runs without partial sums for the rest of the flat buffer.
         Returns (device table, njobs, arena bytes read) and takes the runs off the pending set; None when a run or the buffer
-        is not made of whole 16-byte vectors (PM_NO_PARAM_PAD builds): the caller reduces and runs the plain optimizer."""
-        keys = tuple(sorted(self.pending))
+        is not made of whole 16-byte vectors (PM_NO_PARAM_PAD builds): the caller reduces and runs the plain optimizer.
+        ranges: sorted, disjoint (lo, hi) element ranges (multiples of 4) - the table covers exactly their union and only the
+        pending runs inside them are taken (an optimizer update of the parameters whose gradients are final, while the rest
+        of the backward pass still runs); a pending run that straddles a range boundary -> None."""
         n = self.flat.numel()
+        ranges = tuple((int(a), int(b)) for a, b in ranges) if ranges is not None else ((0, n),)
+        if any(a % 4 or (b % 4 and b != n) or a >= b for a, b in ranges):
+            return None
+        inside = lambda k: any(a <= k[0] and k[0] + (k[1] + 3) // 4 * 4 <= b for a, b in ranges)     # noqa: E731
+        touches = lambda k: any(k[0] < b and a < k[0] + k[1] for a, b in ranges)                   # noqa: E731
+        keys = tuple(sorted(k for k in self.pending if touches(k)))
+        if any(not inside(k) for k in keys):
+            return None
         if n % 4 or any(k[0] % 4 or self.entries[k][2] % 4 or self.entries[k][3] % 4 for k in keys):
             return None
-        cached = self._tables.get(("adam",) + keys)
+        cached = self._tables.get(("adam", ranges) + keys)
         if cached is None:
             jobs: List[ReduceJob] = []
 
@@ -158,27 +168,32 @@ class PartialSums:
                     j.src, j.stride, j.g_off, j.count, j.nslots = None, 0, o, min(1024, hi - o), 0
                     jobs.append(j)
 
-            pos, nbytes = 0, 0.0
-            for key in keys:
-                g_off, count = key
-                buf, nslots, stride, src_off = self.entries[key]
-                plain(pos, g_off)
-                per = 256 if nslots >= 8 else 1024
-                base = buf.data_ptr() + 4 * src_off
-                cnt4 = (count + 3) // 4 * 4              # whole vectors: the pad elements are zero in every buffer
-                for o in range(0, cnt4, per):
-                    j = ReduceJob()
-                    j.src, j.stride, j.g_off = base + 4 * o, stride, g_off + o
-                    j.count, j.nslots = min(per, cnt4 - o), nslots
-                    jobs.append(j)
-                pos = g_off + cnt4
-                nbytes += nslots * count * 4.0
-            plain(pos, n)
+            nbytes = 0.0
+            for lo, hi in ranges:
+                pos = lo
+                for key in keys:
+                    g_off, count = key
+                    if not (lo <= g_off < hi):
+                        continue
+                    buf, nslots, stride, src_off = self.entries[key]
+                    plain(pos, g_off)
+                    per = 256 if nslots >= 8 else 1024
+                    base = buf.data_ptr() + 4 * src_off
+                    cnt4 = (count + 3) // 4 * 4              # whole vectors: the pad elements are zero in every buffer
+                    for o in range(0, cnt4, per):
+                        j = ReduceJob()
+                        j.src, j.stride, j.g_off = base + 4 * o, stride, g_off + o
+                        j.count, j.nslots = min(per, cnt4 - o), nslots
+                        jobs.append(j)
+                    pos = g_off + cnt4
+                    nbytes += nslots * count * 4.0
+                plain(pos, hi)
             raw = b"".join(bytes(j) for j in jobs)
             dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat.device)
             cached = (dev, len(jobs), nbytes)
-            self._tables[("adam",) + keys] = cached
-        self.pending.clear()
+            self._tables[("adam", ranges) + keys] = cached
+        for k in keys:
+            del self.pending[k]
         return cached
 
     def flush_sync(self) -> None:
