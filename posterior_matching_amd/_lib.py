@@ -101,6 +101,12 @@ class WgradPart(C.Structure):
     ]
 
 
+class ColsumJob(C.Structure):
+    """struct pm_colsum_job (include/pmhip.h)"""
+    _fields_ = [("x", C.c_void_p), ("part", C.c_void_p), ("part_stride", C.c_longlong), ("M", C.c_longlong),
+                ("N", C.c_int), ("nslots", C.c_int)]
+
+
 class ReduceJob(C.Structure):
     """struct pm_reduce_job (include/pmhip.h)."""
 
@@ -135,6 +141,7 @@ SIGNATURES = {
     "pm_thin_wgrad_part": [_P, C.POINTER(GatherDesc), _P, _P, C.POINTER(WgradPart)],
     "pm_colsum_part_slots": [_LL, _I, C.POINTER(_I)],
     "pm_colsum_part": [_P, _P, _LL, _I, _P, _LL, _I],
+    "pm_colsum_part_multi": [_P, _P, _I],
     "pm_reduce_partials": [_P, _P, _I, _P],
     "pm_adam_step_jobs": [_P, _P, _I, _P, _P, _P, _P, _LL, _P, C.POINTER(AdamCfg)],
     "pm_thin_conv": [_P, C.POINTER(GatherDesc), _P, _P, _P, _P, _P, _P],

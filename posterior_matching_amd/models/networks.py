@@ -121,6 +121,15 @@ class ConvDecoder(Module):
     def backward(self, dpre: torch.Tensor, need_input_grad: bool = True, lend=None) -> Optional[torch.Tensor]:
         """lend = (stream, n): the weight gradients of layers 0 .. n-1 (the last n of this pass) are queued on `stream`"""
         B = dpre.shape[0]
+        # the bias gradients (column sums of every layer's dpre, read only by the optimizer) wait for ONE launch at the end of
+        # this pass: the dpre_i buffers are per layer and stay untouched until then
+        ops.colsum_defer_begin()
+        try:
+            return self._backward(dpre, need_input_grad, lend, B)
+        finally:
+            ops.colsum_defer_flush()
+
+    def _backward(self, dpre, need_input_grad, lend, B):
         for i in reversed(range(len(self.geoms))):
             g = self.geoms[i]
             inp = self._outs[i - 1] if i > 0 else self._x.t

@@ -1638,6 +1638,35 @@ def fill_zero(t) -> None:
     _call("pm_fill_zero", t.data_ptr(), t.numel() * t.element_size())
 
 
+_colsum_deferred: Optional[list] = None      # (x, arena address, stride, M, N, nslots) of column sums waiting for ONE launch
+
+
+def colsum_defer_begin() -> None:
+    """column sums into a ParamStore's gradient buffer issued from here on wait for colsum_defer_flush(): their inputs must
+    stay untouched until then (a decoder's per-layer dpre buffers do)"""
+    global _colsum_deferred
+    if _colsum_deferred is None and not os.environ.get("PM_NO_COLSUM_MULTI"):
+        _colsum_deferred = []
+
+
+def colsum_defer_flush() -> None:
+    """launches the deferred column sums: one pm_colsum_part_multi per 8 of them, on the current stream"""
+    global _colsum_deferred
+    jobs, _colsum_deferred = _colsum_deferred or [], None
+    for i in range(0, len(jobs), 8):
+        chunk = jobs[i:i + 8]
+        if len(chunk) == 1:
+            x, part, stride, M, N, ns = chunk[0]
+            _call("pm_colsum_part", _ptr(x), M, N, part, stride, ns, tag="colsum_part_kernel",
+                  work={"bytes": _nbytes(x) + 4.0 * ns * N})
+            continue
+        arr = (_lib.ColsumJob * len(chunk))()
+        for j, (x, part, stride, M, N, ns) in enumerate(chunk):
+            arr[j].x, arr[j].part, arr[j].part_stride, arr[j].M, arr[j].N, arr[j].nslots = x.data_ptr(), part, stride, M, N, ns
+        _call("pm_colsum_part_multi", arr, len(chunk), tag="colsum_part_multi_kernel",
+              work={"bytes": sum(_nbytes(x) + 4.0 * ns * N for x, _, _, _, N, ns in chunk)})
+
+
 def colsum(x, out) -> None:
     """out[n] += sum_m x[m, n].  `out` inside a ParamStore's gradient buffer: per-workgroup partial sums (no atomics,
     deterministic; partials.PartialSums), added by the store's next reduce."""
@@ -1652,6 +1681,9 @@ def colsum(x, out) -> None:
             and _lib.load().pm_colsum_part_slots(M, N, C.byref(ns)) == 0):
         buf, off = own.arena(own.offset(out), N, ns.value)
         stride = own.entries[(own.offset(out), N)][2]
+        if _colsum_deferred is not None:
+            _colsum_deferred.append((x, buf.data_ptr() + 4 * off, stride, M, N, ns.value))
+            return
         _call("pm_colsum_part", _ptr(x), M, N, buf.data_ptr() + 4 * off, stride, ns.value, tag="colsum_part_kernel",
               work={"bytes": _nbytes(x) + 4.0 * ns.value * N})
         return
