@@ -224,8 +224,19 @@ __global__ __launch_bounds__(256) void diag_sample_kl_bwd_kernel(const float* __
 // were  add_cols + diag_sample_kl_fwd + a 16 -> 192 1x1 convolution  and  that convolution's data gradient +
 // diag_sample_kl_bwd + copy_cols: three launches of 8 - 13 us each on a dependent chain of 20 decoder blocks, for a few
 // hundred FMAs per position.  One wave per position row (SP_RW rows per wave), W_z in LDS, f32 FMAs.
-constexpr int SP_RW = 4;
-__global__ __launch_bounds__(256) void sample_project_fwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
+// Rows are dealt one per wave, SP_NW waves per workgroup: the first form (4 waves x 4 rows one after the other) spent its 25 us
+// in four serial load -> softplus / log -> wave sum -> store chains per wave and lost to the three separate launches; one row
+// per wave runs the chains of a workgroup's 16 rows side by side, W_z is staged once per 16 rows, and a workgroup makes ONE
+// atomic add to its example's KL (49 per example at 28 x 28, as the unfused kernel does).
+#ifndef PM_SP_RW
+#define PM_SP_RW 1
+#endif
+#ifndef PM_SP_NW
+#define PM_SP_NW 16
+#endif
+constexpr int SP_RW = PM_SP_RW;
+constexpr int SP_NW = PM_SP_NW;
+__global__ __launch_bounds__(64 * SP_NW) void sample_project_fwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
                                                                   int ldp, const float* __restrict__ eps,
                                                                   const float* __restrict__ x_in, const float* __restrict__ wz,
                                                                   const float* __restrict__ bz, float* __restrict__ z,
@@ -234,14 +245,14 @@ __global__ __launch_bounds__(256) void sample_project_fwd_kernel(const float* __
     extern __shared__ float sp_lds[];
     float* Wl = sp_lds;                  // [Z][W]
     float* bl = Wl + Z * W;              // [W]
-    float* zr = bl + W;                  // [4][Z]
-    __shared__ float wsum[4];
-    for (int e = threadIdx.x; e < Z * W; e += 256) Wl[e] = wz[e];
-    for (int e = threadIdx.x; e < W; e += 256) bl[e] = bz ? bz[e] : 0.f;
+    float* zr = bl + W;                  // [SP_NW][Z]
+    __shared__ float wsum[SP_NW];
+    for (int e = threadIdx.x; e < Z * W; e += 64 * SP_NW) Wl[e] = wz[e];
+    for (int e = threadIdx.x; e < W; e += 64 * SP_NW) bl[e] = bz ? bz[e] : 0.f;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long r_first = (long long)blockIdx.x * 4 * SP_RW;
-    long long r_last = r_first + 4 * SP_RW - 1;
+    const long long r_first = (long long)blockIdx.x * SP_NW * SP_RW;
+    long long r_last = r_first + SP_NW * SP_RW - 1;
     if (r_last > R - 1) r_last = R - 1;
     const bool one_example = r_first / P == r_last / P;      // 784 rows adding to ONE address one by one serialise in L2
     float klacc = 0.f;
@@ -270,11 +281,15 @@ __global__ __launch_bounds__(256) void sample_project_fwd_kernel(const float* __
     if (one_example) {
         if (lane == 0) wsum[wave] = klacc;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(kl + r_first / P, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < SP_NW; ++w) t += wsum[w];
+            atomicAdd(kl + r_first / P, t);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void sample_project_bwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
+__global__ __launch_bounds__(64 * SP_NW) void sample_project_bwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
                                                                   int ldp, const float* __restrict__ eps,
                                                                   const float* __restrict__ dx2, const float* __restrict__ wz,
                                                                   float g_kl, float* __restrict__ dpost,
@@ -282,8 +297,8 @@ __global__ __launch_bounds__(256) void sample_project_bwd_kernel(const float* __
     extern __shared__ float sp_lds[];
     const int WP = W + 1;                // padded pitch: the Z rows of a column fall into different banks
     float* Wl = sp_lds;                  // [Z][W + 1]
-    float* dr = Wl + Z * WP;             // [4][W]
-    for (int e = threadIdx.x; e < Z * W; e += 256) Wl[(e / W) * WP + e % W] = wz[e];
+    float* dr = Wl + Z * WP;             // [SP_NW][W]
+    for (int e = threadIdx.x; e < Z * W; e += 64 * SP_NW) Wl[(e / W) * WP + e % W] = wz[e];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // lane -> (latent j, one of NCH column ranges): NCH * Z = 64 for Z = 16; other Z: NCH = 1 and lanes >= Z idle in the dot product
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(256) void sample_project_bwd_kernel(const float* __
     const int wlen = (W + NCH - 1) / NCH;
     float* drow = dr + wave * W;
     for (int it = 0; it < SP_RW; ++it) {
-        const long long r = ((long long)blockIdx.x * 4 + wave) * SP_RW + it;
+        const long long r = ((long long)blockIdx.x * SP_NW + wave) * SP_RW + it;
         if (r >= R) break;                                   // wave-uniform
         for (int w = lane; w < W; w += 64) {
             const float v = dx2[r * W + w];
@@ -813,9 +828,9 @@ extern "C" int pm_sample_project_fwd(pm_stream_t stream, const float* post, cons
     if (!post || !prior || !eps || !x_in || !wz || !z || !x2 || !kl || rows <= 0 || Z <= 0 || Z > 64 || W <= 0 || P <= 0 ||
         ldp < 2 * Z + W)
         return PM_EINVAL;
-    const size_t lds = ((size_t)Z * W + W + 4 * Z) * sizeof(float);
+    const size_t lds = ((size_t)Z * W + W + SP_NW * Z) * sizeof(float);
     if (lds > 60 * 1024) return PM_EINVAL;
-    hipLaunchKernelGGL(sample_project_fwd_kernel, dim3((unsigned)((rows + 4 * SP_RW - 1) / (4 * SP_RW))), dim3(256), lds,
+    hipLaunchKernelGGL(sample_project_fwd_kernel, dim3((unsigned)((rows + SP_NW * SP_RW - 1) / (SP_NW * SP_RW))), dim3(64 * SP_NW), lds,
                        (hipStream_t)stream, post, prior, ldp, eps, x_in, wz, bz, z, x2, kl, rows, Z, W, P);
     return pm_check_launch("pm_sample_project_fwd");
 }
@@ -826,9 +841,9 @@ extern "C" int pm_sample_project_bwd(pm_stream_t stream, const float* post, cons
     if (!post || !prior || !eps || !dx2 || !wz || !dpost || !dprior || rows <= 0 || Z <= 0 || Z > 64 || W <= 0 ||
         ldp < 2 * Z + W)
         return PM_EINVAL;
-    const size_t lds = ((size_t)Z * (W + 1) + 4 * W) * sizeof(float);
+    const size_t lds = ((size_t)Z * (W + 1) + SP_NW * W) * sizeof(float);
     if (lds > 60 * 1024) return PM_EINVAL;
-    hipLaunchKernelGGL(sample_project_bwd_kernel, dim3((unsigned)((rows + 4 * SP_RW - 1) / (4 * SP_RW))), dim3(256), lds,
+    hipLaunchKernelGGL(sample_project_bwd_kernel, dim3((unsigned)((rows + SP_NW * SP_RW - 1) / (SP_NW * SP_RW))), dim3(64 * SP_NW), lds,
                        (hipStream_t)stream, post, prior, ldp, eps, dx2, wz, g_kl, dpost, dprior, rows, Z, W);
     return pm_check_launch("pm_sample_project_bwd");
 }

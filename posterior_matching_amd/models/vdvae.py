@@ -396,8 +396,10 @@ class PosteriorMatchingDecoderBlock(Module):
             ops.wait_stream(main, s1)
             ops.wait_stream(main, s2)
         self._z = self.buf("z", sh(Z))
-        # one launch for the three steps - measured no faster than the three (891 vs 897 img/s at per-GPU 8): off unless asked for
-        fuse_sp = bool(os.environ.get("PM_VDVAE_SAMPLE_PROJECT"))
+        # one launch for the three steps.  Its first form (four rows per wave, one after the other) was no faster than the three
+        # launches (891 vs 897 img/s at per-GPU 8); with one row per wave and 16 waves per workgroup it is: 8.49 -> 8.24 ms
+        # (PM_VDVAE_NO_SAMPLE_PROJECT=1: the three launches, A/B)
+        fuse_sp = not os.environ.get("PM_VDVAE_NO_SAMPLE_PROJECT")
         x2 = self.buf("x2", sh(W))
         if fuse_sp:     # x += h (:558), sample + KL (:559-561), x += z_proj(z) (:562): one launch
             ops.sample_project_fwd(self._pp, self._pr, eps, x_in, self.store.p[self.z_proj.w].view(Z, W),
@@ -547,7 +549,7 @@ class PosteriorMatchingDecoderBlock(Module):
         self.resnet.backward(dx3, dx2, x_pre=self._x2, res=dx3)                 # dx2 = dx1
         self.wgrad(self.z_proj.g, self._z, dx2, self.store.g[self.z_proj.w], self.store.g[self.z_proj.b])
         dpp, dpr = self.buf("dpp", sh(2 * Z)), self.buf("dpr", sh(2 * Z + W))
-        if os.environ.get("PM_VDVAE_SAMPLE_PROJECT"):
+        if not os.environ.get("PM_VDVAE_NO_SAMPLE_PROJECT"):
             # dz = z_proj^T(dx2), the sample / KL gradients, d h = d x1 = dx2: one launch
             ops.sample_project_bwd(self._pp, self._pr, self._eps, dx2, self.store.p[self.z_proj.w].view(Z, W), g_kl, dpp, dpr)
         else:

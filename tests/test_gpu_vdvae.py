@@ -393,11 +393,14 @@ def test_vdvae_forward_and_grads(bf16x3):
     assert worst[0] < (1e-4 if not bf16x3 else 1e-2), worst
 
 
-def test_vdvae_fused_sample_projection_path(monkeypatch):
-    """PM_VDVAE_SAMPLE_PROJECT=1: `x += h`, sample + KL and `x += z_proj(z)` as one launch, and their gradients as one
-    launch (pm_sample_project_fwd / _bwd, reference vdvae.py:558-562), against the float64 oracle like the default path"""
-    monkeypatch.setenv("PM_VDVAE_SAMPLE_PROJECT", "1")
-    B = 5
+@pytest.mark.parametrize("fused,B", [(True, 5), (True, 37), (False, 5)])
+def test_vdvae_fused_sample_projection_path(monkeypatch, fused, B):
+    """`x += h`, sample + KL and `x += z_proj(z)` as one launch, and their gradients as one launch (pm_sample_project_fwd /
+    _bwd, reference vdvae.py:558-562; the default since round 4's one-row-per-wave form) - and the three separate launches
+    (PM_VDVAE_NO_SAMPLE_PROJECT=1) - against the float64 oracle.  B = 37: workgroups of 16 rows that straddle examples at the
+    small resolutions, ragged last workgroups."""
+    if not fused:
+        monkeypatch.setenv("PM_VDVAE_NO_SAMPLE_PROJECT", "1")
     m, p64, x, b, eps = _setup(TINY, B, bf16x3=False)
     leaves = {n: t.clone().requires_grad_(True) for n, t in p64.items()}
     loss, aux, out = DO.vdvae_loss(leaves, TINY, x, b, eps)
