@@ -439,9 +439,16 @@ __global__ __launch_bounds__(256) void gmm_logprob_kernel(const float* __restric
                                                             const float* __restrict__ g, float* __restrict__ mll,
                                                             float* __restrict__ dhead, float* __restrict__ dz, int B,
                                                             int k, int kp, int nc, int accumulate_dz) {
-    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long bb = idx / kp;
-    const int ii = (int)(idx - bb * kp);
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long bb = idx / kp;
+    int ii = (int)(idx - bb * kp);
+    if (BWD) {
+        // backward: nothing crosses threads, so thread t takes head row t ([k][B] rows of 3 nc floats): neighbouring threads read
+        // neighbouring rows (the forward mapping - a wave = two examples' latent dims - puts them B rows = 30 KB apart: 30
+        // scattered 4-byte loads per thread on 32 workgroups, 25 us for 1 MB)
+        ii = (int)(idx / B);
+        bb = idx - (long long)ii * B;
+    }
     const bool ok = bb < B && ii < k;
     int b = ok ? (int)bb : 0;
     int i = ok ? ii : 0;
@@ -645,7 +652,8 @@ extern "C" int pm_gmm_logprob_bwd(pm_stream_t stream, const float* head, const f
     if (!head || !z || !g || !dhead || !gmm_shape_ok(B, k, nc)) return PM_EINVAL;
     const int kp = gmm_pow2(k);
     long long total = (long long)B * kp;
-    hipLaunchKernelGGL(gmm_logprob_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    total = (long long)B * k;                              // one thread per head row, 64-thread workgroups: 128 of them at B = 256
+    hipLaunchKernelGGL(gmm_logprob_kernel<true>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0,
                        (hipStream_t)stream, head, z, g, (float*)nullptr, dhead, dz, B, k, kp, nc, accumulate_dz);
     return pm_check_launch("pm_gmm_logprob_bwd");
 }
