@@ -1643,9 +1643,6 @@ __global__ __launch_bounds__(256, RN == 1 ? 3 : 2) void patch_conv_bd_bf16_kerne
 // replaces it; the accumulators stay in registers across the passes.  Operand traffic: every workgroup reads its patch once
 // (9 x 18 x 256 floats = 166 KB; 42 MB per launch).  The chunk of pass c + 1 is requested from memory BEFORE the k-loop of pass c
 // (registers), so its round trip hides behind that pass's MFMAs; two barriers per pass.
-#ifndef PM_CP_EXP
-#define PM_CP_EXP 0
-#endif
 // The k-steps of a pass are STRAIGHT-LINE code (SPC = steps per pass = 2 x taps is a template parameter): with the pass switch as a
 // branch inside the unrolled steps the compiler could not count the loads in flight at the join and drained them all
 // (s_waitcnt vmcnt(0)) at the head of every group of steps - weights requested NSET steps ahead arrived "just in time" by
@@ -1790,9 +1787,7 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
         if (ps) __syncthreads();                            // every wave is done with the old patch
         store_patch();                                      // this pass's pieces (requested one pass ago)
         __syncthreads();
-#if PM_CP_EXP != 3
         fetch_patch(ps + 1 < npass ? ps + 1 : 0);           // in flight during this pass's MFMAs (the last one is never stored)
-#endif
         int ao[2];                                          // A offsets, read from the table one step before they are needed
         read_a(abase + kd[sb].dy, 0);
         ao[1] = abase + kd[sb + 1].dy;
@@ -1806,17 +1801,11 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int r = 0; r < RN; ++r) {
-#if PM_CP_EXP == 1
-                    acc[r][0] += (float)ah[q & 1][kk][0] * (float)bq[u][r][2 * kk][0] + (float)al[q & 1][kk][1] * (float)bq[u][r][2 * kk + 1][0];
-#else
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q & 1][kk], bq[u][r][2 * kk + 1], acc[r], 0, 0, 0);
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[q & 1][kk], bq[u][r][2 * kk], acc[r], 0, 0, 0);
-#endif
                 }
-#if PM_CP_EXP != 2
             load_b(s + NSET, bq[u]);                        // NSET k-steps ahead (the table's padding covers the end)
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1831,9 +1820,6 @@ __global__ __launch_bounds__(256, 1) void patch_conv_cp_bf16_kernel(GemmArgs p, 
     for (int r = 0; r < RN; ++r) {
         int n = n0 + r * 32 + i;
         if (n >= g.N) continue;
-#if PM_CP_EXP == 4
-        if (acc[r][0] == 12345.f)
-#endif
         pm_epilogue_tile(acc[r], ro, n, bvr[r], aux, res, out, p.out2, p.act2, g.aux_act, g.out_act, g.slope);
     }
 }
