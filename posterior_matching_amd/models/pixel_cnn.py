@@ -176,8 +176,17 @@ class PixelCNN(Module):
         nxt = {b_.group: (self.blocks[i + 2] if i + 2 < len(self.blocks) else None) for i, b_ in enumerate(self.blocks)}
         have_ce1 = set()
 
+        self._ce_e: Dict[int, torch.Tensor] = {}
+        # concat_elu(t) that already exists for a block output t: the gate launch of the block that produced t wrote it as the
+        # ce1 of the next block of its stack.  A block whose ONLY extra input is t (the down pass's horizontal blocks: t = the
+        # vertical output of their level; the up pass's vertical blocks: t = a down-pass vertical output) reads that buffer
+        # instead of launching its own concat_elu (same tensor, no dropout, no second source).  PM_PX_NO_CE_ALIAS=1: A/B
+        ce_of: Dict[int, torch.Tensor] = {}
+        no_alias = bool(os.environ.get("PM_PX_NO_CE_ALIAS"))
+
         def run_block(blk: _Block, input_x, extra_a=None, extra_b=None):
             n = blk.name
+            ce_e_alias = None if (no_alias or extra_a is None or extra_b is not None) else ce_of.get(extra_a.data_ptr())
             ce1 = self.buf(f"{n}/ce1", sh(2 * F))
             if n not in have_ce1:
                 ops.concat_elu_fwd(input_x, None, None, ce1)
@@ -187,8 +196,12 @@ class PixelCNN(Module):
             else:
                 x1a = self.buf(f"{n}/x1a", sh(F))
                 self._fwd(blk.conv1, ce1, x1a)
-                ce_e = self.buf(f"{n}/ce_e", (R, blk.linear.g.CI))
-                ops.concat_elu_fwd(extra_a, extra_b, None, ce_e)
+                if ce_e_alias is not None and extra_b is None and ce_e_alias.numel() == R * blk.linear.g.CI:
+                    ce_e = ce_e_alias.view(R, blk.linear.g.CI)   # concat_elu(extra_a) already exists: see the down pass below
+                else:
+                    ce_e = self.buf(f"{n}/ce_e", (R, blk.linear.g.CI))
+                    ops.concat_elu_fwd(extra_a, extra_b, None, ce_e)
+                self._ce_e[blk.group] = ce_e
                 self._fwd(blk.linear, ce_e, x1.view(R, F), res=x1a.view(R, F))
             drop = None
             if rate > 0.0:
@@ -212,6 +225,7 @@ class PixelCNN(Module):
             if ce_next is not None and ops.gate_fwd_ce_ok(y, hp, input_x, out, ce_next):
                 ops.gate_fwd_ce(y, hp, input_x, out, ce_next, P)
                 have_ce1.add(follower.name)
+                ce_of[out.data_ptr()] = ce_next
             else:
                 ops.gate_fwd(y, hp, input_x, out, P)
             self._drops.append(drop)
@@ -359,7 +373,7 @@ class PixelCNN(Module):
         dx1 = self.buf(f"{n}/dx1", sh(F))
         ops.concat_elu_bwd(x1, None, self._drops[blk.group], dce2, dx1, None, accumulate=False)
         if blk.linear is not None:
-            ce_e = self.buf(f"{n}/ce_e", (R, blk.linear.g.CI))
+            ce_e = self._ce_e[blk.group]              # its own buffer, or the next vertical block's ce1 (forward pass)
             self._wg(blk.linear, ce_e, dx1.view(R, F))
             dce_e = self.buf(f"{n}/dce_e", (R, blk.linear.g.CI))
             self._dg(blk.linear, dx1.view(R, F), dce_e)
