@@ -1216,6 +1216,10 @@ bool plan_skinny(const Geom& g, int groups) {
     static const bool off = getenv("PM_NO_SKINNY") != nullptr;         // A/B switch for measurements
     if (off || groups != 1 || g.d != 1 || g.OH != 1 || g.OW != 1 || g.C % 8 != 0 || g.in_act != PM_ACT_NONE) return false;
     if (g.M > 512 || g.KH * g.KW * g.C < 512) return false;
+    // wide outputs (the partial encoder's 512 -> 32768 data gradient at the CelebA size: 2048 workgroups that each re-read the
+    // 16 rows and meet in LDS for two k-steps per wave - 99 us for 67 MB of weights) stream better through the direct form
+    static const int max_n = getenv("PM_SKINNY_MAXN") ? atoi(getenv("PM_SKINNY_MAXN")) : 2048;      // A/B knob
+    if (g.N > max_n) return false;
     const int y0 = g.off, y1 = g.off + (g.KH - 1) * g.cs, x0 = g.offx, x1 = g.offx + (g.KW - 1) * g.cs;
     if (y0 < 0 || y1 < 0 || y0 >= g.IH || y1 >= g.IH || x0 < 0 || x1 < 0 || x0 >= g.IW || x1 >= g.IW) return false;
     return true;
