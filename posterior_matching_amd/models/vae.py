@@ -37,7 +37,10 @@ class PosteriorMatchingVAE(Module):
         # encoder layers whose weight gradient stays on the main stream although "enc" is lent: the first layer's (the LAST of
         # the backward pass, a thin lane kernel) - with it lent the side queue ends ~45 us behind the main one
         # (profiles/r04_stamp_timeline_pm_vae.txt); same-box pairs 1.376 / 1.360 vs 1.381 / 1.389 ms
-        self.enc_keep_wgrad = "0"
+        # (after the decoder's five bias-gradient launches became one - pm_colsum_part_multi - the main queue had room for one
+        # more: layers 0 AND 4 kept: 1.310 / 1.315 / 1.318 / 1.320 vs 1.327 / 1.346 / 1.331 / 1.332 ms, four same-box pairs,
+        # profiles/r04_ab_enc_keep.txt; "4" alone, "0,1,4", "0,3,4", "0,2", "0,1": no better than "0")
+        self.enc_keep_wgrad = "0,4"
         self.store: Optional[ParamStore] = None
         if not isinstance(posterior_dist, (TriLGaussian, DiagonalGaussian)):
             raise NotImplementedError("posterior_dist must be TriLGaussian or DiagonalGaussian")
