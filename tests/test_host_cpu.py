@@ -491,3 +491,28 @@ def test_planners_and_argument_checks_without_a_gpu():
     bad.C = 0
     assert lib.pm_wgrad_part_slots(C.byref(bad), aligned, aligned, 0, 1, 1, C.byref(n)) != 0
     assert lib.pm_gather_gemm_bf16(None, C.byref(bad), aligned, aligned, None, None, None, aligned) != 0
+    # second half of round 4: split-K slab planning, the fixed-order reductions' scratch sizes, the batching entry points
+    nf = C.c_longlong(-1)
+    d = LayerGeom.dense(2048, 512)._desc(64, "fwd")                 # 8 tiles, 64 k-chunks: splits K
+    assert lib.pm_gemm_splitk_floats(C.byref(d), 0, 1, C.byref(nf)) == 0 and nf.value == 16 * 64 * 512
+    d = LayerGeom.conv(8, 8, 256, 256, 3, 1, "SAME")._desc(16, "fwd")
+    assert lib.pm_gemm_splitk_floats(C.byref(d), 1, 1, C.byref(nf)) == 0 and nf.value % (16 * 64 * 256) == 0 and nf.value > 0
+    d = LayerGeom.dense(256, 256)._desc(8192, "fwd")                # fills the chip: no split
+    assert lib.pm_gemm_splitk_floats(C.byref(d), 0, 1, C.byref(nf)) == 0 and nf.value == 0
+    assert lib.pm_gemm_splitk_floats(C.byref(d), 0, 1, None) != 0
+    assert lib.pm_gather_gemm_sk(None, C.byref(d), aligned, aligned, None, None, None, aligned, None, 0) != 0      # no scratch
+    assert lib.pm_gather_gemm_bf16_sk(None, C.byref(d), aligned, aligned, None, None, None, aligned, None, 0, None, 0) != 0
+    assert lib.pm_vq_dw_exact_floats(12544, 64, 256, C.byref(nf)) == 0 and nf.value == 7 * 64 * 256    # ceil(N / 2048) segments
+    assert lib.pm_vq_dw_exact_floats(1000, 64, 256, C.byref(nf)) == 0 and nf.value == 0               # one segment: no scratch
+    assert lib.pm_vq_dw_exact_floats(1000, 2048, 256, C.byref(nf)) != 0                               # D <= 1024
+    assert lib.pm_vq_dw_exact(None, aligned, aligned, aligned, 12544, 64, 256, None, 0) != 0          # scratch missing
+    assert lib.pm_embed_bwd_sorted(None, aligned, aligned, aligned, 4096, 128, 512, aligned, 10) != 0   # scratch too small
+    assert lib.pm_normal_ll_bwd_det(None, aligned, aligned, aligned, aligned, aligned, aligned, 8, 4, 0.0, None) != 0
+    assert lib.pm_rows_sum_multi(None, None, 3, aligned, 16, 256, 256) != 0
+    ptrs = (C.c_void_p * 65)(*[1 << 20] * 65)
+    assert lib.pm_rows_sum_multi(None, ptrs, 65, aligned, 16, 256, 256) != 0                            # <= 64 tensors
+    jobs = (_lib.ColsumJob * 2)()
+    for j in jobs:
+        j.x, j.part, j.part_stride, j.M, j.N, j.nslots = 1 << 20, 1 << 20, 32, 256 * 784, 32, 1         # wrong slot count
+    assert lib.pm_colsum_part_multi(None, jobs, 2) != 0
+    assert lib.pm_colsum_part_multi(None, jobs, 9) != 0 and lib.pm_colsum_part_multi(None, None, 1) != 0
